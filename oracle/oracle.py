@@ -1,0 +1,322 @@
+"""ctypes bindings for the CPU checkers under oracle/ -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+  * ``Oracle``  -> oracle/libsvs_oracle.so   (plain-C restatement, svs_oracle.c)
+  * ``Ref``     -> oracle/_ref/libsvs_ref.so (the reference's own headers, ref_driver.cpp); optional.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+F32, F16, I8, U8 = 0, 1, 2, 3
+L2, IP, COS = 0, 1, 2
+NP_DTYPES = {F32: np.float32, F16: np.float16, I8: np.int8, U8: np.uint8}
+
+
+def dtype_code(arr: np.ndarray) -> int:
+    for code, dt in NP_DTYPES.items():
+        if arr.dtype == dt:
+            return code
+    raise TypeError(f"unsupported dtype {arr.dtype}")
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement (and oracle/_ref when the reference tree is present)."""
+    so = os.path.join(HERE, "libsvs_oracle.so")
+    srcs = [os.path.join(HERE, f) for f in ("svs_oracle.c", "svs_oracle_build.c", "svs_oracle.h")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", HERE, "libsvs_oracle.so"])
+    ref_so = os.path.join(HERE, "_ref", "libsvs_ref.so")
+    if os.path.isdir("/root/reference/include/svs"):
+        drv = os.path.join(HERE, "ref_driver.cpp")
+        if force or not os.path.exists(ref_so) or os.path.getmtime(drv) > os.path.getmtime(ref_so):
+            subprocess.check_call(["make", "-C", HERE, "ref"])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _Index(C.Structure):
+    _fields_ = [
+        ("metric", C.c_int), ("data_dtype", C.c_int), ("n", C.c_size_t), ("d", C.c_size_t),
+        ("data", C.c_void_p), ("graph", C.c_void_p), ("graph_stride", C.c_size_t),
+        ("entry_points", C.c_void_p), ("n_entry", C.c_size_t),
+        ("sq_enabled", C.c_int), ("sq_scale", C.c_float), ("sq_bias", C.c_float),
+    ]
+
+
+class _Neighbor(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("dist", C.c_float), ("visited", C.c_uint8)]
+
+
+class _Buffer(C.Structure):
+    _fields_ = [
+        ("greater", C.c_int), ("size", C.c_size_t), ("best_unvisited", C.c_size_t), ("window", C.c_size_t),
+        ("capacity", C.c_size_t), ("e", C.POINTER(_Neighbor)), ("filter", C.c_void_p),
+    ]
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        self.lib = C.CDLL(os.path.join(HERE, "libsvs_oracle.so"))
+        L = self.lib
+        L.svso_norm.restype = C.c_float
+        L.svso_norm.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        L.svso_distance.restype = C.c_float
+        L.svso_distance.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.POINTER(C.c_int)]
+        L.svso_distance_batch.restype = C.c_int
+        L.svso_distance_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.svso_search_batch.restype = C.c_int
+        L.svso_search_batch.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svso_flat_search.restype = C.c_int
+        L.svso_flat_search.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.svso_build_vamana.restype = C.c_int
+        L.svso_build_vamana.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.svso_k_recall_at_n.restype = C.c_double
+        L.svso_k_recall_at_n.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+        L.svso_sq_params.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.svso_sq_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.svso_half_to_float.restype = C.c_float
+        L.svso_half_to_float.argtypes = [C.c_uint16]
+        L.svso_float_to_half.restype = C.c_uint16
+        L.svso_float_to_half.argtypes = [C.c_float]
+        L.svso_buffer_init.argtypes = [C.POINTER(_Buffer), C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        L.svso_buffer_insert.restype = C.c_size_t
+        L.svso_buffer_insert.argtypes = [C.POINTER(_Buffer), C.c_uint32, C.c_float]
+        L.svso_buffer_push_back.argtypes = [C.POINTER(_Buffer), C.c_uint32, C.c_float]
+        L.svso_buffer_next.restype = _Neighbor
+        L.svso_buffer_next.argtypes = [C.POINTER(_Buffer)]
+        for f in ("svso_buffer_free", "svso_buffer_clear", "svso_buffer_sort"):
+            getattr(L, f).argtypes = [C.POINTER(_Buffer)]
+        L.svso_buffer_done.argtypes = [C.POINTER(_Buffer)]
+        L.svso_filter_emplace.argtypes = [C.c_void_p, C.c_uint32]
+        L.svso_filter_contains.argtypes = [C.c_void_p, C.c_uint32]
+        L.svso_filter_reset.argtypes = [C.c_void_p]
+
+    # -- distances -------------------------------------------------------------------------------------------
+    def norm(self, x: np.ndarray) -> float:
+        x = np.ascontiguousarray(x)
+        return float(self.lib.svso_norm(_ptr(x), dtype_code(x), x.size))
+
+    def distance_batch(self, metric: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a)
+        b = np.ascontiguousarray(b)
+        assert a.shape[1] == b.shape[1]
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        rc = self.lib.svso_distance_batch(metric, _ptr(a), dtype_code(a), a.shape[0], _ptr(b), dtype_code(b), b.shape[0], a.shape[1], _ptr(out))
+        if rc:
+            raise ValueError(f"unsupported type pair ({a.dtype}, {b.dtype})")
+        return out
+
+    # -- index helpers ---------------------------------------------------------------------------------------
+    def _index(self, metric, data, graph, entry, sq=None):
+        data = np.ascontiguousarray(data)
+        graph = np.ascontiguousarray(graph, dtype=np.uint32)
+        entry = np.ascontiguousarray(entry, dtype=np.uint32)
+        ix = _Index(metric, dtype_code(data), data.shape[0], data.shape[1], data.ctypes.data, graph.ctypes.data,
+                    graph.shape[1], entry.ctypes.data, entry.size, 0, 0.0, 0.0)
+        if sq is not None:
+            ix.sq_enabled, ix.sq_scale, ix.sq_bias = 1, sq[0], sq[1]
+        return ix, (data, graph, entry)
+
+    def search(self, metric, data, graph, entry, queries, k, window, capacity=None, visited_set=False, sq=None, stats=False):
+        capacity = window if capacity is None else capacity
+        ix, keep = self._index(metric, data, graph, entry, sq)
+        queries = np.ascontiguousarray(queries)
+        nq = queries.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32)
+        st = np.zeros((nq, 3), np.uint64)
+        rc = self.lib.svso_search_batch(C.byref(ix), _ptr(queries), dtype_code(queries), nq, k, window, capacity, int(visited_set), _ptr(ids), _ptr(dists), _ptr(st))
+        if rc:
+            raise ValueError(f"svso_search_batch failed rc={rc}")
+        return (ids, dists, st) if stats else (ids, dists)
+
+    def flat_search(self, metric, data, queries, k, sq=None):
+        graph = np.zeros((1, 1), np.uint32)
+        ix, keep = self._index(metric, data, graph, np.zeros(1, np.uint32), sq)
+        queries = np.ascontiguousarray(queries)
+        nq = queries.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32)
+        rc = self.lib.svso_flat_search(C.byref(ix), _ptr(queries), dtype_code(queries), nq, k, _ptr(ids), _ptr(dists))
+        if rc:
+            raise ValueError(f"svso_flat_search failed rc={rc}")
+        return ids, dists
+
+    def build_vamana(self, metric, data, R, L, C_pool=750, prune_to=None, alpha=None):
+        data = np.ascontiguousarray(data)
+        n, d = data.shape
+        prune_to = R if prune_to is None else prune_to
+        if alpha is None:
+            alpha = 1.2 if metric == L2 else 0.95
+        graph = np.zeros((n, R + 1), np.uint32)
+        entry = C.c_uint32(0)
+        rc = self.lib.svso_build_vamana(metric, dtype_code(data), _ptr(data), n, d, R, L, C_pool, prune_to, alpha, _ptr(graph), C.byref(entry))
+        if rc:
+            raise ValueError("svso_build_vamana failed")
+        return graph, np.array([entry.value], np.uint32)
+
+    def recall(self, gt, res, k, n):
+        gt = np.ascontiguousarray(gt, dtype=np.uint32)
+        res = np.ascontiguousarray(res, dtype=np.uint32)
+        return float(self.lib.svso_k_recall_at_n(_ptr(gt), gt.shape[1], _ptr(res), res.shape[1], gt.shape[0], k, n))
+
+    def sq_compress(self, data: np.ndarray, code_dtype=I8):
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        scale, bias = C.c_float(), C.c_float()
+        self.lib.svso_sq_params(_ptr(data), data.shape[0], data.shape[1], code_dtype, C.byref(scale), C.byref(bias))
+        codes = np.empty(data.shape, NP_DTYPES[code_dtype])
+        self.lib.svso_sq_compress(_ptr(data), data.size, code_dtype, scale, bias, _ptr(codes))
+        return codes, float(scale.value), float(bias.value)
+
+    # -- search buffer (op-by-op) ----------------------------------------------------------------------------
+    def buffer(self, window, capacity, greater=False, visited_set=False):
+        return OracleBuffer(self, window, capacity, greater, visited_set)
+
+
+class OracleBuffer:
+    def __init__(self, oracle, window, capacity, greater, visited_set):
+        self.L = oracle.lib
+        self.b = _Buffer()
+        if self.L.svso_buffer_init(C.byref(self.b), window, capacity, int(greater), int(visited_set)):
+            raise ValueError("window > capacity")
+
+    def __del__(self):
+        self.L.svso_buffer_free(C.byref(self.b))
+
+    def clear(self): self.L.svso_buffer_clear(C.byref(self.b))
+    def push_back(self, i, d): self.L.svso_buffer_push_back(C.byref(self.b), i, d)
+    def sort(self): self.L.svso_buffer_sort(C.byref(self.b))
+    def insert(self, i, d): return self.L.svso_buffer_insert(C.byref(self.b), i, d)
+    def done(self): return bool(self.L.svso_buffer_done(C.byref(self.b)))
+    def next(self):
+        n = self.L.svso_buffer_next(C.byref(self.b))
+        return n.id, n.dist
+    def size(self): return self.b.size
+    def best_unvisited(self): return self.b.best_unvisited
+    def get(self, i): return self.b.e[i].id, self.b.e[i].dist, bool(self.b.e[i].visited)
+    def emplace_visited(self, i): return bool(self.b.filter and self.L.svso_filter_emplace(self.b.filter, i))
+    def state(self): return [self.get(i) for i in range(self.size())]
+
+
+class Ref:
+    """The reference's own headers (oracle/_ref/libsvs_ref.so).  ``Ref.available()`` is False when the prebuilt
+    file is missing or the host CPU lacks AVX-512 (F/BW/VNNI)."""
+
+    _path = os.path.join(HERE, "_ref", "libsvs_ref.so")
+
+    @classmethod
+    def available(cls) -> bool:
+        try:
+            flags = open("/proc/cpuinfo").read()
+        except OSError:
+            return False
+        if not all(f in flags for f in ("avx512f", "avx512bw", "avx512vl", "avx512_vnni")):
+            return False
+        build()
+        return os.path.exists(cls._path)
+
+    def __init__(self):
+        if not self.available():
+            raise RuntimeError("oracle/_ref/libsvs_ref.so unavailable")
+        self.lib = C.CDLL(self._path)
+        L = self.lib
+        L.svsref_norm.restype = C.c_float
+        L.svsref_norm.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        L.svsref_distance_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.svsref_search_batch.restype = C.c_int
+        L.svsref_search_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svsref_buffer_new.restype = C.c_void_p
+        L.svsref_buffer_new.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        for f in ("free", "clear", "sort"):
+            getattr(L, "svsref_buffer_" + f).argtypes = [C.c_void_p]
+        L.svsref_buffer_push_back.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+        L.svsref_buffer_insert.restype = C.c_size_t
+        L.svsref_buffer_insert.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+        L.svsref_buffer_done.argtypes = [C.c_void_p]
+        L.svsref_buffer_next.restype = C.c_uint32
+        L.svsref_buffer_next.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.svsref_buffer_size.restype = C.c_size_t
+        L.svsref_buffer_size.argtypes = [C.c_void_p]
+        L.svsref_buffer_best_unvisited.restype = C.c_size_t
+        L.svsref_buffer_best_unvisited.argtypes = [C.c_void_p]
+        L.svsref_buffer_get.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.svsref_buffer_emplace_visited.argtypes = [C.c_void_p, C.c_uint32]
+        L.svsref_filter_new.restype = C.c_void_p
+        for f in ("free", "reset"):
+            getattr(L, "svsref_filter_" + f).argtypes = [C.c_void_p]
+        L.svsref_filter_emplace.argtypes = [C.c_void_p, C.c_uint32]
+        L.svsref_filter_contains.argtypes = [C.c_void_p, C.c_uint32]
+        L.svsref_half_to_float_hw.restype = C.c_float
+        L.svsref_half_to_float_hw.argtypes = [C.c_uint16]
+
+    def norm(self, x):
+        x = np.ascontiguousarray(x)
+        return float(self.lib.svsref_norm(_ptr(x), dtype_code(x), x.size))
+
+    def distance_batch(self, metric, a, b):
+        a = np.ascontiguousarray(a)
+        b = np.ascontiguousarray(b)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        self.lib.svsref_distance_batch(metric, _ptr(a), dtype_code(a), a.shape[0], _ptr(b), dtype_code(b), b.shape[0], a.shape[1], _ptr(out))
+        return out
+
+    def search(self, metric, data, graph, entry, queries, k, window, capacity=None, visited_set=False, nthreads=1, stats=False):
+        capacity = window if capacity is None else capacity
+        data = np.ascontiguousarray(data)
+        graph = np.ascontiguousarray(graph, dtype=np.uint32)
+        entry = np.ascontiguousarray(entry, dtype=np.uint32)
+        queries = np.ascontiguousarray(queries)
+        nq = queries.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32)
+        st = np.zeros((nq, 2), np.uint64)
+        rc = self.lib.svsref_search_batch(metric, dtype_code(data), _ptr(data), data.shape[0], data.shape[1], _ptr(graph), graph.shape[1],
+                                          _ptr(entry), entry.size, _ptr(queries), dtype_code(queries), nq, k, window, capacity,
+                                          int(visited_set), nthreads, _ptr(ids), _ptr(dists), _ptr(st))
+        if rc:
+            raise ValueError(f"svsref_search_batch rc={rc}")
+        return (ids, dists, st) if stats else (ids, dists)
+
+    def buffer(self, window, capacity, greater=False, visited_set=False):
+        return RefBuffer(self, window, capacity, greater, visited_set)
+
+
+class RefBuffer:
+    def __init__(self, ref, window, capacity, greater, visited_set):
+        self.L = ref.lib
+        self.p = self.L.svsref_buffer_new(window, capacity, int(greater), int(visited_set))
+        if not self.p:
+            raise ValueError("window > capacity")
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.svsref_buffer_free(self.p)
+
+    def clear(self): self.L.svsref_buffer_clear(self.p)
+    def push_back(self, i, d): self.L.svsref_buffer_push_back(self.p, i, d)
+    def sort(self): self.L.svsref_buffer_sort(self.p)
+    def insert(self, i, d): return self.L.svsref_buffer_insert(self.p, i, d)
+    def done(self): return bool(self.L.svsref_buffer_done(self.p))
+    def next(self):
+        d = C.c_float()
+        i = self.L.svsref_buffer_next(self.p, C.byref(d))
+        return i, d.value
+    def size(self): return self.L.svsref_buffer_size(self.p)
+    def best_unvisited(self): return self.L.svsref_buffer_best_unvisited(self.p)
+    def get(self, i):
+        a, b, c = C.c_uint32(), C.c_float(), C.c_int()
+        self.L.svsref_buffer_get(self.p, i, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, bool(c.value)
+    def emplace_visited(self, i): return bool(self.L.svsref_buffer_emplace_visited(self.p, i))
+    def state(self): return [self.get(i) for i in range(self.size())]
