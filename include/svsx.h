@@ -1,0 +1,171 @@
+/*
+ * svsx.h -- C ABI of the MI355X-native batched Vamana greedy-search path.
+ *
+ * This is the drop-in boundary: a plain `extern "C"` shared library (libsvsx.so) with host- and
+ * device-pointer entry points, no C++/torch types in any signature.  Each entry point names the reference
+ * interface (intel/ScalableVectorSearch 0.4.0, paths relative to the reference root) it stands behind;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Semantics are those of the reference CPU path: results (neighbour ids AND distance bits) are identical to
+ * `svs::index::vamana::VamanaIndex::search` on the same graph/data/queries/parameters, for the type pairs the
+ * reference has AVX-512 kernels for.
+ *
+ * Threading: an index is immutable after creation; `svsx_search*` may be called concurrently from several
+ * host threads on the same index (index/vamana/index.h:541-545 contract).  `svsx_last_error` is thread-local.
+ */
+#ifndef SVSX_H
+#define SVSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bindings/cpp/include/svs/runtime/api_defs.h:110-117  (enum class ErrorCode) */
+typedef enum {
+    SVSX_SUCCESS = 0,
+    SVSX_UNKNOWN_ERROR = 1,
+    SVSX_INVALID_ARGUMENT = 2,
+    SVSX_NOT_IMPLEMENTED = 3,
+    SVSX_NOT_INITIALIZED = 4,
+    SVSX_RUNTIME_ERROR = 5
+} svsx_status;
+
+/* svs::DistanceType (core/distance.h) / runtime MetricType (api_defs.h:95).  The distance functors these
+ * select are DistanceL2 (euclidean.h:142-166), DistanceIP (inner_product.h:103-127),
+ * DistanceCosineSimilarity (cosine.h:102-144). */
+typedef enum { SVSX_L2 = 0, SVSX_IP = 1, SVSX_COSINE = 2 } svsx_metric;
+
+/* svs::DataType subset with AVX-512 kernels (lib/datatype.h): float32, float16, int8, uint8 */
+typedef enum { SVSX_F32 = 0, SVSX_F16 = 1, SVSX_I8 = 2, SVSX_U8 = 3 } svsx_dtype;
+
+typedef struct svsx_index svsx_index;
+
+/* What VamanaIndex is assembled from (index/vamana/index.h:363-377, auto_assemble :1017-1046):
+ *   data   SimpleData<T>        row-major n x d                (core/data/simple.h:259-618)
+ *   graph  SimpleGraph<uint32>  n rows of graph_row_stride u32, row[0]=degree, row[1..deg]=neighbour ids
+ *                               (core/graph/graph.h:32-48)
+ *   entry points                (index.h:304,446-452)
+ *   SQDataset<T> scale/bias     (quantization/scalar/scalar.h:363-534) when sq_enabled
+ * Host buffers are copied (and re-laid-out) into HBM; they may be freed after the call returns. */
+typedef struct {
+    int metric;                     /* svsx_metric */
+    int data_dtype;                 /* svsx_dtype  */
+    size_t n, d;
+    const void* data;
+    size_t data_row_stride_bytes;   /* 0 = dense (d * sizeof(T)) */
+    const uint32_t* graph;
+    size_t graph_row_stride_u32;    /* = max_degree + 1 in SVS files */
+    uint32_t max_degree;
+    const uint32_t* entry_points;
+    size_t n_entry;
+    int sq_enabled;                 /* data holds SQ codes (int8/uint8) with one global scale/bias */
+    float sq_scale, sq_bias;
+    int device;                     /* HIP device ordinal */
+    uint64_t id_offset;             /* added to every returned id (database shard base) */
+} svsx_index_desc;
+
+/* Adopt arrays that already live in HBM in the device layout (no copy, not owned):
+ *   data   n rows of data_row_stride_bytes (multiple of 16), element j of row i at i*stride + j*sizeof(T)
+ *   graph  n rows of graph_row_stride_u32 ids (multiple of 16), unused slots = 0xFFFFFFFF, no degree slot
+ * Used by the GPU graph builder, which rewrites the graph between search batches. */
+typedef struct {
+    int metric;
+    int data_dtype;
+    size_t n, d;
+    const void* d_data;
+    size_t data_row_stride_bytes;
+    const uint32_t* d_graph;
+    size_t graph_row_stride_u32;
+    const uint32_t* d_entry_points;
+    size_t n_entry;
+    int sq_enabled;
+    float sq_scale, sq_bias;
+    int device;
+    uint64_t id_offset;
+} svsx_device_index_desc;
+
+/* VamanaSearchParameters (index/vamana/search_params.h:28-61) /
+ * runtime VamanaSearchParameters (bindings/cpp/include/svs/runtime/vamana_index.h:37-44).
+ * prefetch_* are accepted for source compatibility; on the GPU latency is hidden by wave occupancy. */
+typedef struct {
+    size_t search_window_size;      /* SearchBufferConfig window   (search_buffer.h:39-96) */
+    size_t search_buffer_capacity;  /* SearchBufferConfig capacity; 0 = same as window     */
+    int visited_set;                /* search_buffer_visited_set_: result-neutral on both sides */
+    size_t prefetch_lookahead;
+    size_t prefetch_step;
+} svsx_search_params;
+
+/* Optional side outputs of a search (device pointers for svsx_search_device, host for svsx_search).
+ *   stats        nq x 4 u32: {expansions, neighbour slots, distance evaluations, accepted inserts}
+ *                = the GreedySearchTracker counts of greedy_search.h:165 / search_tracker.h:29-62
+ *   history_*    per query, the expanded nodes in order (id, distance) -- the builder's
+ *                use_full_search_history pool (vamana_build.h:54-91); history_len may exceed history_cap. */
+typedef struct {
+    uint32_t* stats;
+    uint32_t* history_ids;
+    float* history_dists;
+    uint32_t* history_len;
+    size_t history_cap;
+    size_t query_row_stride_bytes;  /* 0 = dense */
+} svsx_search_aux;
+
+/* auto_assemble / VamanaIndex ctor (index/vamana/index.h:363-377,1017-1046);
+ * runtime VamanaIndex::build/load -> out-param (runtime/vamana_index.h:111-120) */
+int svsx_index_create(const svsx_index_desc* desc, svsx_index** out);
+int svsx_index_create_device_view(const svsx_device_index_desc* desc, svsx_index** out);
+/* runtime VamanaIndex::destroy (runtime/vamana_index.h:111-120) */
+void svsx_index_destroy(svsx_index* index);
+
+/* Batch search, host pointers, synchronous.
+ *   VamanaIndex::search(QueryResultView<I>, queries, VamanaSearchParameters, cancel)  index/vamana/index.h:564-611
+ *   runtime VamanaIndex::search(n, x, k, distances, labels, params, filter)           runtime/vamana_index.h:75-83
+ * ids64 (size_t labels as in QueryResult<size_t>, core/query_result.h:53-172) and/or ids32 may be NULL.
+ * Rows with fewer than k results are padded with id = all-ones, dist = +inf (vamana_index_impl.h:205-209).
+ * If capacity < k both window and capacity are raised to k (index.h:590-592).
+ * Errors: k == 0, window > capacity (search_buffer.h:84-93), unsupported (query, data) type pair
+ * -> SVSX_INVALID_ARGUMENT; NULL index -> SVSX_NOT_INITIALIZED (vamana_index_impl.h:115-130). */
+int svsx_search(
+    const svsx_index* index, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux
+);
+
+/* Same, everything already resident in HBM; enqueued on `hip_stream` (hipStream_t, NULL = default stream),
+ * returns without synchronising. */
+int svsx_search_device(
+    const svsx_index* index, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    uint64_t* d_ids64, uint32_t* d_ids32, float* d_dists, const svsx_search_aux* d_aux, void* hip_stream
+);
+
+/* Distance plugin surface: out[i*nb+j] = distance::compute(f, a_i, b_j) after f.fix_argument(a_i)
+ * (concepts/distance.h:88-128; euclidean.h:191-200, inner_product.h:152-161, cosine.h:171-181).
+ * Host pointers, synchronous. */
+int svsx_distance_batch(
+    int metric, int a_dtype, int b_dtype, size_t d, const void* a, size_t na, const void* b, size_t nb, float* out,
+    int device
+);
+
+/* Multi-shard merge (new, no reference counterpart): per query, S sorted lists of k
+ * (dist, id) -> best k overall with the metric's comparator; ties broken by lower shard then position.
+ * Device pointers: dists/ids laid out [S][nq][k]. */
+int svsx_merge_topk_device(
+    int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, const uint64_t* d_ids, float* d_out_dists,
+    uint64_t* d_out_ids, void* hip_stream
+);
+
+/* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),
+ * [5]=data row stride (bytes). */
+int svsx_index_info(const svsx_index* index, uint64_t info[6]);
+
+/* Status::message() (api_defs.h:119-184): text of the last failure on this thread. */
+const char* svsx_last_error(void);
+
+/* Library version string. */
+const char* svsx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVSX_H */

@@ -1,0 +1,107 @@
+"""Loader for libsvsx.so (the C ABI of include/svsx.h).  There is no Python or CPU fallback: if the HIP
+library is missing this raises, and every compute entry point fails loudly without a GPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvsx.so")
+
+SUCCESS, UNKNOWN_ERROR, INVALID_ARGUMENT, NOT_IMPLEMENTED, NOT_INITIALIZED, RUNTIME_ERROR = range(6)
+
+
+class SvsxError(RuntimeError):
+    """Mirrors svs::ANNException / runtime Status{code, message} (bindings/cpp/include/svs/runtime/api_defs.h:110-184)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[svsx status {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [
+        ("metric", C.c_int), ("data_dtype", C.c_int), ("n", C.c_size_t), ("d", C.c_size_t),
+        ("data", C.c_void_p), ("data_row_stride_bytes", C.c_size_t),
+        ("graph", C.c_void_p), ("graph_row_stride_u32", C.c_size_t), ("max_degree", C.c_uint32),
+        ("entry_points", C.c_void_p), ("n_entry", C.c_size_t),
+        ("sq_enabled", C.c_int), ("sq_scale", C.c_float), ("sq_bias", C.c_float),
+        ("device", C.c_int), ("id_offset", C.c_uint64),
+    ]
+
+
+class DeviceIndexDesc(C.Structure):
+    _fields_ = [
+        ("metric", C.c_int), ("data_dtype", C.c_int), ("n", C.c_size_t), ("d", C.c_size_t),
+        ("d_data", C.c_void_p), ("data_row_stride_bytes", C.c_size_t),
+        ("d_graph", C.c_void_p), ("graph_row_stride_u32", C.c_size_t),
+        ("d_entry_points", C.c_void_p), ("n_entry", C.c_size_t),
+        ("sq_enabled", C.c_int), ("sq_scale", C.c_float), ("sq_bias", C.c_float),
+        ("device", C.c_int), ("id_offset", C.c_uint64),
+    ]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [
+        ("search_window_size", C.c_size_t), ("search_buffer_capacity", C.c_size_t), ("visited_set", C.c_int),
+        ("prefetch_lookahead", C.c_size_t), ("prefetch_step", C.c_size_t),
+    ]
+
+
+class SearchAux(C.Structure):
+    _fields_ = [
+        ("stats", C.c_void_p), ("history_ids", C.c_void_p), ("history_dists", C.c_void_p), ("history_len", C.c_void_p),
+        ("history_cap", C.c_size_t), ("query_row_stride_bytes", C.c_size_t),
+    ]
+
+
+EXPORTS = [
+    "svsx_index_create", "svsx_index_create_device_view", "svsx_index_destroy", "svsx_search", "svsx_search_device",
+    "svsx_distance_batch", "svsx_merge_topk_device", "svsx_index_info", "svsx_last_error", "svsx_version",
+]
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libsvsx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "svsx.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", csrc, "-j4"])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950).  scalablevectorsearch_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        L.svsx_last_error.restype = C.c_char_p
+        L.svsx_version.restype = C.c_char_p
+        L.svsx_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
+        L.svsx_index_create_device_view.argtypes = [C.POINTER(DeviceIndexDesc), C.POINTER(C.c_void_p)]
+        L.svsx_index_destroy.argtypes = [C.c_void_p]
+        L.svsx_index_destroy.restype = None
+        L.svsx_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SearchAux)]
+        L.svsx_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SearchAux), C.c_void_p]
+        L.svsx_distance_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.svsx_merge_topk_device.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svsx_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != SUCCESS:
+        raise SvsxError(rc, lib().svsx_last_error().decode())

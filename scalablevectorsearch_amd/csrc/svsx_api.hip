@@ -1,0 +1,398 @@
+// svsx_api.hip -- host side of the C ABI declared in include/svsx.h (libsvsx.so).
+//
+// Owns the HBM-resident index (re-laid-out copies of the SVS data/graph arrays), validates arguments the way the
+// reference's runtime layer does (bindings/cpp/src/vamana_index.cpp:56-72, vamana_index_impl.h:109-138) and
+// launches the gfx950 kernels.  There is deliberately NO CPU fallback: without a HIP device every compute entry
+// point fails with SVSX_RUNTIME_ERROR.
+#include "../../include/svsx.h"
+#include "svsx_device.h"
+#include "svsx_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace svsx;
+
+struct svsx_index {
+    int metric = 0;
+    int data_dtype = 0;
+    size_t n = 0, d = 0;
+    void* d_data = nullptr;
+    size_t row_bytes = 0;
+    uint32_t* d_graph = nullptr;
+    size_t gstride = 0;
+    uint32_t* d_entry = nullptr;
+    size_t n_entry = 0;
+    int sq_enabled = 0;
+    float sq_scale = 1.0f, sq_bias = 0.0f;
+    int device = 0;
+    uint64_t id_offset = 0;
+    bool owns = true;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : dt == DT_F16 ? 2 : (dt == DT_I8 || dt == DT_U8) ? 1 : 0; }
+
+// Which kernel family serves (query dtype, data dtype) -- the reference's AVX-512 specialisation table
+// (euclidean.h:318-358 and the VNNI pairs :291-313); everything else has only a scalar loop there and is
+// rejected here.
+int select_qmode(int metric, int q_dtype, int data_dtype, int sq_enabled) {
+    if (sq_enabled) {
+        if (data_dtype != DT_I8 && data_dtype != DT_U8) return -1;
+        if (q_dtype != DT_F32 && q_dtype != DT_F16) return -1;
+        return metric == M_L2 ? QM_SQ_L2 : metric == M_IP ? QM_SQ_IP : QM_SQ_COS;
+    }
+    if ((q_dtype == DT_I8 && data_dtype == DT_I8) || (q_dtype == DT_U8 && data_dtype == DT_U8)) return QM_INT;
+    if (q_dtype == DT_F32) return QM_FLOAT;
+    if (q_dtype == DT_F16 && (data_dtype == DT_F32 || data_dtype == DT_F16)) return QM_FLOAT;
+    return -1;
+}
+
+size_t padded_row_bytes(size_t d, int dt) { return ((d + 15) & ~size_t(15)) * dtype_size(dt); }
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    ~DeviceBuffer() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+int validate_common(int metric, int dtype, size_t n, size_t d) {
+    if (metric < 0 || metric > 2) return fail(SVSX_INVALID_ARGUMENT, "unknown metric %d", metric);
+    if (dtype_size(dtype) == 0) return fail(SVSX_INVALID_ARGUMENT, "unknown data dtype %d", dtype);
+    if (n == 0 || d == 0) return fail(SVSX_INVALID_ARGUMENT, "empty dataset (n=%zu, d=%zu)", n, d);
+    if (n >= (size_t(1) << 31)) return fail(SVSX_INVALID_ARGUMENT, "n=%zu exceeds 2^31-1 ids per index (shard it)", n);
+    return SVSX_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* svsx_last_error(void) { return g_error.c_str(); }
+const char* svsx_version(void) { return "svsx 0.1.0 (gfx950)"; }
+
+int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
+    if (!desc || !out) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (int rc = validate_common(desc->metric, desc->data_dtype, desc->n, desc->d)) return rc;
+    if (!desc->data || !desc->graph || !desc->entry_points || desc->n_entry == 0)
+        return fail(SVSX_INVALID_ARGUMENT, "data, graph and at least one entry point are required");
+    if (desc->graph_row_stride_u32 < 2) return fail(SVSX_INVALID_ARGUMENT, "graph row stride must be >= 2 (degree slot + ids)");
+    if (desc->sq_enabled && desc->data_dtype != SVSX_I8 && desc->data_dtype != SVSX_U8)
+        return fail(SVSX_INVALID_ARGUMENT, "scalar-quantized data must be int8 or uint8");
+    for (size_t i = 0; i < desc->n_entry; ++i)
+        if (desc->entry_points[i] >= desc->n) return fail(SVSX_INVALID_ARGUMENT, "entry point %u out of range", desc->entry_points[i]);
+    HIP_TRY(hipSetDevice(desc->device));
+
+    svsx_index* ix = new (std::nothrow) svsx_index();
+    if (!ix) return fail(SVSX_RUNTIME_ERROR, "out of host memory");
+    ix->metric = desc->metric;
+    ix->data_dtype = desc->data_dtype;
+    ix->n = desc->n;
+    ix->d = desc->d;
+    ix->n_entry = desc->n_entry;
+    ix->sq_enabled = desc->sq_enabled;
+    ix->sq_scale = desc->sq_scale;
+    ix->sq_bias = desc->sq_bias;
+    ix->device = desc->device;
+    ix->id_offset = desc->id_offset;
+    ix->owns = true;
+
+    auto cleanup = [&](int rc) {
+        svsx_index_destroy(ix);
+        return rc;
+    };
+    // data: rows zero padded to a multiple of 16 elements (16-B aligned chunks for every lane of a row group)
+    const size_t es = dtype_size(desc->data_dtype);
+    const size_t src_stride = desc->data_row_stride_bytes ? desc->data_row_stride_bytes : desc->d * es;
+    if (src_stride < desc->d * es) return cleanup(fail(SVSX_INVALID_ARGUMENT, "data row stride smaller than a row"));
+    ix->row_bytes = padded_row_bytes(desc->d, desc->data_dtype);
+    const size_t data_bytes = ix->row_bytes * desc->n + 64; // slack
+    if (hipMalloc(&ix->d_data, data_bytes) != hipSuccess) return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMalloc(%zu) for data failed", data_bytes));
+    if (ix->row_bytes != desc->d * es) {
+        if (hipMemset(ix->d_data, 0, data_bytes) != hipSuccess) return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMemset failed"));
+    }
+    if (hipMemcpy2D(ix->d_data, ix->row_bytes, desc->data, src_stride, desc->d * es, desc->n, hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(SVSX_RUNTIME_ERROR, "copying data to the device failed"));
+
+    // graph: SVS rows -> packed rows of `gstride` ids (multiple of 16 u32 = 64 B) padded with 0xFFFFFFFF
+    size_t maxdeg = desc->max_degree ? desc->max_degree : desc->graph_row_stride_u32 - 1;
+    if (maxdeg > desc->graph_row_stride_u32 - 1) maxdeg = desc->graph_row_stride_u32 - 1;
+    ix->gstride = (maxdeg + 15) & ~size_t(15);
+    {
+        DeviceBuffer tmp;
+        const size_t src_bytes = desc->n * desc->graph_row_stride_u32 * sizeof(uint32_t);
+        if (tmp.alloc(src_bytes) != hipSuccess) return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMalloc(%zu) for graph staging failed", src_bytes));
+        if (hipMemcpy(tmp.p, desc->graph, src_bytes, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(SVSX_RUNTIME_ERROR, "copying graph to the device failed"));
+        if (hipMalloc(reinterpret_cast<void**>(&ix->d_graph), desc->n * ix->gstride * sizeof(uint32_t)) != hipSuccess)
+            return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMalloc for graph failed"));
+        if (launch_pack_graph(static_cast<const uint32_t*>(tmp.p), static_cast<uint32_t>(desc->graph_row_stride_u32), static_cast<uint32_t>(desc->n),
+                              ix->d_graph, static_cast<uint32_t>(ix->gstride), nullptr) != hipSuccess)
+            return cleanup(fail(SVSX_RUNTIME_ERROR, "graph re-layout kernel failed: %s", hipGetErrorString(hipGetLastError())));
+        if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(SVSX_RUNTIME_ERROR, "graph re-layout kernel failed"));
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&ix->d_entry), desc->n_entry * sizeof(uint32_t)) != hipSuccess)
+        return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMalloc for entry points failed"));
+    if (hipMemcpy(ix->d_entry, desc->entry_points, desc->n_entry * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(SVSX_RUNTIME_ERROR, "copying entry points failed"));
+    *out = ix;
+    return SVSX_SUCCESS;
+}
+
+int svsx_index_create_device_view(const svsx_device_index_desc* desc, svsx_index** out) {
+    if (!desc || !out) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (int rc = validate_common(desc->metric, desc->data_dtype, desc->n, desc->d)) return rc;
+    if (!desc->d_data || !desc->d_graph || !desc->d_entry_points || desc->n_entry == 0)
+        return fail(SVSX_INVALID_ARGUMENT, "device data, graph and entry points are required");
+    if (desc->data_row_stride_bytes < padded_row_bytes(desc->d, desc->data_dtype) || (desc->data_row_stride_bytes & 15))
+        return fail(SVSX_INVALID_ARGUMENT, "device rows must be padded to 16 elements and 16-byte aligned");
+    if (desc->graph_row_stride_u32 == 0 || (desc->graph_row_stride_u32 & 15))
+        return fail(SVSX_INVALID_ARGUMENT, "device graph rows must be a multiple of 16 ids");
+    svsx_index* ix = new (std::nothrow) svsx_index();
+    if (!ix) return fail(SVSX_RUNTIME_ERROR, "out of host memory");
+    ix->metric = desc->metric;
+    ix->data_dtype = desc->data_dtype;
+    ix->n = desc->n;
+    ix->d = desc->d;
+    ix->d_data = const_cast<void*>(desc->d_data);
+    ix->row_bytes = desc->data_row_stride_bytes;
+    ix->d_graph = const_cast<uint32_t*>(desc->d_graph);
+    ix->gstride = desc->graph_row_stride_u32;
+    ix->d_entry = const_cast<uint32_t*>(desc->d_entry_points);
+    ix->n_entry = desc->n_entry;
+    ix->sq_enabled = desc->sq_enabled;
+    ix->sq_scale = desc->sq_scale;
+    ix->sq_bias = desc->sq_bias;
+    ix->device = desc->device;
+    ix->id_offset = desc->id_offset;
+    ix->owns = false;
+    *out = ix;
+    return SVSX_SUCCESS;
+}
+
+void svsx_index_destroy(svsx_index* ix) {
+    if (!ix) return;
+    if (ix->owns) {
+        (void)hipSetDevice(ix->device);
+        if (ix->d_data) (void)hipFree(ix->d_data);
+        if (ix->d_graph) (void)hipFree(ix->d_graph);
+        if (ix->d_entry) (void)hipFree(ix->d_entry);
+    }
+    delete ix;
+}
+
+int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    info[0] = ix->n;
+    info[1] = ix->d;
+    info[2] = ix->row_bytes * ix->n;
+    info[3] = ix->gstride * ix->n * sizeof(uint32_t);
+    info[4] = ix->gstride;
+    info[5] = ix->row_bytes;
+    return SVSX_SUCCESS;
+}
+
+static int search_common(
+    const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    uint64_t* d_ids64, uint32_t* d_ids32, float* d_dists, const svsx_search_aux* aux, hipStream_t stream
+) {
+    size_t window = params ? params->search_window_size : 0;
+    size_t capacity = params ? params->search_buffer_capacity : 0;
+    if (capacity == 0) capacity = window;
+    if (window > capacity)
+        return fail(SVSX_INVALID_ARGUMENT, "Improper configuration for search buffer! Effective size (%zu) cannot be less than capacity (%zu).", window, capacity);
+    if (capacity < k) { // index/vamana/index.h:590-592
+        window = k;
+        capacity = k;
+    }
+    if (capacity == 0) return fail(SVSX_INVALID_ARGUMENT, "search window size must be positive");
+    if (capacity > 16000) return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu exceeds the LDS budget of one wave", capacity);
+    const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
+    if (qmode < 0)
+        return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d%s) pair", q_dtype, ix->data_dtype, ix->sq_enabled ? ", SQ" : "");
+    SearchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.data = ix->d_data;
+    a.row_bytes = ix->row_bytes;
+    a.graph = ix->d_graph;
+    a.gstride = static_cast<uint32_t>(ix->gstride);
+    a.n = static_cast<uint32_t>(ix->n);
+    a.d = static_cast<uint32_t>(ix->d);
+    a.entry = ix->d_entry;
+    a.n_entry = static_cast<uint32_t>(ix->n_entry);
+    a.sq_scale = ix->sq_scale;
+    a.sq_bias = ix->sq_bias;
+    a.id_offset = ix->id_offset;
+    a.queries = d_queries;
+    a.q_dtype = q_dtype;
+    a.q_row_bytes = (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype);
+    a.nq = static_cast<uint32_t>(nq);
+    a.window = static_cast<uint32_t>(window);
+    a.capacity = static_cast<uint32_t>(capacity);
+    a.k = static_cast<uint32_t>(k);
+    a.ids64 = d_ids64;
+    a.ids32 = d_ids32;
+    a.dists = d_dists;
+    if (aux) {
+        a.stats = aux->stats;
+        a.history_ids = aux->history_ids;
+        a.history_dists = aux->history_dists;
+        a.history_len = aux->history_len;
+        a.history_cap = static_cast<uint32_t>(aux->history_cap);
+    }
+    hipError_t e = launch_search(ix->data_dtype, ix->metric, qmode, a, stream);
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "search kernel launch failed: %s", hipGetErrorString(e));
+    return SVSX_SUCCESS;
+}
+
+static int check_search_args(const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (k == 0) return fail(SVSX_INVALID_ARGUMENT, "k must be greater than 0");
+    if (dtype_size(q_dtype) == 0) return fail(SVSX_INVALID_ARGUMENT, "unknown query dtype %d", q_dtype);
+    if (nq > 0 && !queries) return fail(SVSX_INVALID_ARGUMENT, "null queries");
+    if (nq >= (size_t(1) << 31)) return fail(SVSX_INVALID_ARGUMENT, "too many queries in one batch");
+    return SVSX_SUCCESS;
+}
+
+int svsx_search_device(
+    const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    uint64_t* d_ids64, uint32_t* d_ids32, float* d_dists, const svsx_search_aux* d_aux, void* hip_stream
+) {
+    if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k)) return rc;
+    if (nq == 0) return SVSX_SUCCESS;
+    HIP_TRY(hipSetDevice(ix->device));
+    return search_common(ix, d_queries, q_dtype, nq, k, params, d_ids64, d_ids32, d_dists, d_aux, static_cast<hipStream_t>(hip_stream));
+}
+
+int svsx_search(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux
+) {
+    if (!ix) {
+        // vamana_index_impl.h:115-123: outputs filled with the "unspecified" sentinels
+        if (dists) for (size_t i = 0; i < nq * k; ++i) dists[i] = __builtin_inff();
+        if (ids64) for (size_t i = 0; i < nq * k; ++i) ids64[i] = ~0ull;
+        if (ids32) for (size_t i = 0; i < nq * k; ++i) ids32[i] = 0xFFFFFFFFu;
+        return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    }
+    if (int rc = check_search_args(ix, queries, q_dtype, nq, k)) return rc;
+    if (nq == 0) return SVSX_SUCCESS;
+    HIP_TRY(hipSetDevice(ix->device));
+    const size_t q_stride = (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype);
+    DeviceBuffer dq, d64, d32, dd, dst, dhi, dhd, dhl;
+    HIP_TRY(dq.alloc(q_stride * nq));
+    HIP_TRY(hipMemcpy(dq.p, queries, q_stride * nq, hipMemcpyHostToDevice));
+    if (ids64) HIP_TRY(d64.alloc(nq * k * 8));
+    if (ids32) HIP_TRY(d32.alloc(nq * k * 4));
+    if (dists) HIP_TRY(dd.alloc(nq * k * 4));
+    svsx_search_aux daux;
+    memset(&daux, 0, sizeof(daux));
+    daux.query_row_stride_bytes = q_stride;
+    if (aux) {
+        daux.history_cap = aux->history_cap;
+        if (aux->stats) { HIP_TRY(dst.alloc(nq * 16)); daux.stats = static_cast<uint32_t*>(dst.p); }
+        if (aux->history_ids && aux->history_cap) { HIP_TRY(dhi.alloc(nq * aux->history_cap * 4)); daux.history_ids = static_cast<uint32_t*>(dhi.p); }
+        if (aux->history_dists && aux->history_cap) { HIP_TRY(dhd.alloc(nq * aux->history_cap * 4)); daux.history_dists = static_cast<float*>(dhd.p); }
+        if (aux->history_len) { HIP_TRY(dhl.alloc(nq * 4)); daux.history_len = static_cast<uint32_t*>(dhl.p); }
+    }
+    if (int rc = search_common(ix, dq.p, q_dtype, nq, k, params, static_cast<uint64_t*>(d64.p), static_cast<uint32_t*>(d32.p), static_cast<float*>(dd.p), &daux, nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ids64) HIP_TRY(hipMemcpy(ids64, d64.p, nq * k * 8, hipMemcpyDeviceToHost));
+    if (ids32) HIP_TRY(hipMemcpy(ids32, d32.p, nq * k * 4, hipMemcpyDeviceToHost));
+    if (dists) HIP_TRY(hipMemcpy(dists, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
+    if (aux) {
+        if (aux->stats) HIP_TRY(hipMemcpy(aux->stats, dst.p, nq * 16, hipMemcpyDeviceToHost));
+        if (daux.history_ids) HIP_TRY(hipMemcpy(aux->history_ids, dhi.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost));
+        if (daux.history_dists) HIP_TRY(hipMemcpy(aux->history_dists, dhd.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost));
+        if (aux->history_len) HIP_TRY(hipMemcpy(aux->history_len, dhl.p, nq * 4, hipMemcpyDeviceToHost));
+    }
+    return SVSX_SUCCESS;
+}
+
+int svsx_distance_batch(
+    int metric, int a_dtype, int b_dtype, size_t d, const void* a, size_t na, const void* b, size_t nb, float* out, int device
+) {
+    if (metric < 0 || metric > 2) return fail(SVSX_INVALID_ARGUMENT, "unknown metric %d", metric);
+    if (!dtype_size(a_dtype) || !dtype_size(b_dtype)) return fail(SVSX_INVALID_ARGUMENT, "unknown dtype");
+    if (d == 0) return fail(SVSX_INVALID_ARGUMENT, "d must be positive");
+    if (na == 0 || nb == 0) return SVSX_SUCCESS;
+    if (!a || !b || !out) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    const int qmode = select_qmode(metric, a_dtype, b_dtype, 0);
+    if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (%d, %d) type pair", a_dtype, b_dtype);
+    HIP_TRY(hipSetDevice(device));
+    DeviceBuffer da, db, dout;
+    const size_t a_bytes = na * d * dtype_size(a_dtype);
+    const size_t b_row = padded_row_bytes(d, b_dtype);
+    HIP_TRY(da.alloc(a_bytes));
+    HIP_TRY(db.alloc(b_row * nb + 64));
+    HIP_TRY(dout.alloc(na * nb * 4));
+    HIP_TRY(hipMemcpy(da.p, a, a_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(db.p, 0, b_row * nb + 64));
+    HIP_TRY(hipMemcpy2D(db.p, b_row, b, d * dtype_size(b_dtype), d * dtype_size(b_dtype), nb, hipMemcpyHostToDevice));
+    DistanceArgs args;
+    args.a = da.p;
+    args.b = db.p;
+    args.b_row_bytes = b_row;
+    args.a_dtype = a_dtype;
+    args.na = static_cast<uint32_t>(na);
+    args.nb = static_cast<uint32_t>(nb);
+    args.d = static_cast<uint32_t>(d);
+    args.out = static_cast<float*>(dout.p);
+    hipError_t e = launch_distance(b_dtype, metric, qmode, args, nullptr);
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "distance kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, na * nb * 4, hipMemcpyDeviceToHost));
+    return SVSX_SUCCESS;
+}
+
+int svsx_merge_topk_device(
+    int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, const uint64_t* d_ids, float* d_out_dists,
+    uint64_t* d_out_ids, void* hip_stream
+) {
+    if (metric < 0 || metric > 2) return fail(SVSX_INVALID_ARGUMENT, "unknown metric %d", metric);
+    if (n_shards == 0 || n_shards > 64) return fail(SVSX_INVALID_ARGUMENT, "n_shards must be in [1, 64]");
+    if (k == 0 || k > 65535) return fail(SVSX_INVALID_ARGUMENT, "k out of range");
+    if (nq == 0) return SVSX_SUCCESS;
+    if (!d_dists || !d_ids || !d_out_dists || !d_out_ids) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    MergeArgs a;
+    a.dists = d_dists;
+    a.ids = d_ids;
+    a.out_dists = d_out_dists;
+    a.out_ids = d_out_ids;
+    a.n_shards = static_cast<uint32_t>(n_shards);
+    a.nq = static_cast<uint32_t>(nq);
+    a.k = static_cast<uint32_t>(k);
+    hipError_t e = launch_merge(metric, a, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "merge kernel launch failed: %s", hipGetErrorString(e));
+    return SVSX_SUCCESS;
+}
+
+} // extern "C"

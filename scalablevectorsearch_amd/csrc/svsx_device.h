@@ -1,0 +1,497 @@
+// svsx_device.h -- device-side building blocks of the MI355X (gfx950) Vamana greedy-search path.
+//
+// Arithmetic contract (what makes neighbour ids AND distance bits equal to the reference CPU path):
+//   * float kernels reproduce the accumulation tree of simd::generic_simd_op with 16 float lanes
+//     (core/distance/simd_utils.h:204-252): 4 independent accumulators per lane-slot l over 64-element blocks,
+//     (s0+s1)+(s2+s3), remaining 16-blocks and the masked tail into s0, then the _mm512_reduce_add_ps tree
+//     (l,l+8) -> (l,l+4) -> (0,2),(1,3) -> final.  A group of G lanes owns one candidate row; lane `sub` owns the
+//     E = 16/G lane-slots l = E*sub .. E*sub+E-1 of EVERY 16-block, so every fma chain stays inside one lane and
+//     the tree needs only quad-local DPP exchanges.
+//   * int8/uint8 kernels are exact int32 (v_dot4), like the reference's VNNI kernels
+//     (euclidean.h:265-313, inner_product.h:222-267, cosine.h:261-326).
+//   * compiled with -ffp-contract=off: every fused op is an explicit fmaf, everything else rounds separately.
+//     sqrtf and '/' are the correctly rounded forms (-fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svsx {
+
+enum : int { DT_F32 = 0, DT_F16 = 1, DT_I8 = 2, DT_U8 = 3 };
+enum : int { M_L2 = 0, M_IP = 1, M_COS = 2 };
+// How the query is held and what epilogue applies.
+enum : int {
+    QM_FLOAT = 0,   // query widened to f32 in LDS; data T widened on load (K1-K4)
+    QM_INT = 1,     // query and data both int8 or both uint8, exact int32 (K5, K6)
+    QM_SQ_IP = 2,   // InnerProductCompressed   (quantization/scalar/scalar.h:107-153): float path + scale*ip + bias*sum(q)
+    QM_SQ_COS = 3,  // CosineSimilarityCompressed (scalar.h:155-195): decompress on load, then float cosine
+    QM_SQ_L2 = 4    // EuclideanCompressed<T>   (scalar.h:58-105): query compressed to T, scale^2 * int L2
+};
+
+constexpr uint32_t kInvalidId = 0xFFFFFFFFu;
+constexpr uint32_t kVisitedBit = 0x80000000u;
+constexpr uint32_t kIdMask = 0x7FFFFFFFu;
+
+template <typename To, typename From> __device__ __forceinline__ To bit_cast_(From v) {
+    return __builtin_bit_cast(To, v);
+}
+
+// quad-local lane exchange through DPP (no LDS traffic): lane ^ 1 and lane ^ 2.
+__device__ __forceinline__ float xor1f(float v) {
+    return bit_cast_<float>(__builtin_amdgcn_update_dpp(0, bit_cast_<int>(v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float xor2f(float v) {
+    return bit_cast_<float>(__builtin_amdgcn_update_dpp(0, bit_cast_<int>(v), 0x4E, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int xor1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ int xor2i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); }
+
+// ---------------------------------------------------------------------------------------------------------
+// element traits: E lane-slots per lane, G = 16/E lanes per candidate row, chunk = E elements per load
+template <int DT> struct Elem;
+template <> struct Elem<DT_F32> { static constexpr int E = 4, BYTES = 4; };   // 16-B loads, 4 lanes / row
+template <> struct Elem<DT_F16> { static constexpr int E = 8, BYTES = 2; };   // 16-B loads, 2 lanes / row
+template <> struct Elem<DT_I8> { static constexpr int E = 8, BYTES = 1; };    //  8-B loads, 2 lanes / row
+template <> struct Elem<DT_U8> { static constexpr int E = 8, BYTES = 1; };
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+// Load E consecutive elements and widen to f32 exactly as ConvertToFloat<16>::load does
+// (simd_utils.h:262-301: loadu / cvtph_ps / cvtep[iu]8_epi32 + cvtepi32_ps).
+template <int DT> __device__ __forceinline__ void load_chunk(const unsigned char* p, float (&out)[Elem<DT>::E]) {
+    if constexpr (DT == DT_F32) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else if constexpr (DT == DT_F16) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = static_cast<float>(v[e]);
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t w = e < 4 ? v.x : v.y;
+            const uint32_t byte = (w >> (8 * (e & 3))) & 0xFFu;
+            if constexpr (DT == DT_I8) out[e] = static_cast<float>(static_cast<int>(static_cast<int8_t>(byte)));
+            else out[e] = static_cast<float>(byte);
+        }
+    }
+}
+
+template <int E> __device__ __forceinline__ void zero_chunk(float (&x)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = 0.0f;
+}
+
+// One accumulate step of L2FloatOp / IPFloatOp / CosineFloatOp (euclidean.h:246-249, inner_product.h:205-207,
+// cosine.h:238-241).
+template <int METRIC> __device__ __forceinline__ void acc_step(float& s, float& n, float q, float x) {
+    if constexpr (METRIC == M_L2) {
+        const float c = q - x;
+        s = __builtin_fmaf(c, c, s);
+    } else {
+        s = __builtin_fmaf(q, x, s);
+        if constexpr (METRIC == M_COS) n = __builtin_fmaf(x, x, n);
+    }
+}
+
+// _mm512_reduce_add_ps over the 16 lane-slots of one row, distributed E per lane over G = 16/E adjacent lanes.
+template <int E> __device__ __forceinline__ float reduce_slots(float (&v)[E]) {
+    if constexpr (E == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] + xor2f(v[e]); // t[j] = v[j+8] + v[j]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] + xor1f(v[e]); // u[j] = t[j+4] + t[j]
+        const float w0 = v[0] + v[2];
+        const float w1 = v[1] + v[3];
+        return w0 + w1;
+    } else {
+        static_assert(E == 8, "E must be 4 or 8");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] + xor1f(v[e]); // t[j] = v[j+8] + v[j]
+        float u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = v[j + 4] + v[j];     // u[j] = t[j+4] + t[j]
+        const float w0 = u[0] + u[2];
+        const float w1 = u[1] + u[3];
+        return w0 + w1;
+    }
+}
+
+// Float-path distance of one candidate row against the query held (as f32, zero padded to 16) in LDS.
+// All 64 lanes execute this in lock-step; `active` only predicates the global loads.
+//   DS > 0: compile-time dimension (fully unrolled, all row loads issued up front); DS == 0: runtime d.
+//   DECOMP: apply the SQ decompression scale*float(v)+bias to every loaded element (scalar.h:44-46,175-184).
+template <int DT, int METRIC, int DS, bool DECOMP>
+__device__ __forceinline__ void float_row_distance(
+    const unsigned char* __restrict__ row, bool active, const float* __restrict__ qf, int d_runtime, int sub,
+    float sq_scale, float sq_bias, float& out_main, float& out_nrm
+) {
+    constexpr int E = Elem<DT>::E;
+    constexpr int CB = E * Elem<DT>::BYTES; // bytes per chunk
+    const int d = DS > 0 ? DS : d_runtime;
+    const int nb = d >> 4;
+    const int n64 = nb >> 2;
+    const unsigned char* lane_row = row + sub * CB;
+    const float* lane_q = qf + sub * E;
+
+    float s[4][E], n[4][E];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        zero_chunk<E>(s[j]);
+        zero_chunk<E>(n[j]);
+    }
+
+    auto fetch = [&](int block, float (&x)[E]) {
+        zero_chunk<E>(x);
+        if (active) load_chunk<DT>(lane_row + block * (16 * Elem<DT>::BYTES), x);
+        if constexpr (DECOMP) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float t = sq_scale * x[e];
+                x[e] = t + sq_bias;
+            }
+        }
+    };
+    auto fetch_q = [&](int block, float (&q)[E]) {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(lane_q + block * 16 + e);
+            q[e] = v.x; q[e + 1] = v.y; q[e + 2] = v.z; q[e + 3] = v.w;
+        }
+    };
+
+    int b = 0;
+    if (n64 > 0) {
+        if constexpr (DS > 0) {
+            // static: issue every load of the 64-blocks first, then the arithmetic
+            constexpr int NB64 = (DS >> 6) * 4;
+            float x[NB64 > 0 ? NB64 : 1][E];
+#pragma unroll
+            for (int i = 0; i < NB64; ++i) fetch(i, x[i]);
+#pragma unroll
+            for (int i = 0; i < NB64; ++i) {
+                float q[E];
+                fetch_q(i, q);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc_step<METRIC>(s[i & 3][e], n[i & 3][e], q[e], x[i][e]);
+            }
+            b = NB64;
+        } else {
+            for (int t = 0; t < n64; ++t) {
+                float x[4][E];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fetch(4 * t + j, x[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float q[E];
+                    fetch_q(4 * t + j, q);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc_step<METRIC>(s[j][e], n[j][e], q[e], x[j][e]);
+                }
+            }
+            b = 4 * n64;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            s[0][e] = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+            if constexpr (METRIC == M_COS) n[0][e] = (n[0][e] + n[1][e]) + (n[2][e] + n[3][e]);
+        }
+    }
+    // full-width epilogue: remaining 16-blocks into s0
+    if constexpr (DS > 0) {
+        constexpr int B0 = (DS >> 6) * 4, B1 = DS >> 4;
+        float x[(B1 - B0) > 0 ? (B1 - B0) : 1][E];
+#pragma unroll
+        for (int i = B0; i < B1; ++i) fetch(i, x[i - B0]);
+#pragma unroll
+        for (int i = B0; i < B1; ++i) {
+            float q[E];
+            fetch_q(i, q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc_step<METRIC>(s[0][e], n[0][e], q[e], x[i - B0][e]);
+        }
+        b = B1;
+    } else {
+        for (; b < nb; ++b) {
+            float x[E], q[E];
+            fetch(b, x);
+            fetch_q(b, q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc_step<METRIC>(s[0][e], n[0][e], q[e], x[e]);
+        }
+    }
+    // ragged epilogue: masked lane-slots keep their accumulator (mask3_fmadd)
+    if ((d & 15) != 0) {
+        float x[E], q[E];
+        fetch(b, x);
+        fetch_q(b, q);
+        const int first = 16 * b + sub * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float ts = s[0][e], tn = n[0][e];
+            acc_step<METRIC>(ts, tn, q[e], x[e]);
+            const bool in = (first + e) < d;
+            s[0][e] = in ? ts : s[0][e];
+            if constexpr (METRIC == M_COS) n[0][e] = in ? tn : n[0][e];
+        }
+    }
+    out_main = reduce_slots<E>(s[0]);
+    if constexpr (METRIC == M_COS) out_nrm = reduce_slots<E>(n[0]);
+    else out_nrm = 0.0f;
+}
+
+// Exact int32 sums of one row against the query bytes in LDS: ab = sum(q*x), bb = sum(x*x).
+// Rows and the LDS query are zero padded to 16 elements, 4 lanes share a row (16-B chunks, any order).
+template <int DT>
+__device__ __forceinline__ void int_row_sums(
+    const unsigned char* __restrict__ row, bool active, const uint32_t* __restrict__ qw, int d, int sub4, int& ab, int& bb
+) {
+    const int nch = (d + 15) >> 4;
+    int sab = 0, sbb = 0;
+    for (int m = sub4; m < nch; m += 4) {
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (active) x = *reinterpret_cast<const uint4*>(row + 16 * m);
+        const uint4 q = *reinterpret_cast<const uint4*>(qw + 4 * m);
+        if constexpr (DT == DT_I8) {
+            sab = __builtin_amdgcn_sdot4(q.x, x.x, sab, false);
+            sab = __builtin_amdgcn_sdot4(q.y, x.y, sab, false);
+            sab = __builtin_amdgcn_sdot4(q.z, x.z, sab, false);
+            sab = __builtin_amdgcn_sdot4(q.w, x.w, sab, false);
+            sbb = __builtin_amdgcn_sdot4(x.x, x.x, sbb, false);
+            sbb = __builtin_amdgcn_sdot4(x.y, x.y, sbb, false);
+            sbb = __builtin_amdgcn_sdot4(x.z, x.z, sbb, false);
+            sbb = __builtin_amdgcn_sdot4(x.w, x.w, sbb, false);
+        } else {
+            sab = (int)__builtin_amdgcn_udot4(q.x, x.x, (unsigned)sab, false);
+            sab = (int)__builtin_amdgcn_udot4(q.y, x.y, (unsigned)sab, false);
+            sab = (int)__builtin_amdgcn_udot4(q.z, x.z, (unsigned)sab, false);
+            sab = (int)__builtin_amdgcn_udot4(q.w, x.w, (unsigned)sab, false);
+            sbb = (int)__builtin_amdgcn_udot4(x.x, x.x, (unsigned)sbb, false);
+            sbb = (int)__builtin_amdgcn_udot4(x.y, x.y, (unsigned)sbb, false);
+            sbb = (int)__builtin_amdgcn_udot4(x.z, x.z, (unsigned)sbb, false);
+            sbb = (int)__builtin_amdgcn_udot4(x.w, x.w, (unsigned)sbb, false);
+        }
+    }
+    sab += xor1i(sab);
+    sab += xor2i(sab);
+    sbb += xor1i(sbb);
+    sbb += xor2i(sbb);
+    ab = sab;
+    bb = sbb;
+}
+
+// SQ compress (scalar.h:37-42): clamp(round((v - bias) / scale), MIN, MAX); std::round = half away from zero.
+template <int DT> __device__ __forceinline__ int sq_compress(float v, float scale, float bias) {
+    float r = roundf((v - bias) / scale);
+    constexpr float lo = DT == DT_I8 ? -128.0f : 0.0f;
+    constexpr float hi = DT == DT_I8 ? 127.0f : 255.0f;
+    r = r < lo ? lo : r;
+    r = r > hi ? hi : r;
+    return static_cast<int>(r);
+}
+
+// Per-query constants produced by fix_argument (concepts/distance.h:88-92).
+struct QueryFix {
+    float norm;    // cosine: ||q||                                (cosine.h:117-119, distance_core.h:45-66)
+    float offset;  // SQ IP: bias * sum(q)                         (scalar.h:122-130)
+    int qq;        // int L2: sum(q*q)
+};
+
+// Load query `qptr` into the wave's LDS slice and run fix_argument (greedy_search.h:140):
+//   float paths: widened exactly to f32 (zero padded to 16) in qf;  int paths: bytes (zero padded) in qw.
+template <int DT, int METRIC, int QMODE>
+__device__ __forceinline__ QueryFix prepare_query(
+    const unsigned char* __restrict__ qptr, int q_dtype, int d, int dpad, float* qf, uint32_t* qw, float sq_scale,
+    float sq_bias, uint32_t lane
+) {
+    constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    QueryFix fx;
+    fx.norm = 0.0f;
+    fx.offset = 0.0f;
+    fx.qq = 0;
+    auto query_elem = [&](int i) -> float { // exact widening of query element i
+        switch (q_dtype) {
+            case DT_F32: return reinterpret_cast<const float*>(qptr)[i];
+            case DT_F16: return static_cast<float>(reinterpret_cast<const _Float16*>(qptr)[i]);
+            case DT_I8: return static_cast<float>(static_cast<int>(reinterpret_cast<const int8_t*>(qptr)[i]));
+            default: return static_cast<float>(static_cast<unsigned>(qptr[i]));
+        }
+    };
+    if constexpr (!INTPATH) {
+        for (int i = lane; i < dpad; i += 64) qf[i] = i < d ? query_elem(i) : 0.0f;
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if constexpr (METRIC == M_COS) {
+            // norm() (distance_core.h:45-66): accum += x*x sequentially in f32, multiply and add rounded separately
+            float accum = 0.0f;
+            for (int i = 0; i < d; ++i) {
+                const float v = qf[i];
+                const float p = v * v;
+                accum = accum + p;
+            }
+            fx.norm = sqrtf(accum);
+        }
+        if constexpr (QMODE == QM_SQ_IP) {
+            // std::reduce (libstdc++ 11 <numeric>:299-309): groups of four, (q0+q1)+(q2+q3) added to the running sum
+            float init = 0.0f;
+            int i = 0;
+            for (; d - i >= 4; i += 4) {
+                const float v1 = qf[i] + qf[i + 1];
+                const float v2 = qf[i + 2] + qf[i + 3];
+                const float v3 = v1 + v2;
+                init = init + v3;
+            }
+            for (; i < d; ++i) init = init + qf[i];
+            fx.offset = sq_bias * init;
+        }
+    } else {
+        unsigned char* qb = reinterpret_cast<unsigned char*>(qw);
+        for (int i = lane; i < dpad; i += 64) {
+            int v = 0;
+            if (i < d) {
+                if constexpr (QMODE == QM_SQ_L2) v = sq_compress<DT>(query_elem(i), sq_scale, sq_bias);
+                else v = (DT == DT_I8) ? static_cast<int>(reinterpret_cast<const int8_t*>(qptr)[i]) : static_cast<int>(qptr[i]);
+            }
+            qb[i] = static_cast<unsigned char>(v);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        // sum(q*q) (exact) and, for cosine, the sequential f32 norm of the integer query
+        int part = 0;
+        for (int m = lane; m < dpad / 4; m += 64) {
+            const uint32_t w = qw[m];
+            if constexpr (DT == DT_I8) part = __builtin_amdgcn_sdot4(w, w, part, false);
+            else part = (int)__builtin_amdgcn_udot4(w, w, (unsigned)part, false);
+        }
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+        fx.qq = part;
+        if constexpr (METRIC == M_COS) {
+            float accum = 0.0f;
+            for (int i = 0; i < d; ++i) {
+                const int v = (DT == DT_I8) ? static_cast<int>(static_cast<int8_t>(qb[i])) : static_cast<int>(qb[i]);
+                accum = accum + static_cast<float>(v * v);
+            }
+            fx.norm = sqrtf(accum);
+        }
+    }
+    return fx;
+}
+
+// Final distance value for one candidate from the reduced sums.
+template <int METRIC, int QMODE>
+__device__ __forceinline__ float finish_distance(float fmain, float fnrm, int ab, int bb, const QueryFix& fx, float sq_scale) {
+    if constexpr (QMODE == QM_INT || QMODE == QM_SQ_L2) {
+        if constexpr (METRIC == M_L2) {
+            // sum((q-x)^2) == qq - 2ab + bb exactly (two's complement ring), then narrow_cast<float>
+            const int l2 = fx.qq - 2 * ab + bb;
+            const float v = static_cast<float>(l2);
+            if constexpr (QMODE == QM_SQ_L2) return (sq_scale * sq_scale) * v; // scalar.h:88-94
+            return v;
+        } else if constexpr (METRIC == M_IP) {
+            return static_cast<float>(ab);
+        } else {
+            const float b_norm = sqrtf(static_cast<float>(bb)); // cosine.h:284-287
+            return static_cast<float>(ab) / (fx.norm * b_norm);
+        }
+    } else {
+        if constexpr (METRIC == M_COS) {
+            return fmain / (sqrtf(fnrm) * fx.norm); // cosine.h:334-335
+        } else if constexpr (QMODE == QM_SQ_IP) {
+            const float t = sq_scale * fmain; // scalar.h:134-141
+            return t + fx.offset;
+        } else {
+            return fmain;
+        }
+    }
+}
+
+template <bool GREATER> __device__ __forceinline__ bool cmpf(float a, float b) { return GREATER ? (a > b) : (a < b); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Sorted candidate buffer of one query, resident in LDS, owned by ONE wavefront (search_buffer.h:104-497).
+// entry = {dist bits, id | visited<<31}; capacity+1 entries like the reference (spare slot at [capacity]).
+// LDS operations of a single wave execute in program order, so no barrier is needed; signal fences stop the
+// compiler from reordering the cross-lane dependent accesses.
+struct WaveBuffer {
+    uint2* e;
+    uint32_t size;
+    uint32_t best_unvisited;
+    uint32_t window;
+    uint32_t capacity;
+};
+
+__device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+
+// SearchBuffer::insert_inner (search_buffer.h:353-403).  d / id are wave-uniform.  Returns true if inserted.
+template <bool GREATER>
+__device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id, uint32_t lane) {
+    // position after all elements that do not compare greater (lower_bound with !cmp(d, other)) + duplicate scan
+    uint32_t pos = 0;
+    bool dup = false;
+    for (uint32_t base = 0; base < b.size; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < b.size;
+        uint2 en = make_uint2(0, 0);
+        if (valid) en = b.e[i];
+        const float ed = __uint_as_float(en.x);
+        const bool before = valid && !cmpf<GREATER>(d, ed);
+        const unsigned long long m = __ballot(before);
+        const bool same = valid && (ed == d) && ((en.y & kIdMask) == id);
+        dup = dup || (__ballot(same) != 0ull);
+        const uint32_t cnt = __popcll(m);
+        pos += cnt;
+        const uint32_t nvalid = (b.size - base) < 64u ? (b.size - base) : 64u;
+        if (cnt < nvalid) break; // sorted: nothing further can be "before"
+    }
+    if (dup) return false;
+    lds_order();
+    // unsafe_insert: copy_backward [pos, size) one slot to the right, highest chunk first
+    const uint32_t end = b.size;
+    if (end > pos) {
+        const uint32_t nchunk = (end - pos + 63u) >> 6;
+        for (int c = static_cast<int>(nchunk) - 1; c >= 0; --c) {
+            const uint32_t i = pos + (static_cast<uint32_t>(c) << 6) + lane;
+            uint2 en = make_uint2(0, 0);
+            if (i < end) en = b.e[i];
+            lds_order();
+            if (i < end) b.e[i + 1] = en;
+            lds_order();
+        }
+    }
+    if (lane == 0) b.e[pos] = make_uint2(__float_as_uint(d), id);
+    lds_order();
+    b.size = (b.size + 1 < b.capacity) ? b.size + 1 : b.capacity;
+    b.best_unvisited = pos < b.best_unvisited ? pos : b.best_unvisited;
+    return true;
+}
+
+// SearchBuffer::next (search_buffer.h:294-304): returns the node id, marks it visited, advances best_unvisited.
+__device__ __forceinline__ uint32_t wave_next(WaveBuffer& b, uint32_t lane, float& node_dist) {
+    const uint2 en = b.e[b.best_unvisited];
+    lds_order();
+    if (lane == 0) b.e[b.best_unvisited].y = en.y | kVisitedBit;
+    lds_order();
+    node_dist = __uint_as_float(en.x);
+    const uint32_t upper = b.size < b.window ? b.size : b.window;
+    uint32_t nb = b.best_unvisited + 1;
+    while (nb < upper) {
+        const uint32_t i = nb + lane;
+        bool unvisited = false;
+        if (i < upper) unvisited = (b.e[i].y & kVisitedBit) == 0u;
+        const unsigned long long m = __ballot(unvisited);
+        if (m != 0ull) {
+            nb += static_cast<uint32_t>(__builtin_ctzll(m));
+            break;
+        }
+        nb += 64;
+    }
+    b.best_unvisited = nb < upper ? nb : upper;
+    return en.y & kIdMask;
+}
+
+__device__ __forceinline__ bool wave_done(const WaveBuffer& b) {
+    const uint32_t upper = b.size < b.window ? b.size : b.window;
+    return b.best_unvisited == upper;
+}
+
+} // namespace svsx

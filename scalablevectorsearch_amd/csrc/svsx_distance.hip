@@ -1,0 +1,134 @@
+// svsx_distance.hip -- the svs::distance plugin surface as a batched kernel, the shard top-k merge and the
+// graph re-layout kernel (gfx950).
+//
+//   distance_kernel   out[i][j] = distance::compute(f, a_i, b_j) after f.fix_argument(a_i)
+//                     (concepts/distance.h:88-128; K1-K6 of SURVEY 8a) -- same device routines, hence same bits,
+//                     as the search kernel.
+//   merge_kernel      per query S-way merge of sorted (dist,id) lists (no reference counterpart).
+//   pack_graph_kernel SVS graph rows [deg, n0..] (core/graph/graph.h:32-48) -> packed rows padded with 0xFFFFFFFF.
+#include "svsx_device.h"
+#include "svsx_kernels.h"
+
+namespace svsx {
+
+template <int DT, int METRIC, int QMODE>
+__global__ __launch_bounds__(64) void distance_kernel(const DistanceArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool INTPATH = (QMODE == QM_INT);
+    constexpr int G = INTPATH ? 4 : 16 / Elem<DT>::E;
+    constexpr int RPP = 64 / G;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const int d = static_cast<int>(a.d);
+    const int dpad = (d + 15) & ~15;
+    float* qf = reinterpret_cast<float*>(smem);
+    uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
+    const size_t a_row = static_cast<size_t>(d) * (a.a_dtype == DT_F32 ? 4 : a.a_dtype == DT_F16 ? 2 : 1);
+    const unsigned char* qptr = static_cast<const unsigned char*>(a.a) + static_cast<size_t>(qi) * a_row;
+    const QueryFix fx = prepare_query<DT, METRIC, QMODE>(qptr, a.a_dtype, d, dpad, qf, qw, 1.0f, 0.0f, lane);
+    const int sub = static_cast<int>(lane) & (G - 1);
+    const uint32_t grp = lane / G;
+    const unsigned char* data = static_cast<const unsigned char*>(a.b);
+    for (uint32_t j0 = blockIdx.y * RPP; j0 < a.nb; j0 += gridDim.y * RPP) {
+        const uint32_t j = j0 + grp;
+        const bool act = j < a.nb;
+        const unsigned char* row = data + static_cast<size_t>(act ? j : 0u) * a.b_row_bytes;
+        float fmain = 0.0f, fnrm = 0.0f;
+        int ab = 0, bb = 0;
+        if constexpr (INTPATH) int_row_sums<DT>(row, act, qw, d, sub, ab, bb);
+        else float_row_distance<DT, METRIC, 0, false>(row, act, qf, d, sub, 1.0f, 0.0f, fmain, fnrm);
+        const float r = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, 1.0f);
+        if (act && sub == 0) a.out[static_cast<size_t>(qi) * a.nb + j] = r;
+    }
+}
+
+template <int DT, int QMODE> static hipError_t launch_distance_metric(int metric, const DistanceArgs& a, hipStream_t stream) {
+    const int dpad = (static_cast<int>(a.d) + 15) & ~15;
+    const size_t lds = QMODE == QM_INT ? dpad : dpad * 4;
+    uint32_t gy = (a.nb + 255) / 256;
+    if (gy == 0) gy = 1;
+    if (gy > 64) gy = 64;
+    dim3 grid(a.na, gy);
+    switch (metric) {
+        case M_L2: hipLaunchKernelGGL((distance_kernel<DT, M_L2, QMODE>), grid, dim3(64), lds, stream, a); break;
+        case M_IP: hipLaunchKernelGGL((distance_kernel<DT, M_IP, QMODE>), grid, dim3(64), lds, stream, a); break;
+        case M_COS: hipLaunchKernelGGL((distance_kernel<DT, M_COS, QMODE>), grid, dim3(64), lds, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_distance(int b_dtype, int metric, int qmode, const DistanceArgs& a, hipStream_t stream) {
+    if (qmode == QM_FLOAT) {
+        switch (b_dtype) {
+            case DT_F32: return launch_distance_metric<DT_F32, QM_FLOAT>(metric, a, stream);
+            case DT_F16: return launch_distance_metric<DT_F16, QM_FLOAT>(metric, a, stream);
+            case DT_I8: return launch_distance_metric<DT_I8, QM_FLOAT>(metric, a, stream);
+            case DT_U8: return launch_distance_metric<DT_U8, QM_FLOAT>(metric, a, stream);
+        }
+    } else if (qmode == QM_INT) {
+        if (b_dtype == DT_I8) return launch_distance_metric<DT_I8, QM_INT>(metric, a, stream);
+        if (b_dtype == DT_U8) return launch_distance_metric<DT_U8, QM_INT>(metric, a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One thread per query: S cursors over sorted lists; pick the best head, ties -> lowest shard (strict compare).
+template <bool GREATER> __global__ void merge_kernel(const MergeArgs a) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.nq) return;
+    constexpr int MAXS = 64;
+    uint16_t cur[MAXS];
+    for (uint32_t s = 0; s < a.n_shards; ++s) cur[s] = 0;
+    for (uint32_t j = 0; j < a.k; ++j) {
+        int best = -1;
+        float bd = 0.0f;
+        for (uint32_t s = 0; s < a.n_shards; ++s) {
+            if (cur[s] >= a.k) continue;
+            const size_t o = (static_cast<size_t>(s) * a.nq + q) * a.k + cur[s];
+            if (a.ids[o] == ~0ull) { cur[s] = static_cast<uint16_t>(a.k); continue; } // padded tail
+            const float dd = a.dists[o];
+            if (best < 0 || cmpf<GREATER>(dd, bd)) {
+                best = static_cast<int>(s);
+                bd = dd;
+            }
+        }
+        const size_t oo = static_cast<size_t>(q) * a.k + j;
+        if (best < 0) {
+            a.out_ids[oo] = ~0ull;
+            a.out_dists[oo] = __builtin_inff();
+        } else {
+            const size_t o = (static_cast<size_t>(best) * a.nq + q) * a.k + cur[best];
+            a.out_ids[oo] = a.ids[o];
+            a.out_dists[oo] = bd;
+            cur[best]++;
+        }
+    }
+}
+
+hipError_t launch_merge(int metric, const MergeArgs& a, hipStream_t stream) {
+    if (a.n_shards == 0 || a.n_shards > 64 || a.k > 65535) return hipErrorInvalidValue;
+    const dim3 block(128), grid((a.nq + 127) / 128);
+    if (metric == M_L2) hipLaunchKernelGGL(merge_kernel<false>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(merge_kernel<true>, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pack_graph_kernel(const uint32_t* __restrict__ in, uint32_t in_stride, uint32_t n, uint32_t* __restrict__ out, uint32_t out_stride) {
+    const uint32_t row = blockIdx.x;
+    if (row >= n) return;
+    const uint32_t* r = in + static_cast<size_t>(row) * in_stride;
+    const uint32_t deg = r[0];
+    for (uint32_t j = threadIdx.x; j < out_stride; j += blockDim.x) {
+        out[static_cast<size_t>(row) * out_stride + j] = (j < deg && j + 1 < in_stride) ? r[1 + j] : kInvalidId;
+    }
+}
+
+hipError_t launch_pack_graph(const uint32_t* d_in, uint32_t in_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_graph_kernel, dim3(n), dim3(64), 0, stream, d_in, in_stride, n, d_out, out_stride);
+    return hipGetLastError();
+}
+
+} // namespace svsx

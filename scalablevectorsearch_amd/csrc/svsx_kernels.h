@@ -1,0 +1,64 @@
+// svsx_kernels.h -- host-visible kernel argument blocks and launchers (internal to libsvsx.so).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace svsx {
+
+struct SearchArgs {
+    // index (device layout)
+    const void* data;        // n rows, row_bytes each (zero padded to 16 elements)
+    size_t row_bytes;
+    const uint32_t* graph;   // n rows of gstride ids, packed from slot 0, unused = 0xFFFFFFFF
+    uint32_t gstride;
+    uint32_t n;
+    uint32_t d;
+    const uint32_t* entry;
+    uint32_t n_entry;
+    float sq_scale, sq_bias;
+    uint64_t id_offset;
+    // queries
+    const void* queries;
+    size_t q_row_bytes;
+    int q_dtype;
+    uint32_t nq;
+    // parameters
+    uint32_t window, capacity, k;
+    // outputs
+    uint64_t* ids64;
+    uint32_t* ids32;
+    float* dists;
+    uint32_t* stats;
+    uint32_t* history_ids;
+    float* history_dists;
+    uint32_t* history_len;
+    uint32_t history_cap;
+};
+
+hipError_t launch_search(int data_dtype, int metric, int qmode, const SearchArgs& a, hipStream_t stream);
+
+struct DistanceArgs {
+    const void* a;      // na rows, dense, a_dtype
+    const void* b;      // nb rows, b_row_bytes each, zero padded to 16 elements
+    size_t b_row_bytes;
+    int a_dtype;
+    uint32_t na, nb, d;
+    float* out;         // na x nb
+};
+hipError_t launch_distance(int b_dtype, int metric, int qmode, const DistanceArgs& a, hipStream_t stream);
+
+struct MergeArgs {
+    const float* dists;     // [S][nq][k]
+    const uint64_t* ids;    // [S][nq][k]
+    float* out_dists;       // [nq][k]
+    uint64_t* out_ids;      // [nq][k]
+    uint32_t n_shards, nq, k;
+};
+hipError_t launch_merge(int metric, const MergeArgs& a, hipStream_t stream);
+
+// layout conversion kernels (index creation)
+hipError_t launch_pack_graph(const uint32_t* d_svs_graph, uint32_t svs_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, hipStream_t stream);
+
+} // namespace svsx

@@ -1,0 +1,245 @@
+// svsx_search.hip -- batched Vamana greedy search, one wavefront per query (gfx950 / CDNA4).
+//
+// Restates, wave-parallel but order-exact, the reference's per-thread loop:
+//   VamanaIndex::search batch        index/vamana/index.h:564-611
+//   per_thread_batch_search          index/vamana/extensions.h:555-592
+//   greedy_search                    index/vamana/greedy_search.h:124-203
+//   EntryPointInitializer            index/vamana/greedy_search.h:62-94
+//   SearchBuffer                     index/vamana/search_buffer.h:104-497
+//
+// Mapping to the machine:
+//   * grid = nq single-wave workgroups; the hardware dispatcher is the work queue (a CU holds up to 32 waves,
+//     each wave hides its own gather latency behind the others').
+//   * query (f32 or bytes) and the sorted candidate buffer live in the wave's LDS slice.
+//   * per expansion: one coalesced load of the padded adjacency row (lane c <- neighbour c), then passes of
+//     64/G candidate rows: G adjacent lanes stream one row with 16-B loads (row = 384 B at d=96 f32), reduce
+//     with DPP quad exchanges in the reference's exact summation tree, and the surviving candidates
+//     (ballot against the current worst) are inserted in adjacency order -> identical buffer contents to the
+//     sequential CPU loop.
+#include "svsx_device.h"
+#include "svsx_kernels.h"
+
+namespace svsx {
+
+template <int DT, int METRIC, int QMODE, int DS>
+__global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool GREATER = METRIC != M_L2;
+    constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    constexpr int G = INTPATH ? 4 : 16 / Elem<DT>::E; // lanes per candidate row
+    constexpr int RPP = 64 / G;                        // rows per pass
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const int d = DS > 0 ? DS : static_cast<int>(a.d);
+    const int dpad = (d + 15) & ~15;
+
+    WaveBuffer buf;
+    buf.e = reinterpret_cast<uint2*>(smem);
+    buf.size = 0;
+    buf.best_unvisited = 0;
+    buf.window = a.window;
+    buf.capacity = a.capacity;
+    const uint32_t buf_bytes = ((a.capacity + 1) * 8u + 15u) & ~15u;
+    float* qf = reinterpret_cast<float*>(smem + buf_bytes);          // float path: dpad f32
+    uint32_t* qw = reinterpret_cast<uint32_t*>(smem + buf_bytes);    // int path: dpad bytes
+
+    // ---- load + fix the query (maybe_fix_argument, greedy_search.h:140) -------------------------------------
+    const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
+    const QueryFix fx = prepare_query<DT, METRIC, QMODE>(qptr, a.q_dtype, d, dpad, qf, qw, a.sq_scale, a.sq_bias, lane);
+
+    const unsigned char* data = static_cast<const unsigned char*>(a.data);
+    const int sub = static_cast<int>(lane) & (G - 1);
+    const uint32_t grp = lane / G;
+
+    // distance of the candidate whose id each lane-group holds; every lane of the wave participates
+    auto group_distance = [&](uint32_t cid, bool active) -> float {
+        const unsigned char* row = data + static_cast<size_t>(active ? cid : 0u) * a.row_bytes;
+        float fmain = 0.0f, fnrm = 0.0f;
+        int ab = 0, bb = 0;
+        if constexpr (INTPATH) {
+            int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
+        } else {
+            float_row_distance<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+        }
+        return finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
+    };
+
+    uint32_t n_exp = 0, n_slots = 0, n_eval = 0, n_ins = 0;
+
+    // ---- EntryPointInitializer: distances to the entry points, push_back, sort --------------------------------
+    {
+        for (uint32_t base = 0; base < a.n_entry; base += RPP) {
+            const uint32_t ci = base + grp;
+            const bool act = ci < a.n_entry;
+            const uint32_t cid = act ? a.entry[ci] : 0u;
+            const float dist = group_distance(cid, act);
+            unsigned long long m = __ballot(act && sub == 0);
+            while (m != 0ull) {
+                const int bl = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
+                const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
+                ++n_eval;
+                if (buf.size < buf.capacity) {
+                    // push_back + (stable) sort == ordered insert without the duplicate check
+                    uint32_t pos = 0;
+                    for (uint32_t i0 = 0; i0 < buf.size; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        bool before = false;
+                        if (i < buf.size) before = !cmpf<GREATER>(dd, __uint_as_float(buf.e[i].x));
+                        pos += __popcll(__ballot(before));
+                    }
+                    lds_order();
+                    for (int i = static_cast<int>(buf.size) - 1; i >= static_cast<int>(pos); --i) {
+                        if (lane == 0) buf.e[i + 1] = buf.e[i];
+                    }
+                    if (lane == 0) buf.e[pos] = make_uint2(__float_as_uint(dd), id);
+                    lds_order();
+                    buf.size++;
+                }
+            }
+        }
+    }
+
+    bool full = buf.size == buf.capacity;
+    float worst = full ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
+
+    // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
+    while (!wave_done(buf)) {
+        float node_dist;
+        const uint32_t node = wave_next(buf, lane, node_dist);
+        if (a.history_ids != nullptr && lane == 0 && n_exp < a.history_cap) {
+            a.history_ids[static_cast<size_t>(qi) * a.history_cap + n_exp] = node;
+            if (a.history_dists != nullptr) a.history_dists[static_cast<size_t>(qi) * a.history_cap + n_exp] = node_dist;
+        }
+        ++n_exp;
+        const uint32_t* grow = a.graph + static_cast<size_t>(node) * a.gstride;
+        for (uint32_t gbase = 0; gbase < a.gstride; gbase += 64) {
+            uint32_t nid = kInvalidId;
+            if (gbase + lane < a.gstride) nid = grow[gbase + lane];
+            const uint32_t cnt = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
+            n_slots += cnt;
+            for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
+                const uint32_t ci = p0 + grp;
+                const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
+                const bool act = ci < cnt;
+                const float dist = group_distance(cid, act);
+                const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
+                unsigned long long m = __ballot(act && sub == 0 && !skip);
+                n_eval += (cnt - p0) < static_cast<uint32_t>(RPP) ? (cnt - p0) : static_cast<uint32_t>(RPP);
+                while (m != 0ull) {
+                    const int bl = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
+                    if (full && cmpf<GREATER>(worst, dd)) continue; // worst may have improved within this pass
+                    const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
+                    if (wave_insert<GREATER>(buf, dd, id, lane)) {
+                        ++n_ins;
+                        full = buf.size == buf.capacity;
+                        if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
+                    }
+                }
+            }
+            if (cnt < 64u) break;
+        }
+    }
+
+    // ---- copy-back (extensions.h:588-590), padded like vamana_index_impl.h:205-209 -----------------------------
+    for (uint32_t j = lane; j < a.k; j += 64) {
+        uint32_t id = kInvalidId;
+        float dist = __builtin_inff();
+        const bool have = j < buf.size;
+        if (have) {
+            const uint2 en = buf.e[j];
+            id = en.y & kIdMask;
+            dist = __uint_as_float(en.x);
+        }
+        const size_t o = static_cast<size_t>(qi) * a.k + j;
+        if (a.ids64 != nullptr) a.ids64[o] = have ? (static_cast<uint64_t>(id) + a.id_offset) : ~0ull;
+        if (a.ids32 != nullptr) a.ids32[o] = have ? static_cast<uint32_t>(id + static_cast<uint32_t>(a.id_offset)) : kInvalidId;
+        if (a.dists != nullptr) a.dists[o] = dist;
+    }
+    if (lane == 0) {
+        if (a.stats != nullptr) {
+            uint32_t* st = a.stats + static_cast<size_t>(qi) * 4;
+            st[0] = n_exp;
+            st[1] = n_slots;
+            st[2] = n_eval;
+            st[3] = n_ins;
+        }
+        if (a.history_len != nullptr) a.history_len[qi] = n_exp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, int METRIC, int QMODE, int DS> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+    const int d = static_cast<int>(a.d);
+    const int dpad = (d + 15) & ~15;
+    const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
+    const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = search_kernel<DT, METRIC, QMODE, DS>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
+    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
+        if (a.d == 96) return launch_one<DT, METRIC, QMODE, 96>(a, stream);
+        if (a.d == 128) return launch_one<DT, METRIC, QMODE, 128>(a, stream);
+    }
+    return launch_one<DT, METRIC, QMODE, 0>(a, stream);
+}
+
+template <int DT, int QMODE> static hipError_t launch_metric(int metric, const SearchArgs& a, hipStream_t stream) {
+    switch (metric) {
+        case M_L2:
+            if constexpr (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_dim<DT, M_L2, QMODE>(a, stream);
+        case M_IP:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_dim<DT, M_IP, QMODE>(a, stream);
+        case M_COS:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_IP) return hipErrorInvalidValue;
+            else return launch_dim<DT, M_COS, QMODE>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_search(int data_dtype, int metric, int qmode, const SearchArgs& a, hipStream_t stream) {
+    switch (qmode) {
+        case QM_FLOAT:
+            switch (data_dtype) {
+                case DT_F32: return launch_metric<DT_F32, QM_FLOAT>(metric, a, stream);
+                case DT_F16: return launch_metric<DT_F16, QM_FLOAT>(metric, a, stream);
+                case DT_I8: return launch_metric<DT_I8, QM_FLOAT>(metric, a, stream);
+                case DT_U8: return launch_metric<DT_U8, QM_FLOAT>(metric, a, stream);
+            }
+            break;
+        case QM_INT:
+            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_INT>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_INT>(metric, a, stream);
+            break;
+        case QM_SQ_IP:
+            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_SQ_IP>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_SQ_IP>(metric, a, stream);
+            break;
+        case QM_SQ_COS:
+            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_SQ_COS>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_SQ_COS>(metric, a, stream);
+            break;
+        case QM_SQ_L2:
+            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_SQ_L2>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_SQ_L2>(metric, a, stream);
+            break;
+    }
+    return hipErrorInvalidValue;
+}
+
+} // namespace svsx

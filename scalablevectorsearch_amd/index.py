@@ -1,0 +1,221 @@
+"""Host-side mirror of svs::index::vamana::VamanaIndex for the batch-search path, over the C ABI.
+
+Reference interfaces mirrored (paths relative to the reference root):
+  VamanaIndex::search(QueryResultView, queries, VamanaSearchParameters, cancel)   index/vamana/index.h:564-611
+  VamanaSearchParameters                                                           index/vamana/search_params.h:28-61
+  SearchBufferConfig                                                               index/vamana/search_buffer.h:39-96
+  QueryResult<size_t>                                                              core/query_result.h:53-172
+  k_recall_at_n                                                                    core/recall.h:47-58
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .distance import as_functor, dtype_code
+
+
+class SearchBufferConfig:
+    """search_buffer.h:39-96: invariant search_window_size <= total_capacity (throws ANNException otherwise)."""
+
+    def __init__(self, search_window_size: int = 0, total_capacity: int | None = None):
+        total_capacity = search_window_size if total_capacity is None else total_capacity
+        if search_window_size > total_capacity:
+            raise _lib.SvsxError(
+                _lib.INVALID_ARGUMENT,
+                f"Improper configuration for search buffer! Effective size ({search_window_size}) cannot be less than capacity ({total_capacity}).",
+            )
+        self.search_window_size = int(search_window_size)
+        self.total_capacity = int(total_capacity)
+
+    def get_search_window_size(self) -> int:
+        return self.search_window_size
+
+    def get_total_capacity(self) -> int:
+        return self.total_capacity
+
+    def __eq__(self, o):
+        return isinstance(o, SearchBufferConfig) and (self.search_window_size, self.total_capacity) == (o.search_window_size, o.total_capacity)
+
+    def __repr__(self):
+        return f"SearchBufferConfig({self.search_window_size}, {self.total_capacity})"
+
+
+@dataclass
+class VamanaSearchParameters:
+    """search_params.h:28-61.  prefetch_* are accepted and ignored (occupancy hides latency on the GPU)."""
+
+    buffer_config: SearchBufferConfig = field(default_factory=SearchBufferConfig)
+    search_buffer_visited_set: bool = False
+    prefetch_lookahead: int = 4
+    prefetch_step: int = 1
+
+    def _c(self) -> _lib.SearchParams:
+        return _lib.SearchParams(self.buffer_config.search_window_size, self.buffer_config.total_capacity,
+                                 int(self.search_buffer_visited_set), self.prefetch_lookahead, self.prefetch_step)
+
+
+@dataclass
+class QueryResult:
+    """core/query_result.h:53-172: row-major nq x k ids (size_t) and f32 distances."""
+
+    indices: np.ndarray
+    distances: np.ndarray
+
+    def n_queries(self) -> int:
+        return self.indices.shape[0]
+
+    def n_neighbors(self) -> int:
+        return self.indices.shape[1]
+
+
+def k_recall_at_n(groundtruth: np.ndarray, results: np.ndarray, k: int = 0, n: int = 0) -> float:
+    """core/recall.h:47-58,181-185: |gt[:k] ∩ res[:n]| summed over queries / (k * nq); k, n default to all columns."""
+    groundtruth = np.asarray(groundtruth)
+    results = np.asarray(results.indices if isinstance(results, QueryResult) else results)
+    nmax = results.shape[1]
+    k = k or nmax  # recall.h:68-69: defaults to n-recall@n ("not a typo")
+    n = n or nmax
+    if groundtruth.shape[0] != results.shape[0]:
+        raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Groundtruth contains {groundtruth.shape[0]} points while the result has {results.shape[0]} points!")
+    if k > n:
+        raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Argument k ({k}) must be less than n ({n})")
+    if k > groundtruth.shape[1]:
+        raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Argument k ({k}) must be less than groundtruth entries ({groundtruth.shape[1]})")
+    if n > nmax:
+        raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Argument n ({n}) must be less than result entries ({nmax})")
+    hits = 0
+    for g, r in zip(groundtruth[:, :k].astype(np.int64), results[:, :n].astype(np.int64)):
+        hits += np.intersect1d(g, r).size
+    return hits / (k * groundtruth.shape[0])
+
+
+class VamanaIndex:
+    """A read-only Vamana index resident in one GPU's HBM.
+
+    ``graph`` uses the SVS row layout (core/graph/graph.h:32-48): ``graph[i, 0]`` = degree,
+    ``graph[i, 1:1+deg]`` = neighbour ids.  ``data`` is row-major n x d (float32/float16/int8/uint8);
+    ``sq=(scale, bias)`` declares int8/uint8 data to be SQDataset codes (quantization/scalar/scalar.h).
+    """
+
+    def __init__(self, graph, data, distance, entry_points, device: int = 0, sq=None, id_offset: int = 0, num_threads: int = 1):
+        self.distance = as_functor(distance)
+        data = np.ascontiguousarray(data)
+        graph = np.ascontiguousarray(graph, dtype=np.uint32)
+        entry = np.ascontiguousarray(np.atleast_1d(entry_points), dtype=np.uint32)
+        if data.ndim != 2 or graph.ndim != 2 or graph.shape[0] != data.shape[0]:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "Wrong sizes!")  # index.h:420-422
+        desc = _lib.IndexDesc(
+            int(self.distance.metric), dtype_code(data), data.shape[0], data.shape[1], data.ctypes.data, 0,
+            graph.ctypes.data, graph.shape[1], graph.shape[1] - 1, entry.ctypes.data, entry.size,
+            int(sq is not None), float(sq[0]) if sq else 1.0, float(sq[1]) if sq else 0.0, device, id_offset,
+        )
+        self._h = C.c_void_p()
+        self._keep = None
+        _lib.check(_lib.lib().svsx_index_create(C.byref(desc), C.byref(self._h)))
+        self.device = device
+        self.n, self.d = data.shape
+        self.data_dtype = data.dtype
+        self.entry_points = entry.copy()
+        # construct_default_search_parameters (index.h:243-250) leaves window 0 -> raised to k at search time
+        self._params = VamanaSearchParameters()
+
+    @classmethod
+    def from_device(cls, d_graph, d_data, distance, d_entry_points, n: int, d: int, data_dtype, device: int = 0, sq=None, id_offset: int = 0):
+        """Adopt torch tensors already in the device layout (svsx_index_create_device_view): data rows padded to
+        16 elements, graph rows of 16k ids padded with 0xFFFFFFFF.  The tensors are kept alive by the index."""
+        self = cls.__new__(cls)
+        self.distance = as_functor(distance)
+        code = dtype_code(np.empty(0, data_dtype))
+        desc = _lib.DeviceIndexDesc(
+            int(self.distance.metric), code, n, d, d_data.data_ptr(), d_data.stride(0) * d_data.element_size(),
+            d_graph.data_ptr(), d_graph.stride(0), d_entry_points.data_ptr(), d_entry_points.numel(),
+            int(sq is not None), float(sq[0]) if sq else 1.0, float(sq[1]) if sq else 0.0, device, id_offset,
+        )
+        self._h = C.c_void_p()
+        self._keep = (d_graph, d_data, d_entry_points)
+        _lib.check(_lib.lib().svsx_index_create_device_view(C.byref(desc), C.byref(self._h)))
+        self.device = device
+        self.n, self.d = n, d
+        self.data_dtype = np.dtype(data_dtype)
+        self.entry_points = None
+        self._params = VamanaSearchParameters()
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().svsx_index_destroy(h)
+            self._h = None
+
+    # -- parameters (index.h:318, get/set_search_parameters) ---------------------------------------------------
+    def get_search_parameters(self) -> VamanaSearchParameters:
+        return self._params
+
+    def set_search_parameters(self, p: VamanaSearchParameters) -> None:
+        self._params = p
+
+    @property
+    def search_window_size(self) -> int:
+        return self._params.buffer_config.search_window_size
+
+    @search_window_size.setter
+    def search_window_size(self, w: int) -> None:
+        self._params.buffer_config = SearchBufferConfig(w)
+
+    def size(self) -> int:
+        return self.n
+
+    def dimensions(self) -> int:
+        return self.d
+
+    def info(self) -> dict:
+        arr = (C.c_uint64 * 6)()
+        _lib.check(_lib.lib().svsx_index_info(self._h, arr))
+        return dict(n=arr[0], d=arr[1], data_bytes=arr[2], graph_bytes=arr[3], graph_row_stride=arr[4], data_row_bytes=arr[5])
+
+    # -- search ---------------------------------------------------------------------------------------------------
+    def search(self, queries, num_neighbors: int, search_parameters: VamanaSearchParameters | None = None, stats: bool = False):
+        """Batch search with host arrays (svs.Vamana.search(queries, k) -> (ids, distances))."""
+        queries = np.ascontiguousarray(np.atleast_2d(queries))
+        if queries.shape[1] != self.d:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Query dimension {queries.shape[1]} does not match index dimension {self.d}")
+        nq = queries.shape[0]
+        ids = np.empty((nq, num_neighbors), np.uint64)
+        dists = np.empty((nq, num_neighbors), np.float32)
+        sp = (search_parameters or self._params)._c()
+        aux = _lib.SearchAux()
+        st = None
+        if stats:
+            st = np.zeros((nq, 4), np.uint32)
+            aux.stats = st.ctypes.data
+        _lib.check(_lib.lib().svsx_search(self._h, queries.ctypes.data, dtype_code(queries), nq, num_neighbors, C.byref(sp),
+                                          ids.ctypes.data, None, dists.ctypes.data, C.byref(aux)))
+        res = QueryResult(ids, dists)
+        return (res, st) if stats else res
+
+    def search_device(self, d_queries, num_neighbors: int, search_parameters: VamanaSearchParameters | None = None,
+                      d_ids64=None, d_ids32=None, d_dists=None, d_stats=None, history=None, q_dtype=None, stream=None):
+        """Enqueue a batch search on torch CUDA tensors (no synchronisation).  ``history`` = (ids, dists, len) tensors."""
+        import torch
+
+        nq = d_queries.shape[0]
+        code = q_dtype if q_dtype is not None else {torch.float32: 0, torch.float16: 1, torch.int8: 2, torch.uint8: 3}[d_queries.dtype]
+        sp = (search_parameters or self._params)._c()
+        aux = _lib.SearchAux()
+        aux.query_row_stride_bytes = d_queries.stride(0) * d_queries.element_size()
+        if d_stats is not None:
+            aux.stats = d_stats.data_ptr()
+        if history is not None:
+            aux.history_ids = history[0].data_ptr()
+            aux.history_dists = history[1].data_ptr() if history[1] is not None else None
+            aux.history_len = history[2].data_ptr()
+            aux.history_cap = history[0].shape[1]
+        s = stream if stream is not None else torch.cuda.current_stream(d_queries.device).cuda_stream
+        _lib.check(_lib.lib().svsx_search_device(
+            self._h, d_queries.data_ptr(), code, nq, num_neighbors, C.byref(sp),
+            d_ids64.data_ptr() if d_ids64 is not None else None, d_ids32.data_ptr() if d_ids32 is not None else None,
+            d_dists.data_ptr() if d_dists is not None else None, C.byref(aux), C.c_void_p(s)))

@@ -1,0 +1,180 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import deep_like
+
+pytestmark = pytest.mark.gpu
+
+F32, F16, I8, U8 = 0, 1, 2, 3
+L2, IP, COS = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def svs():
+    import scalablevectorsearch_amd as svs
+
+    return svs
+
+
+def _gen(rng, dt, n, d):
+    if dt == F32:
+        return rng.standard_normal((n, d)).astype(np.float32)
+    if dt == F16:
+        return rng.standard_normal((n, d)).astype(np.float16)
+    if dt == I8:
+        return rng.integers(-128, 128, (n, d)).astype(np.int8)
+    return rng.integers(0, 256, (n, d)).astype(np.uint8)
+
+
+PAIRS = [(F32, F32), (F32, F16), (F16, F32), (F16, F16), (F32, I8), (F32, U8), (I8, I8), (U8, U8)]
+
+
+@pytest.mark.parametrize("d", [1, 7, 16, 17, 63, 64, 65, 96, 100, 128, 160, 223, 768])
+def test_distance_bits_match_oracle(svs, oracle, d):
+    """distance plugin surface: every AVX-512 specialised type pair x metric, incl. ragged tails (dims of
+    tests/svs/core/distances/*.cpp: 160 even, 223 ragged) -- bit-exact, stricter than the reference's Approx."""
+    rng = np.random.default_rng(d)
+    for qa, qb in PAIRS:
+        a = _gen(rng, qa, 9, d)
+        b = _gen(rng, qb, 70, d)
+        for m, f in ((L2, svs.DistanceL2()), (IP, svs.DistanceIP()), (COS, svs.DistanceCosineSimilarity())):
+            got = svs.compute(f, a, b)
+            want = oracle.distance_batch(m, a, b)
+            bad = got.view(np.uint32) != want.view(np.uint32)
+            # NaN (0/0 cosine) compares by bit pattern too, but allow any NaN payload
+            bad &= ~(np.isnan(got) & np.isnan(want))
+            assert not bad.any(), (d, qa, qb, m, got[bad][:4], want[bad][:4])
+
+
+def test_unsupported_pair_is_rejected(svs):
+    a = np.zeros((1, 8), np.int8)
+    b = np.zeros((1, 8), np.float32)
+    with pytest.raises(svs.SvsxError) as e:
+        svs.compute(svs.DistanceL2(), a, b)
+    assert e.value.code == 2
+
+
+def _search_both(svs, oracle, metric, fn, x, graph, entry, q, k, w, c, sq=None):
+    idx = svs.VamanaIndex(graph, x, fn, entry, sq=sq)
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c))
+    res, st = idx.search(q, k, sp, stats=True)
+    ids, dists, ost = oracle.search(metric, x, graph, entry, q, k, w, c, sq=sq, stats=True)
+    return res, st, ids, dists, ost
+
+
+@pytest.mark.parametrize("w,c,k", [(10, 10, 10), (32, 32, 10), (20, 40, 10), (128, 128, 10), (5, 5, 10), (64, 64, 64), (1, 1, 1)])
+def test_search_f32_l2_bit_exact(svs, oracle, small_world, w, c, k):
+    sw = small_world
+    res, st, ids, dists, ost = _search_both(svs, oracle, L2, svs.DistanceL2(), sw["x"], sw["graph"], sw["entry"], sw["q"], k, w, c)
+    assert (res.indices == ids.astype(np.uint64)).all()
+    assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+    # tracker counts (greedy_search.h:165): expansions and neighbour slots identical
+    assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("qdt,ddt", PAIRS)
+def test_search_all_type_pairs(svs, oracle, small_world, metric, qdt, ddt):
+    sw = small_world
+    fn = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}[metric]
+
+    def conv(a, dt):
+        if dt == F32:
+            return a
+        if dt == F16:
+            return a.astype(np.float16)
+        if dt == I8:
+            return np.clip(np.round(a * 400), -128, 127).astype(np.int8)
+        return np.clip(np.round(a * 400 + 128), 0, 255).astype(np.uint8)
+
+    x = conv(sw["x"], ddt)
+    q = conv(sw["q"], qdt)
+    for (w, c) in [(16, 16), (12, 30)]:
+        res, st, ids, dists, ost = _search_both(svs, oracle, metric, fn, x, sw["graph"], sw["entry"], q, 10, w, c)
+        assert (res.indices == ids.astype(np.uint64)).all(), (metric, qdt, ddt)
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+        assert (st[:, :2] == ost[:, :2]).all()
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("code", [I8, U8])
+def test_search_scalar_quantized(svs, oracle, small_world, metric, code):
+    """SQDataset<int8/uint8> + compressed distances (quantization/scalar/scalar.h:58-195)."""
+    sw = small_world
+    fn = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}[metric]
+    codes, scale, bias = oracle.sq_compress(sw["x"], code)
+    for q in (sw["q"], sw["q"].astype(np.float16)):
+        res, st, ids, dists, ost = _search_both(svs, oracle, metric, fn, codes, sw["graph"], sw["entry"], q, 10, 24, 24, sq=(scale, bias))
+        assert (res.indices == ids.astype(np.uint64)).all()
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("d", [100, 223, 40])
+def test_search_ragged_dims(svs, oracle, d):
+    from oracle.oracle import L2 as OL2
+
+    x = deep_like(600, d, 16, seed=3, normalize=False)
+    q = deep_like(32, d, 16, seed=4, normalize=False)
+    graph, entry = oracle.build_vamana(OL2, x, R=24, L=32)
+    for fn, m in ((svs.DistanceL2(), L2), (svs.DistanceCosineSimilarity(), COS)):
+        res, st, ids, dists, ost = _search_both(svs, oracle, m, fn, x, graph, entry, q, 8, 20, 20)
+        assert (res.indices == ids.astype(np.uint64)).all()
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+
+
+def test_search_wide_graph_and_duplicates(svs, oracle):
+    """max degree 128 (two adjacency chunks), heavy distance ties (integer grid data) and duplicate vectors."""
+    from oracle.oracle import L2 as OL2
+
+    rng = np.random.default_rng(5)
+    x = rng.integers(-2, 3, (800, 32)).astype(np.float32)
+    x[100:140] = x[0:40]  # exact duplicates -> equal distances, different ids
+    q = rng.integers(-2, 3, (40, 32)).astype(np.float32)
+    graph, entry = oracle.build_vamana(OL2, x, R=128, L=140)
+    assert graph[:, 0].max() > 64
+    for (w, c) in [(30, 30), (150, 150), (10, 64)]:
+        res, st, ids, dists, ost = _search_both(svs, oracle, L2, svs.DistanceL2(), x, graph, entry, q, 10, w, c)
+        assert (res.indices == ids.astype(np.uint64)).all()
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+        assert (st[:, :2] == ost[:, :2]).all()
+
+
+def test_fewer_than_k_results_are_padded(svs, oracle):
+    """vamana_index_impl.h:205-209: id = all-ones, dist = +inf."""
+    x = deep_like(6, 16, 4, seed=6)
+    graph = np.zeros((6, 4), np.uint32)
+    graph[0, :3] = (2, 1, 2)
+    graph[1, :2] = (1, 0)
+    graph[2, :2] = (1, 0)  # nodes 3..5 unreachable
+    q = deep_like(3, 16, 4, seed=7)
+    idx = svs.VamanaIndex(graph, x, svs.DistanceL2(), [0])
+    res = idx.search(q, 5, svs.VamanaSearchParameters(svs.SearchBufferConfig(8)))
+    ids, dists = oracle.search(L2, x, graph, np.array([0], np.uint32), q, 5, 8)
+    assert (res.indices[:, :3] == ids[:, :3]).all()
+    assert (res.indices[:, 3:] == np.uint64(2**64 - 1)).all()
+    assert np.isposinf(res.distances[:, 3:]).all()
+    assert (res.distances[:, :3].view(np.uint32) == dists[:, :3].view(np.uint32)).all()
+
+
+def test_argument_errors(svs, small_world):
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    with pytest.raises(svs.SvsxError) as e:
+        idx.search(sw["q"], 0)
+    assert e.value.code == 2 and "k must be greater than 0" in e.value.message
+    with pytest.raises(svs.SvsxError):
+        svs.SearchBufferConfig(10, 9)
+    with pytest.raises(svs.SvsxError) as e:
+        idx.search(sw["q"].astype(np.int8), 5)
+    assert e.value.code == 2
+    # empty batch is a no-op (vamana_index_impl.h:125-127)
+    r = idx.search(np.zeros((0, 96), np.float32), 5)
+    assert r.indices.shape == (0, 5)
+
+
+def test_multiple_entry_points(svs, oracle, small_world):
+    sw = small_world
+    entry = np.array([int(sw["entry"][0]), 3, 700], np.uint32)
+    res, st, ids, dists, ost = _search_both(svs, oracle, L2, svs.DistanceL2(), sw["x"], sw["graph"], entry, sw["q"], 10, 20, 20)
+    assert (res.indices == ids.astype(np.uint64)).all()
