@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""bench.py -- QPS of the batched Vamana greedy search on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch search (10 000 queries, k=10, search_window=128) over a deep-1M-like index
+(1 000 000 x 96 float32, L2, Vamana graph R=64) resident in HBM; queries/results are device tensors.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns one read-only shard of the same
+size (weak scaling), the query batch is the same on all ranks, per-shard top-k are exchanged with one RCCL
+all-gather and merged on the GPU.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def deep_like_device(n, d, latent, seed, device, sigma=0.1):
+    """SURVEY 8d generator G(latent, sigma): x = normalize(z A + sigma eps), A seeded by 7."""
+    import torch
+
+    ga = torch.Generator(device=device).manual_seed(7)
+    a = torch.randn((latent, d), generator=ga, device=device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty((n, d), device=device)
+    for lo in range(0, n, 1 << 20):
+        m = min(1 << 20, n - lo)
+        z = torch.randn((m, latent), generator=g, device=device)
+        e = torch.randn((m, d), generator=g, device=device)
+        x = z @ a + sigma * e
+        out[lo : lo + m] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+def brute_force_topk(x, q, k, chunk=1 << 18):
+    """Exact L2 ground truth (plumbing, torch GEMM): ids [nq,k]."""
+    import torch
+
+    qn = (q * q).sum(1, keepdim=True)
+    best_d = torch.full((q.shape[0], k), float("inf"), device=q.device)
+    best_i = torch.zeros((q.shape[0], k), dtype=torch.int64, device=q.device)
+    for lo in range(0, x.shape[0], chunk):
+        xs = x[lo : lo + chunk]
+        dist = qn + (xs * xs).sum(1)[None, :] - 2.0 * (q @ xs.T)
+        dd, ii = torch.topk(dist, k, dim=1, largest=False)
+        cat_d = torch.cat([best_d, dd], 1)
+        cat_i = torch.cat([best_i, ii + lo], 1)
+        sel = torch.topk(cat_d, k, dim=1, largest=False)
+        best_d = sel.values
+        best_i = torch.gather(cat_i, 1, sel.indices)
+    return best_i
+
+
+def recall_at(gt, ids, k):
+    import torch
+
+    hit = (ids[:, :k, None].to(torch.int64) == gt[:, None, :k]).any(2).sum().item()
+    return hit / (gt.shape[0] * k)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000, help="vectors per GPU shard (default: the BASELINE config)")
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--window", type=int, default=128)
+    ap.add_argument("--degree", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-cache", default="", help="load/save the built graph here (lets a profiler run skip the build)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import scalablevectorsearch_amd as svs
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n, d, nq, k, R = args.n, 96, args.nq, 10, args.degree
+    t0 = time.time()
+    # shard `rank` of a (world x n) database: independent seeds per shard, global ids = local + rank*n
+    x = deep_like_device(n, d, 24, seed=1 + 1000 * rank, device=device)
+    q = deep_like_device(nq, d, 24, seed=2, device=device)  # identical on every rank
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    t0 = time.time()
+    bp = VamanaBuildParameters(alpha=1.2, graph_max_degree=R, window_size=2 * R, max_candidate_pool_size=750, prune_to=R - 4)
+    cache = f"{args.graph_cache}.r{rank}" if args.graph_cache else ""
+    if cache and os.path.exists(cache):
+        blob = torch.load(cache, map_location=device)
+        graph, entry = blob["graph"], blob["entry"]
+    else:
+        graph, entry = build_vamana_device(x, n, d, svs.DistanceL2(), bp, device=local_rank)
+        if cache:
+            torch.save({"graph": graph, "entry": entry}, cache)
+    t_build = time.time() - t0
+    deg_mean = float((graph[:, :R] >= 0).sum(1).float().mean())
+    if rank == 0:
+        log(f"[bench] data {t_gen:.1f}s, graph build {t_build:.1f}s (R={R}, mean degree {deg_mean:.1f}), entry {entry}")
+
+    d_entry = torch.tensor([entry], dtype=torch.int32, device=device)
+    index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n, d, np.float32, device=local_rank, id_offset=rank * n)
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window))
+
+    ids = torch.empty((nq, k), dtype=torch.int64, device=device)  # written as uint64
+    dists = torch.empty((nq, k), dtype=torch.float32, device=device)
+    stats = torch.zeros((nq, 4), dtype=torch.int32, device=device)
+    if world > 1:
+        all_d = torch.empty((world, nq, k), dtype=torch.float32, device=device)
+        all_i = torch.empty((world, nq, k), dtype=torch.int64, device=device)
+        out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=device)
+
+    import ctypes as C
+
+    from scalablevectorsearch_amd import _lib
+
+    def step(with_stats=False):
+        index.search_device(q, k, sp, d_ids64=ids, d_dists=dists, d_stats=stats if with_stats else None)
+        if world > 1:
+            dist.all_gather_into_tensor(all_d.view(-1), dists.view(-1))
+            dist.all_gather_into_tensor(all_i.view(-1), ids.view(-1))
+            _lib.check(_lib.lib().svsx_merge_topk_device(0, world, nq, k, all_d.data_ptr(), all_i.data_ptr(), out_d.data_ptr(), out_i.data_ptr(),
+                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    # ---- correctness of what is being timed: recall against exact ground truth ---------------------------------
+    step(with_stats=True)
+    torch.cuda.synchronize()
+    gt_local = brute_force_topk(x, q, k) + rank * n
+    if world > 1:
+        # global ground truth = merge of per-shard exact top-k
+        gd = ((q[:, None, :] - x[(gt_local - rank * n)]) ** 2).sum(-1)
+        g_all_d = torch.empty((world, nq, k), device=device)
+        g_all_i = torch.empty((world, nq, k), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(g_all_d.view(-1), gd.contiguous().view(-1))
+        dist.all_gather_into_tensor(g_all_i.view(-1), gt_local.contiguous().view(-1))
+        cd = g_all_d.permute(1, 0, 2).reshape(nq, world * k)
+        ci = g_all_i.permute(1, 0, 2).reshape(nq, world * k)
+        sel = torch.topk(cd, k, dim=1, largest=False).indices
+        gt = torch.gather(ci, 1, sel)
+        recall = recall_at(gt, out_i, k)
+    else:
+        gt = gt_local
+        recall = recall_at(gt, ids, k)
+    st = stats.to(torch.int64)
+    exp_total = int(st[:, 0].sum())
+    slots_total = int(st[:, 1].sum())
+    # SURVEY 8(d) algorithmic bytes: sum_v [4(1+deg v) + deg v * d * 4] + n_entry*d*4 + d*4 + k*(8+4) per query
+    alg_bytes = 4 * (exp_total + slots_total) + slots_total * d * 4 + nq * (d * 4 + d * 4 + k * 12)
+
+    # ---- timed region ---------------------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
+        ev[i][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(all_d.view(-1), dists.view(-1))
+            dist.all_gather_into_tensor(all_i.view(-1), ids.view(-1))
+            _lib.check(_lib.lib().svsx_merge_topk_device(0, world, nq, k, all_d.data_ptr(), all_i.data_ptr(), out_d.data_ptr(), out_i.data_ptr(),
+                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    shard_queries_per_s = world * nq * args.steps / elapsed
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "QPS at recall@10>=0.9 (batch=10k); achieved HBM GB/s vs roofline",
+        "value": shard_queries_per_s,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"deep-1M-like d=96 float32 L2, batch={nq}, search_window={args.window}, k=10, 1xMI355X per shard",
+            "vectors_per_gpu": n,
+            "graph": f"Vamana R={R} L={2*R} alpha=1.2 (GPU-built, mean degree {deg_mean:.1f})",
+            "recall_at_10": recall,
+            "sharded_index_qps": nq * args.steps / elapsed,
+            "shards": world,
+            "expansions_per_query": exp_total / nq,
+            "neighbor_slots_per_query": slots_total / nq,
+            "build_seconds": t_build,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "svsx::search_kernel<f32,L2,float,96>",
+            "kernel_ms": kern_ms,
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(x, q, graph, entry, R, k, args.window, ids)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(x, q, graph, entry, R, k, window, gpu_ids):
+    """Time the CPU checker on this box's host cores over a bounded sample of the SAME workload and check that the
+    GPU ids are identical on that sample.  kind="reference": oracle/_ref (the reference's own greedy_search /
+    SearchBuffer / generic_simd_op, AVX-512, static partition over threads); kind="port": the scalar C oracle."""
+    from scalablevectorsearch_amd.build import device_graph_to_svs
+
+    from oracle.oracle import L2, Oracle, Ref
+
+    xh = x.cpu().numpy()
+    qh = q.cpu().numpy()
+    gh = device_graph_to_svs(graph, R)
+    eh = np.array([entry], np.uint32)
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    if Ref.available():
+        r = Ref()
+        kind, threads = "reference", ncores
+        run = lambda qq: r.search(L2, xh, gh, eh, qq, k, window, nthreads=threads)
+    else:
+        o = Oracle()
+        kind, threads = "port", 1
+        run = lambda qq: o.search(L2, xh, gh, eh, qq, k, window)
+    # size the sample for ~10-20 s of CPU work
+    probe = qh[: min(len(qh), 64 * threads)]
+    t0 = time.perf_counter()
+    run(probe)
+    rate = len(probe) / (time.perf_counter() - t0)
+    ns = int(min(len(qh), max(len(probe), rate * 5.0)))
+    best = None
+    ids_cpu = None
+    t_all = time.perf_counter()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ids_cpu, _ = run(qh[:ns])
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        if time.perf_counter() - t_all > 20:
+            break
+    same = bool((gpu_ids[:ns].cpu().numpy().astype(np.uint64) == ids_cpu.astype(np.uint64)).all())
+    return {
+        "value": ns / best,
+        "unit": "queries/s",
+        "cores": threads,
+        "kind": kind,
+        "sample": f"first {ns} of the {len(qh)} queries, same graph/data/window, best of <=3 runs; GPU ids identical on sample: {same}",
+    }
+
+
+if __name__ == "__main__":
+    main()

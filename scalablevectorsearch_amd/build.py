@@ -1,0 +1,257 @@
+"""GPU-assisted batch-synchronous Vamana builder ("next" scope, not the graded hot path).
+
+Follows the reference builder's structure -- search a batch with the build window, prune, add reverse edges
+(index/vamana/vamana_build.h:232-599, prune.h:100-246, two passes alpha=1 then alpha, index.h:426-439, medoid entry
+point core/medioid.h:292-353) -- with the batch search done by THIS repo's HIP greedy-search kernel (history
+output = the tracker's full search history, vamana_build.h:54-91) and the prune / reverse-edge bookkeeping as
+batched torch tensor ops (plumbing).  The reference build is thread-schedule dependent, so graphs are comparable
+by quality (recall-vs-window), never byte-for-byte; search parity is always judged on identical graph bytes.
+
+The graph lives in HBM in the device layout of include/svsx.h (rows of `gstride` ids, 0xFFFFFFFF = unused).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from .distance import DistanceType, as_functor
+from .index import SearchBufferConfig, VamanaIndex, VamanaSearchParameters
+
+INVALID = -1  # 0xFFFFFFFF viewed as int32
+
+
+@dataclass
+class VamanaBuildParameters:
+    """index/vamana/build_params.h:28-75."""
+
+    alpha: float = 1.2
+    graph_max_degree: int = 64
+    window_size: int = 128
+    max_candidate_pool_size: int = 750
+    prune_to: int = 0  # 0 -> graph_max_degree - 4 like tools/benchmark_inputs (124 for 128)
+    use_full_search_history: bool = True
+
+
+def _pairwise(metric: DistanceType, a, b_norm2, b):
+    """[B,P,d] x [B,P,d] -> [B,P,P] distances of the build metric (fp32 GEMM; build-quality arithmetic)."""
+    import torch
+
+    g = torch.bmm(a, b.transpose(1, 2))
+    if metric == DistanceType.L2:
+        return (b_norm2[:, :, None] + b_norm2[:, None, :] - 2.0 * g).clamp_min_(0.0)
+    if metric == DistanceType.MIP:
+        return g
+    n = b_norm2.clamp_min(1e-30).sqrt()
+    return g / (n[:, :, None] * n[:, None, :])
+
+
+def _point_dist(metric: DistanceType, x, y):
+    """x [B,d] vs y [B,P,d] -> [B,P]."""
+    if metric == DistanceType.L2:
+        return ((y - x[:, None, :]) ** 2).sum(-1)
+    ip = (y * x[:, None, :]).sum(-1)
+    if metric == DistanceType.MIP:
+        return ip
+    return ip / (y.norm(dim=-1) * x.norm(dim=-1)[:, None]).clamp_min(1e-30)
+
+
+def _prune(metric, greater, data_f32, node_ids, pool_ids, pool_d, max_out, alpha, out_width):
+    """heuristic_prune_neighbors for a batch of nodes (prune.h:100-246).
+
+    pool_ids [B,P] int64 sorted best-first by (distance, id), padded with -1; pool_d [B,P] distance to the node.
+    Returns [B,out_width] int32 ids packed from slot 0, padded with -1.
+    """
+    import torch
+
+    B, P = pool_ids.shape
+    dev = pool_ids.device
+    valid = pool_ids >= 0
+    vec = data_f32[pool_ids.clamp_min(0)]  # [B,P,d]
+    n2 = (vec * vec).sum(-1)
+    pair = _pairwise(metric, vec, n2, vec)  # [B,P,P]
+    result = torch.full((B, out_width), INVALID, dtype=torch.int32, device=dev)
+    count = torch.zeros(B, dtype=torch.int64, device=dev)
+    rows = torch.arange(B, device=dev)
+    cols = torch.arange(P, device=dev)
+    not_self = pool_ids != node_ids[:, None]
+    big = torch.finfo(torch.float32).max
+    if not greater:
+        # ProgressivePruneStrategy (L2): state = max over selected s of d(node,t)/d(s,t); skip while cur < state
+        state = torch.full((B, P), -big, device=dev)
+        cur = 1.0
+        while True:
+            for s in range(P):
+                can = valid[:, s] & not_self[:, s] & ~(cur < state[:, s]) & (count < max_out)
+                if not bool(can.any()):
+                    continue
+                state[:, s] = torch.where(can, torch.full_like(state[:, s], big), state[:, s])
+                slot = count.clamp_max(out_width - 1)
+                result[rows, slot] = torch.where(can, pool_ids[:, s].to(torch.int32), result[rows, slot])
+                count = count + can.to(torch.int64)
+                ratio = torch.nan_to_num(pool_d / pair[:, s, :], nan=-big)
+                upd = can[:, None] & (cols[None, :] > s) & ~(cur < state)
+                state = torch.where(upd, torch.maximum(state, ratio), state)
+            if alpha == 1.0 or alpha < cur * alpha or not bool((count < max_out).any()):
+                break
+            cur *= alpha
+    else:
+        # IterativePruneStrategy (IP / cosine): 0 available, 1 added, 2 pruned
+        state = torch.zeros((B, P), dtype=torch.int8, device=dev)
+        cur = 1.0
+        while True:
+            for s in range(P):
+                can = valid[:, s] & not_self[:, s] & (state[:, s] == 0) & (count < max_out)
+                if not bool(can.any()):
+                    continue
+                state[:, s] = torch.where(can, torch.ones_like(state[:, s]), state[:, s])
+                slot = count.clamp_max(out_width - 1)
+                result[rows, slot] = torch.where(can, pool_ids[:, s].to(torch.int32), result[rows, slot])
+                count = count + can.to(torch.int64)
+                kill = can[:, None] & (cols[None, :] > s) & (state == 0) & (cur * pair[:, s, :] > pool_d)
+                state = torch.where(kill, torch.full_like(state, 2), state)
+            if alpha == 1.0 or not (alpha <= cur * alpha) or not bool((count < max_out).any()):
+                break
+            state = torch.where(state == 2, torch.zeros_like(state), state)
+            cur *= alpha
+    return result
+
+
+def _make_pool(ids, dists, greater, pool_size):
+    """Deduplicate (by id), sort by TotalOrder (distance, then id) and truncate (vamana_build.h:441-446)."""
+    import torch
+
+    ids = ids.clone()
+    bad = ids < 0
+    key = torch.where(bad, torch.full_like(ids, 2**40), ids)
+    order = torch.argsort(key, dim=1, stable=True)
+    ids_s = torch.gather(ids, 1, order)
+    d_s = torch.gather(dists, 1, order)
+    dup = torch.zeros_like(ids_s, dtype=torch.bool)
+    dup[:, 1:] = ids_s[:, 1:] == ids_s[:, :-1]
+    ids_s = torch.where(dup, torch.full_like(ids_s, -1), ids_s)
+    worst = -math.inf if greater else math.inf
+    d_s = torch.where(ids_s < 0, torch.full_like(d_s, worst), d_s)
+    # stable sort by distance keeps the id order among ties (ids already ascending)
+    order = torch.argsort(d_s, dim=1, descending=greater, stable=True)
+    ids_s = torch.gather(ids_s, 1, order)[:, :pool_size]
+    d_s = torch.gather(d_s, 1, order)[:, :pool_size]
+    return ids_s, d_s
+
+
+def find_medoid(data_f32) -> int:
+    """utils::find_medioid (core/medioid.h:292-353): the point closest (L2) to the component-wise mean."""
+    import torch
+
+    mean = data_f32.double().mean(0).float()
+    best, arg = math.inf, 0
+    for lo in range(0, data_f32.shape[0], 1 << 20):
+        d = ((data_f32[lo : lo + (1 << 20)] - mean) ** 2).sum(1)
+        v, i = torch.min(d, 0)
+        if float(v) < best:
+            best, arg = float(v), lo + int(i)
+    return arg
+
+
+def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildParameters, data_dtype=np.float32, device: int = 0,
+                        entry_point: int | None = None, progress=None):
+    """Build a Vamana graph over `d_data` (torch tensor on cuda:device in the device layout: rows padded to 16 elements).
+
+    Returns (d_graph [n, gstride] int32 with -1 padding, entry_point).
+    """
+    import torch
+
+    fn = as_functor(distance)
+    metric, greater = fn.metric, fn.greater
+    R = params.graph_max_degree
+    prune_to = params.prune_to or max(R - 4, 1)
+    L = params.window_size
+    gstride = (R + 15) // 16 * 16
+    dev = d_data.device
+    data_f32 = d_data[:, :d].float() if d_data.dtype != torch.float32 or d_data.shape[1] != d else d_data
+    graph = torch.full((n, gstride), INVALID, dtype=torch.int32, device=dev)
+    entry = find_medoid(data_f32) if entry_point is None else entry_point
+    d_entry = torch.tensor([entry], dtype=torch.int32, device=dev)
+    index = VamanaIndex.from_device(graph, d_data, fn, d_entry, n, d, data_dtype, device=device)
+    sp = VamanaSearchParameters(SearchBufferConfig(L))
+
+    nb = max(40, -(-n // 4096))
+    nb = min(nb, n)
+    bs = -(-n // nb)
+    H = 2 * L + 32  # history capacity (expanded nodes per query)
+    hist_ids = torch.empty((bs, H), dtype=torch.int32, device=dev)
+    hist_d = torch.empty((bs, H), dtype=torch.float32, device=dev)
+    hist_len = torch.empty((bs,), dtype=torch.int32, device=dev)
+    out_ids = torch.empty((bs, 1), dtype=torch.int32, device=dev)
+    hcols = torch.arange(H, device=dev)
+    pool_size = min(params.max_candidate_pool_size, H + R)
+    pool_size = min(pool_size, 256)  # bounds the [B,P,P] pairwise tensor; pool is sorted best-first before the cut
+    over_cap = 64
+
+    for pass_alpha in (1.0, params.alpha):
+        for b in range(nb):
+            lo, hi = min(n, bs * b), min(n, bs * (b + 1))
+            B = hi - lo
+            if B <= 0:
+                continue
+            node_ids = torch.arange(lo, hi, device=dev)
+            # ---- generate_neighbors: greedy search with the current graph --------------------------------------
+            index.search_device(d_data[lo:hi], 1, sp, d_ids32=out_ids[:B], history=(hist_ids[:B], hist_d[:B], hist_len[:B]),
+                                q_dtype={np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int8): 2, np.dtype(np.uint8): 3}[np.dtype(data_dtype)])
+            hl = hist_len[:B].clamp_max(H).to(torch.int64)
+            hid = torch.where(hcols[None, :] < hl[:, None], hist_ids[:B].to(torch.int64), torch.full((B, H), -1, dtype=torch.int64, device=dev))
+            hd = hist_d[:B]
+            adj = graph[lo:hi, :R].to(torch.int64)
+            adj_d = _point_dist(metric, data_f32[lo:hi], data_f32[adj.clamp_min(0)])
+            pool_ids, pool_d = _make_pool(torch.cat([hid, adj], 1), torch.cat([hd, adj_d], 1), greater, pool_size)
+            new_rows = _prune(metric, greater, data_f32, node_ids, pool_ids, pool_d, R, params.alpha, gstride)
+            graph[lo:hi] = new_rows
+            # ---- add_reverse_edges ---------------------------------------------------------------------------------
+            src = node_ids[:, None].expand(B, gstride).reshape(-1)
+            dst = new_rows.reshape(-1).to(torch.int64)
+            keep = dst >= 0
+            src, dst = src[keep], dst[keep]
+            present = (graph[dst, :R].to(torch.int64) == src[:, None]).any(1)
+            src, dst = src[~present], dst[~present]
+            if dst.numel() > 0:
+                order = torch.argsort(dst, stable=True)
+                src, dst = src[order], dst[order]
+                uniq, inv, cnt = torch.unique_consecutive(dst, return_inverse=True, return_counts=True)
+                start = torch.cumsum(cnt, 0) - cnt
+                rank = torch.arange(dst.numel(), device=dev) - start[inv]
+                deg = (graph[uniq, :R] >= 0).sum(1)
+                slot = deg[inv] + rank
+                fits = slot < R
+                graph[dst[fits], slot[fits]] = src[fits].to(torch.int32)
+                over = ~fits
+                if bool(over.any()):
+                    o_dst, o_src = dst[over], src[over]
+                    o_rank = slot[over] - R
+                    ok = o_rank < over_cap
+                    o_dst, o_src, o_rank = o_dst[ok], o_src[ok], o_rank[ok]
+                    ou, oinv = torch.unique_consecutive(o_dst, return_inverse=True)
+                    cand = torch.full((ou.numel(), R + over_cap), -1, dtype=torch.int64, device=dev)
+                    cand[:, :R] = graph[ou, :R].to(torch.int64)
+                    cand[oinv, R + o_rank] = o_src
+                    for c0 in range(0, ou.numel(), 4096):  # bound the pairwise tensor
+                        cu, cc = ou[c0 : c0 + 4096], cand[c0 : c0 + 4096]
+                        cd = _point_dist(metric, data_f32[cu], data_f32[cc.clamp_min(0)])
+                        p_ids, p_d = _make_pool(cc, cd, greater, R + over_cap)
+                        graph[cu] = _prune(metric, greater, data_f32, cu, p_ids, p_d, prune_to, pass_alpha, gstride)
+            if progress is not None:
+                progress(pass_alpha, b, nb)
+    torch.cuda.synchronize(dev)
+    return graph, entry
+
+
+def device_graph_to_svs(d_graph, max_degree: int) -> np.ndarray:
+    """Device layout -> SVS row layout [deg, ids...] (core/graph/graph.h:32-48) on the host."""
+    g = d_graph.cpu().numpy().view(np.uint32)
+    n = g.shape[0]
+    ids = g[:, :max_degree]
+    deg = (ids != 0xFFFFFFFF).sum(1).astype(np.uint32)
+    out = np.zeros((n, max_degree + 1), np.uint32)
+    out[:, 0] = deg
+    out[:, 1:] = np.where(ids != 0xFFFFFFFF, ids, 0)
+    return out

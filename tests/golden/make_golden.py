@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE'S OWN CODE (oracle/_ref: svs::index::vamana::greedy_search,
+SearchBuffer, VisitedFilter and simd::generic_simd_op compiled from /root/reference/include).
+
+Run in the build container (needs /root/reference and an AVX-512 host):  python tests/golden/make_golden.py
+The .npz files hold only inputs and expected outputs (data), no reference source.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle.oracle import COS, F16, F32, I8, IP, L2, U8, Oracle, Ref  # noqa: E402
+
+PAIRS = [(F32, F32), (F32, F16), (F16, F32), (F16, F16), (F32, I8), (F32, U8), (I8, I8), (U8, U8)]
+NAMES = {F32: "f32", F16: "f16", I8: "i8", U8: "u8"}
+
+
+def gen(rng, dt, n, d):
+    if dt == F32:
+        return rng.standard_normal((n, d)).astype(np.float32)
+    if dt == F16:
+        return rng.standard_normal((n, d)).astype(np.float16)
+    if dt == I8:
+        return rng.integers(-128, 128, (n, d)).astype(np.int8)
+    return rng.integers(0, 256, (n, d)).astype(np.uint8)
+
+
+def main():
+    ref, orc = Ref(), Oracle()
+    rng = np.random.default_rng(20260926)
+
+    # ---- distance known answers (K1-K6) ----------------------------------------------------------------------
+    out = {}
+    for d in (96, 100, 223):
+        for dt in (F32, F16, I8, U8):
+            out[f"a_{NAMES[dt]}_{d}"] = gen(rng, dt, 5, d)
+            out[f"b_{NAMES[dt]}_{d}"] = gen(rng, dt, 7, d)
+        for qa, qb in PAIRS:
+            for m in (L2, IP, COS):
+                out[f"dist_{NAMES[qa]}_{NAMES[qb]}_{m}_{d}"] = ref.distance_batch(m, out[f"a_{NAMES[qa]}_{d}"], out[f"b_{NAMES[qb]}_{d}"])
+    np.savez_compressed(os.path.join(HERE, "distances.npz"), **out)
+
+    # ---- search known answers: one graph, all type pairs / metrics / buffer configs ---------------------------
+    n, d, nq = 1000, 100, 24
+    a = np.random.default_rng(7).standard_normal((16, d)).astype(np.float32)
+    x = (rng.standard_normal((n, 16)).astype(np.float32) @ a + 0.1 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    q = (rng.standard_normal((nq, 16)).astype(np.float32) @ a + 0.1 * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+    graph, entry = orc.build_vamana(L2, x, R=24, L=40)
+    s = dict(graph=graph, entry=entry)
+    scale = 127.0 / np.abs(x).max()
+    variants = {
+        F32: (x, q), F16: (x.astype(np.float16), q.astype(np.float16)),
+        I8: (np.clip(np.round(x * scale), -128, 127).astype(np.int8), np.clip(np.round(q * scale), -128, 127).astype(np.int8)),
+        U8: (np.clip(np.round(x * scale + 128), 0, 255).astype(np.uint8), np.clip(np.round(q * scale + 128), 0, 255).astype(np.uint8)),
+    }
+    for dt, (xv, qv) in variants.items():
+        s[f"x_{NAMES[dt]}"] = xv
+        s[f"q_{NAMES[dt]}"] = qv
+    configs = [(10, 10, 10), (24, 24, 10), (12, 30, 8), (3, 3, 10), (64, 64, 20)]
+    s["configs"] = np.array(configs)
+    for qa, qb in PAIRS:
+        for m in (L2, IP, COS):
+            for ci, (w, c, k) in enumerate(configs):
+                ids, dists, st = ref.search(m, variants[qb][0], graph, entry, variants[qa][1], k, w, c, stats=True)
+                # the reference's own visited-set / multi-thread variants must agree (result-neutral)
+                ids2, d2 = ref.search(m, variants[qb][0], graph, entry, variants[qa][1], k, w, c, visited_set=True, nthreads=3)
+                assert (ids == ids2).all() and (dists.view(np.uint32) == d2.view(np.uint32)).all()
+                key = f"{NAMES[qa]}_{NAMES[qb]}_{m}_{ci}"
+                s["ids_" + key] = ids
+                s["dists_" + key] = dists
+                s["stats_" + key] = st
+    np.savez_compressed(os.path.join(HERE, "search.npz"), **s)
+
+    # ---- SearchBuffer op trace (split window/capacity, ties, duplicate ids) -------------------------------------
+    t = {}
+    for name, greater, w, c in (("less", False, 6, 10), ("greater", True, 5, 5)):
+        rb = ref.buffer(w, c, greater)
+        ops, snaps = [], []
+        rb.push_back(7, 3.0)
+        rb.sort()
+        ops.append((0, 7, 3.0))
+        for step in range(400):
+            if not rb.done() and rng.random() < 0.25:
+                i, dd = rb.next()
+                ops.append((1, i, dd))
+            else:
+                i = int(rng.integers(0, 60))
+                dd = float((i * 5) % 11)
+                r = rb.insert(i, dd)
+                ops.append((2, i, dd))
+            st = rb.state()
+            snap = np.full((c, 3), -1.0)
+            for j, (ii, d2, v) in enumerate(st):
+                snap[j] = (ii, d2, v)
+            snaps.append(np.concatenate([[rb.size(), rb.best_unvisited(), float(rb.done())], snap.ravel()]))
+        t[f"ops_{name}"] = np.array(ops, dtype=np.float64)
+        t[f"snaps_{name}"] = np.array(snaps)
+        t[f"cfg_{name}"] = np.array([w, c, int(greater)])
+    np.savez_compressed(os.path.join(HERE, "buffer_trace.npz"), **t)
+    for f in ("distances.npz", "search.npz", "buffer_trace.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

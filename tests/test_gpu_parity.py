@@ -178,3 +178,87 @@ def test_multiple_entry_points(svs, oracle, small_world):
     entry = np.array([int(sw["entry"][0]), 3, 700], np.uint32)
     res, st, ids, dists, ost = _search_both(svs, oracle, L2, svs.DistanceL2(), sw["x"], sw["graph"], entry, sw["q"], 10, 20, 20)
     assert (res.indices == ids.astype(np.uint64)).all()
+
+
+# ---- committed golden vectors (generated from the reference's own code, tests/golden/make_golden.py) -----------
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = {F32: "f32", F16: "f16", I8: "i8", U8: "u8"}
+
+
+def test_golden_distances_on_gpu(svs):
+    g = np.load(os.path.join(GOLD, "distances.npz"))
+    fns = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}
+    for d in (96, 100, 223):
+        for qa, qb in PAIRS:
+            for m in (L2, IP, COS):
+                got = svs.compute(fns[m], g[f"a_{NAMES[qa]}_{d}"], g[f"b_{NAMES[qb]}_{d}"])
+                want = g[f"dist_{NAMES[qa]}_{NAMES[qb]}_{m}_{d}"]
+                assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all(), (d, qa, qb, m)
+
+
+def test_golden_search_on_gpu(svs):
+    g = np.load(os.path.join(GOLD, "search.npz"))
+    fns = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}
+    for qa, qb in PAIRS:
+        for m in (L2, IP, COS):
+            idx = svs.VamanaIndex(g["graph"], g[f"x_{NAMES[qb]}"], fns[m], g["entry"])
+            for ci, (w, c, k) in enumerate(g["configs"]):
+                res, st = idx.search(g[f"q_{NAMES[qa]}"], int(k), svs.VamanaSearchParameters(svs.SearchBufferConfig(int(w), int(c))), stats=True)
+                key = f"{NAMES[qa]}_{NAMES[qb]}_{m}_{ci}"
+                assert (res.indices == g["ids_" + key].astype(np.uint64)).all(), key
+                assert (res.distances.view(np.uint32) == g["dists_" + key].view(np.uint32)).all(), key
+                assert (st[:, :2].astype(np.uint64) == g["stats_" + key]).all(), key
+
+
+def test_device_resident_search_and_u32_ids(svs, oracle, small_world):
+    """svsx_search_device: queries/results in HBM, enqueued on torch's current stream; 32- and 64-bit ids agree."""
+    import torch
+
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    q = torch.from_numpy(sw["q"]).cuda()
+    ids64 = torch.empty((64, 10), dtype=torch.int64, device="cuda")
+    ids32 = torch.empty((64, 10), dtype=torch.int32, device="cuda")
+    dists = torch.empty((64, 10), dtype=torch.float32, device="cuda")
+    idx.search_device(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(20, 32)), d_ids64=ids64, d_ids32=ids32, d_dists=dists)
+    torch.cuda.synchronize()
+    ids, d = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 20, 32)
+    assert (ids64.cpu().numpy() == ids).all() and (ids32.cpu().numpy() == ids.astype(np.int32)).all()
+    assert (dists.cpu().numpy().view(np.uint32) == d.view(np.uint32)).all()
+
+
+def test_full_size_properties(svs):
+    """BASELINE-size invariants that do not need the oracle: 200k x 96 index, 4096 queries, window 128:
+    rows sorted best-first, ids unique and in range, result independent of batch composition (idempotence /
+    permutation of the query batch), distances recomputable from the ids."""
+    import torch
+
+    from bench import brute_force_topk, deep_like_device
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device
+
+    dev = torch.device("cuda", 0)
+    n, d, nq, k = 200_000, 96, 4096, 10
+    x = deep_like_device(n, d, 24, 1, dev)
+    q = deep_like_device(nq, d, 24, 2, dev)
+    graph, entry = build_vamana_device(x, n, d, svs.DistanceL2(), VamanaBuildParameters(graph_max_degree=32, window_size=64, prune_to=28), device=0)
+    idx = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), torch.tensor([entry], dtype=torch.int32, device=dev), n, d, np.float32)
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(128))
+    ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    idx.search_device(q, k, sp, d_ids64=ids, d_dists=dist)
+    perm = torch.randperm(nq, device=dev)
+    ids2 = torch.empty_like(ids)
+    dist2 = torch.empty_like(dist)
+    idx.search_device(q[perm].contiguous(), k, sp, d_ids64=ids2, d_dists=dist2)
+    torch.cuda.synchronize()
+    assert (ids[perm] == ids2).all() and (dist[perm] == dist2).all()
+    assert (dist[:, 1:] >= dist[:, :-1]).all()
+    assert int(ids.min()) >= 0 and int(ids.max()) < n
+    assert (torch.sort(ids, 1).values[:, 1:] != torch.sort(ids, 1).values[:, :-1]).all()
+    recomputed = ((x[ids] - q[:, None, :]) ** 2).sum(-1)
+    assert torch.allclose(recomputed, dist, rtol=1e-4, atol=1e-6)
+    gt = brute_force_topk(x, q, k)
+    recall = (ids[:, :, None] == gt[:, None, :]).any(2).float().mean().item()
+    assert recall > 0.95, recall

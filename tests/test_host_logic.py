@@ -1,0 +1,70 @@
+"""Host-side mirror of the reference interface: parameter objects, recall, error behaviour.  No GPU needed."""
+import numpy as np
+import pytest
+
+import scalablevectorsearch_amd as svs
+
+
+def test_search_buffer_config_mirror():
+    """tests/svs/index/vamana/search_buffer.cpp:314-331."""
+    c = svs.SearchBufferConfig()
+    assert (c.get_search_window_size(), c.get_total_capacity()) == (0, 0)
+    c = svs.SearchBufferConfig(10)
+    assert (c.get_search_window_size(), c.get_total_capacity()) == (10, 10)
+    c = svs.SearchBufferConfig(10, 20)
+    assert (c.get_search_window_size(), c.get_total_capacity()) == (10, 20)
+    with pytest.raises(svs.SvsxError):
+        svs.SearchBufferConfig(10, 9)
+    assert svs.SearchBufferConfig(3, 4) == svs.SearchBufferConfig(3, 4)
+
+
+def test_search_parameters_defaults():
+    """index/vamana/search_params.h:28-61 defaults."""
+    p = svs.VamanaSearchParameters()
+    assert p.search_buffer_visited_set is False and p.prefetch_lookahead == 4 and p.prefetch_step == 1
+    c = p._c()
+    assert (c.search_window_size, c.search_buffer_capacity, c.visited_set) == (0, 0, 0)
+
+
+def test_k_recall_at_n_mirror(oracle):
+    """tests/svs/core/recall.cpp:44-86 incl. the argument errors and the n-recall@n default."""
+    gt = np.array([[1, 2, 3, 4]])
+    res = np.array([[1, 0, 5, 6, 7, 2, 3, 4]])
+    want = {(1, 1): 1.0, (2, 2): 0.5, (3, 3): 1 / 3, (4, 4): 0.25, (4, 5): 0.25, (4, 6): 0.5, (4, 7): 0.75, (4, 8): 1.0}
+    for (k, n), v in want.items():
+        assert svs.k_recall_at_n(gt, res, k, n) == pytest.approx(v)
+    res2 = np.array([[0, 2]])
+    assert svs.k_recall_at_n(gt, res2, 1, 2) == 0
+    assert svs.k_recall_at_n(gt, res2, 2, 2) == 0.5
+    assert svs.k_recall_at_n(gt, res2) == 0.5
+    with pytest.raises(svs.SvsxError):
+        svs.k_recall_at_n(gt, res2, 2, 1)
+    with pytest.raises(svs.SvsxError):
+        svs.k_recall_at_n(gt, res2, 2, 5)
+    with pytest.raises(svs.SvsxError):
+        svs.k_recall_at_n(gt, np.zeros((1, 10), int))
+    with pytest.raises(svs.SvsxError):
+        svs.k_recall_at_n(gt, np.zeros((1, 10), int), 5, 5)
+    # bulk: mean of per-row recalls, and agreement with the oracle's restatement
+    rng = np.random.default_rng(0)
+    g = rng.integers(0, 100, (16, 4))
+    r = rng.integers(0, 100, (16, 8))
+    g = np.array([rng.permutation(100)[:4] for _ in range(16)])
+    r = np.array([rng.permutation(100)[:8] for _ in range(16)])
+    rows = np.mean([svs.k_recall_at_n(g[i : i + 1], r[i : i + 1], 3, 5) for i in range(16)])
+    assert svs.k_recall_at_n(g, r, 3, 5) == pytest.approx(rows, rel=1e-5)
+    assert svs.k_recall_at_n(g, r, 3, 5) == pytest.approx(oracle.recall(g, r, 3, 5))
+
+
+def test_distance_functor_surface():
+    """concepts/distance.h / core/distance/*.h: compare direction, names, enum <-> functor dispatch."""
+    assert svs.DistanceL2().greater is False and svs.DistanceIP().greater and svs.DistanceCosineSimilarity().greater
+    assert svs.DistanceL2.name == "squared_l2" and svs.DistanceIP.name == "inner_product"
+    from scalablevectorsearch_amd.distance import as_functor
+
+    assert isinstance(as_functor(svs.DistanceType.MIP), svs.DistanceIP)
+    assert isinstance(as_functor(svs.DistanceCosineSimilarity), svs.DistanceCosineSimilarity)
+    with pytest.raises(svs.SvsxError):
+        svs.compute(svs.DistanceL2(), np.zeros((1, 4), np.float64), np.zeros((1, 4), np.float32))
+    with pytest.raises(svs.SvsxError):
+        svs.compute(svs.DistanceL2(), np.zeros((1, 4), np.float32), np.zeros((1, 5), np.float32))

@@ -1,0 +1,217 @@
+"""The CPU oracle against the reference's OWN tests, restated.  No GPU needed.
+
+Each test names the reference test it restates (paths relative to the reference root)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import COS, F16, F32, I8, IP, L2, U8
+
+
+def test_search_buffer_insert_known_answers(oracle):
+    """tests/svs/index/vamana/search_buffer.cpp:382-520 -- cases 1a..6b, verbatim expectations."""
+    b = oracle.buffer(5, 5)
+    assert b.size() == 0
+    b.push_back(1, 10)
+    assert b.get(0)[:2] == (1, 10.0)
+    assert b.insert(2, 20) == 1 and b.size() == 2                      # 1a
+    b.b.e[1].visited = 1
+    assert b.insert(2, 20) == b.size() + 1 and b.size() == 2           # 1b duplicate
+    assert b.state() == [(1, 10.0, False), (2, 20.0, True)]
+    assert b.insert(3, 5) == 0 and b.size() == 3                       # 2a
+    assert b.state() == [(3, 5.0, False), (1, 10.0, False), (2, 20.0, True)]
+    assert b.insert(3, 5) == b.size() + 1                              # 2b
+    assert b.insert(4, 15) == 2 and b.size() == 4                      # 3a
+    assert b.state() == [(3, 5.0, False), (1, 10.0, False), (4, 15.0, False), (2, 20.0, True)]
+    assert b.insert(4, 15) == b.size() + 1                             # 3b
+    assert b.insert(5, 30) == 4 and b.size() == 5                      # prep 4
+    assert b.insert(6, 1000) == 5 and b.size() == 5                    # 4: end of a full buffer
+    assert b.state() == [(3, 5.0, False), (1, 10.0, False), (4, 15.0, False), (2, 20.0, True), (5, 30.0, False)]
+    assert b.insert(7, 1) == 0 and b.size() == 5                       # 5a
+    assert b.state() == [(7, 1.0, False), (3, 5.0, False), (1, 10.0, False), (4, 15.0, False), (2, 20.0, True)]
+    assert b.insert(7, 1) == b.size() + 1                              # 5b
+    assert b.insert(8, 8) == 2 and b.size() == 5                       # 6a
+    assert b.state() == [(7, 1.0, False), (3, 5.0, False), (8, 8.0, False), (1, 10.0, False), (4, 15.0, False)]
+    assert b.insert(8, 8) == b.size() + 1                              # 6b
+    b.clear()
+    assert b.size() == 0
+
+
+def test_search_buffer_sorting_and_config(oracle):
+    """search_buffer.cpp:314-342 (config invariant) and :525-545 (sort, both comparators)."""
+    b = oracle.buffer(5, 5)
+    for i, d in ((1, 100), (2, 10), (3, 50)):
+        b.push_back(i, d)
+    b.sort()
+    assert [e[:2] for e in b.state()] == [(2, 10.0), (3, 50.0), (1, 100.0)]
+    g = oracle.buffer(5, 5, greater=True)
+    for i, d in ((1, 100), (2, 10), (3, 50)):
+        g.push_back(i, d)
+    g.sort()
+    assert [e[:2] for e in g.state()] == [(1, 100.0), (3, 50.0), (2, 10.0)]
+    with pytest.raises(ValueError):
+        oracle.buffer(10, 9)
+    b = oracle.buffer(10, 20)
+    assert (b.b.window, b.b.capacity) == (10, 20)
+
+
+def test_search_buffer_cannot_push_off_the_edge(oracle):
+    """search_buffer.cpp 'Can't push off the edge': push_back on a full buffer is a no-op."""
+    b = oracle.buffer(3, 3)
+    for i in range(5):
+        b.push_back(i, float(i))
+    assert b.size() == 3 and [e[0] for e in b.state()] == [0, 1, 2]
+
+
+def test_search_buffer_fuzz_against_reference_model(oracle):
+    """search_buffer.cpp:50-130,590-611: fuzz against the in-test model SearchBufferReference
+    (global visited set, linear insert after non-greater, shrink to capacity), less and greater, (32,32) and (32,64)."""
+    rng = np.random.default_rng(0xC0FFEE)
+    for greater in (False, True):
+        for roi, cap in ((32, 32), (32, 64)):
+            b = oracle.buffer(roi, cap, greater)
+            for _ in range(5):
+                b.clear()
+                model, seen = [], set()
+                for _ in range(1000):
+                    i, d = int(rng.integers(0, 1000)), float(rng.integers(0, 200))
+                    if i in seen:
+                        continue
+                    seen.add(i)
+                    b.insert(i, d)
+                    pos = 0
+                    while pos < len(model) and not ((d > model[pos][1]) if greater else (d < model[pos][1])):
+                        pos += 1
+                    model.insert(pos, (i, d))
+                    del model[cap:]
+                    assert [e[:2] for e in b.state()] == model
+
+
+def test_visited_filter_protocol(oracle):
+    """tests/svs/index/vamana/filter.cpp:34-103 for VisitedFilter<uint32_t,16>."""
+    import ctypes as C
+
+    f = (C.c_uint16 * 65536)()
+    L = oracle.lib
+    L.svso_filter_reset(f)
+    cap = 65536
+    first, second = range(0, cap, 97), range(cap, 2 * cap, 97)
+    assert not any(L.svso_filter_contains(f, i) for i in first)
+    assert not any(L.svso_filter_emplace(f, i) for i in first)
+    assert all(L.svso_filter_contains(f, i) for i in first)
+    assert all(L.svso_filter_emplace(f, i) for i in first)
+    assert not any(L.svso_filter_emplace(f, i) for i in second)
+    assert not any(L.svso_filter_contains(f, i) for i in first)
+    assert all(L.svso_filter_contains(f, i) for i in second)
+    assert not any(L.svso_filter_emplace(f, i) for i in first)
+    assert not any(L.svso_filter_contains(f, i) for i in second)
+    assert all(L.svso_filter_contains(f, i) for i in first)
+    L.svso_filter_reset(f)
+    assert all(v == 0xFFFF for v in f)
+
+
+def test_recall_known_answers(oracle):
+    """tests/svs/core/recall.cpp:44-68."""
+    gt = np.array([[1, 2, 3, 4]], np.uint32)
+    res = np.array([[1, 0, 5, 6, 7, 2, 3, 4]], np.uint32)
+    want = {(1, 1): 1.0, (2, 2): 0.5, (3, 3): 1 / 3, (4, 4): 0.25, (4, 5): 0.25, (4, 6): 0.5, (4, 7): 0.75, (4, 8): 1.0}
+    for (k, n), v in want.items():
+        assert oracle.recall(gt, res, k, n) == pytest.approx(v, abs=1e-15)
+    res2 = np.array([[0, 2]], np.uint32)
+    assert oracle.recall(gt, res2, 1, 2) == 0
+    assert oracle.recall(gt, res2, 2, 2) == 0.5
+
+
+def _double_reference(metric, a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    if metric == L2:
+        return ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+    ip = a @ b.T
+    if metric == IP:
+        return ip
+    return ip / (np.linalg.norm(a, axis=1)[:, None] * np.linalg.norm(b, axis=1)[None, :])
+
+
+@pytest.mark.parametrize("d", [160, 223])
+def test_distances_against_double_precision_reference(oracle, d):
+    """tests/svs/core/distances/distance_euclidean.cpp:42-122 (Approx default = 100*FLT_EPSILON relative),
+    inner_product.cpp:45-132 (eps 0.02, margin 0.03), cosine.cpp:46-135 (eps 0.01, margin 0.015); dims 160 and 223."""
+    rng = np.random.default_rng(d)
+
+    def gen(dt):
+        if dt == F32:
+            return rng.uniform(-1, 1, (20, d)).astype(np.float32)
+        if dt == F16:
+            return rng.uniform(-1, 1, (20, d)).astype(np.float16)
+        if dt == I8:
+            return rng.integers(-128, 128, (20, d)).astype(np.int8)
+        return rng.integers(0, 256, (20, d)).astype(np.uint8)
+
+    for qa, qb in [(F32, F32), (F32, F16), (F16, F16), (F32, U8), (U8, U8), (F32, I8), (I8, I8)]:
+        a, b = gen(qa), gen(qb)
+        got = oracle.distance_batch(L2, a, b)
+        want = _double_reference(L2, a, b)
+        assert np.allclose(got, want, rtol=100 * np.finfo(np.float32).eps, atol=0)
+        got = oracle.distance_batch(IP, a, b)
+        assert np.allclose(got, _double_reference(IP, a, b), rtol=0.02, atol=0.03)
+        got = oracle.distance_batch(COS, a, b)
+        assert np.allclose(got, _double_reference(COS, a, b), rtol=0.01, atol=0.015)
+
+
+def test_unspecialised_type_pairs_are_reported(oracle):
+    with pytest.raises(ValueError):
+        oracle.distance_batch(L2, np.zeros((1, 4), np.int8), np.zeros((1, 4), np.float32))
+    with pytest.raises(ValueError):
+        oracle.distance_batch(L2, np.zeros((1, 4), np.float16), np.zeros((1, 4), np.uint8))
+
+
+def test_scalar_quantization_formulas(oracle):
+    """tests/svs/quantization/scalar/scalar.cpp:30-312: scale/bias from global extrema, reconstruction error <= scale/2
+    (+rounding), compressed distances close to the float distances (eps 0.01, margin 0.01 scaled)."""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-3, 5, (200, 32)).astype(np.float32)
+    for code, lo, hi in ((I8, -128, 127), (U8, 0, 255)):
+        codes, scale, bias = oracle.sq_compress(x, code)
+        assert scale == pytest.approx((x.max() - x.min()) / (hi - lo), rel=1e-6)
+        assert bias == pytest.approx(x.min() - lo * scale, rel=1e-5, abs=1e-6)
+        recon = scale * codes.astype(np.float32) + bias
+        assert np.abs(recon - x).max() <= scale / 2 * 1.001 + 1e-6
+        assert codes.min() == lo and codes.max() == hi
+    # SQ search on an index: ids close to the uncompressed search (reference integration test tolerance 0.008 recall)
+    g, ep = oracle.build_vamana(L2, x, R=16, L=24)
+    q = rng.uniform(-3, 5, (40, 32)).astype(np.float32)
+    gt, _ = oracle.flat_search(L2, x, q, 5)
+    codes, scale, bias = oracle.sq_compress(x, I8)
+    ids_f, _ = oracle.search(L2, x, g, ep, q, 5, 24)
+    ids_q, dq = oracle.search(L2, codes, g, ep, q, 5, 24, sq=(scale, bias))
+    assert abs(oracle.recall(gt, ids_f, 5, 5) - oracle.recall(gt, ids_q, 5, 5)) < 0.05
+    # SQ-L2 distance == scale^2 * integer L2 of the codes
+    qc = np.clip(np.round((q - bias) / scale), -128, 127).astype(np.int32)
+    exact = ((qc[:, None, :] - codes[ids_q].astype(np.int32)) ** 2).sum(-1).astype(np.float32) * np.float32(scale * scale)
+    assert np.allclose(dq, exact, rtol=1e-6)
+
+
+def test_half_conversions_are_exact(oracle):
+    """lib/float16.h + simd_utils.h:271-277: half->float is exact for every half (checked against numpy)."""
+    h = np.arange(65536, dtype=np.uint16)
+    want = h.view(np.float16).astype(np.float32)
+    got = np.array([oracle.lib.svso_half_to_float(int(v)) for v in h[::7]], np.float32)
+    w = want[::7]
+    assert ((got == w) | (np.isnan(got) & np.isnan(w))).all()
+
+
+def test_batch_search_plumbing(oracle, small_world):
+    """tests/svs/index/index.cpp:85-184 (batch API plumbing): result shape, k > capacity raises the buffer to k
+    (index/vamana/index.h:590-592), rows sorted best-first, ids valid, split-buffer equals itself across calls."""
+    sw = small_world
+    ids, dists = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 20, 4, 4)
+    ids2, dists2 = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 20, 20, 20)
+    assert ids.shape == (64, 20) and (ids == ids2).all() and (dists == dists2).all()
+    assert (np.diff(dists, axis=1) >= 0).all() and ids.max() < 1500
+    gt, gd = oracle.flat_search(L2, sw["x"], sw["q"], 10)
+    ids, _ = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 48)
+    assert oracle.recall(gt, ids, 10, 10) > 0.95
+    # visited set on/off is result-neutral (greedy_search.h:191-193)
+    a = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 24, 40, visited_set=True)
+    b = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 24, 40, visited_set=False)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
