@@ -249,11 +249,57 @@ def main():
         },
     }
 
+    if world == 1:
+        # smallest window with recall@10 >= 0.9 (binary search of index/vamana/calibrate.h:286-300), timed the same way
+        lo_w, hi_w = k, args.window
+        while lo_w < hi_w:
+            mid = (lo_w + hi_w) // 2
+            index.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(mid)), d_ids64=ids, d_dists=dists)
+            torch.cuda.synchronize()
+            if recall_at(gt, ids, k) >= 0.9:
+                hi_w = mid
+            else:
+                lo_w = mid + 1
+        sp_m = svs.VamanaSearchParameters(svs.SearchBufferConfig(lo_w))
+        for _ in range(args.warmup):
+            index.search_device(q, k, sp_m, d_ids64=ids, d_dists=dists)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            index.search_device(q, k, sp_m, d_ids64=ids, d_dists=dists)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        matched = {"window": lo_w, "recall_at_10": recall_at(gt, ids, k), "gpu_qps": nq * args.steps / dt}
+        ids_matched = ids.clone()
+        result["config"]["matched_recall_point"] = matched
+        index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)  # restore window-128 results for the parity sample
+        torch.cuda.synchronize()
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(x, q, graph, entry, R, k, args.window, ids)
+        cm = cpu_baseline(x, q, graph, entry, R, k, matched["window"], ids_matched)
+        matched["cpu_qps"] = cm["value"]
+        matched["cpu_cores"] = cm["cores"]
+        matched["gpu_over_cpu"] = matched["gpu_qps"] / cm["value"]
+        matched["ids_identical_on_sample"] = "identical on sample: True" in cm["sample"]
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_cores():
+    """Threads the host leg may really use: min(affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(x, q, graph, entry, R, k, window, gpu_ids):
@@ -268,11 +314,7 @@ def cpu_baseline(x, q, graph, entry, R, k, window, gpu_ids):
     qh = q.cpu().numpy()
     gh = device_graph_to_svs(graph, R)
     eh = np.array([entry], np.uint32)
-    ncores = os.cpu_count() or 1
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    ncores = host_cores()
     if Ref.available():
         r = Ref()
         kind, threads = "reference", ncores

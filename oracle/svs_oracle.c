@@ -482,7 +482,7 @@ int svso_greedy_search(
         scratch = (float*)malloc(ix->d * sizeof(float));
         if (!scratch) { free(fq.owned); return -2; }
     }
-    svso_stats local = {0, 0, 0};
+    svso_stats local = {0, 0, 0, 0};
     size_t hlen = 0;
 
     svso_buffer_clear(buf);
@@ -507,6 +507,9 @@ int svso_greedy_search(
         hlen++;
         for (uint32_t j = 0; j < deg; ++j) {
             uint32_t id = row[1 + j];
+            if (stats) { /* analysis counter: how many slots a buffer-membership prefilter would skip */
+                for (size_t t = 0; t < buf->size; ++t) if (buf->e[t].id == id) { local.in_buffer++; break; }
+            }
             if (buf->filter && svso_filter_emplace(buf->filter, id)) continue; /* :191-193 */
             float dd = index_distance(ix, &fq, id, scratch);
             local.distance_evals++;

@@ -84,6 +84,13 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc, gfx950).  scalablevectorsearch_amd has no CPU fallback."
             )
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Import torch FIRST so that
+        # libsvsx.so binds to the runtime torch already loaded (same SONAME) instead of pulling in /opt/rocm's copy,
+        # which would leave torch unable to see the GPU afterwards.  Without torch the RUNPATH (/opt/rocm) is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - plain C/C++ hosts
+            pass
         L = C.CDLL(LIB_PATH)
         L.svsx_last_error.restype = C.c_char_p
         L.svsx_version.restype = C.c_char_p
