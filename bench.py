@@ -212,6 +212,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     shard_queries_per_s = world * nq * args.steps / elapsed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(n, nq, args.window, R) if world == 1 else (None, None)
     result = {
         "metric": "QPS at recall@10>=0.9 (batch=10k); achieved HBM GB/s vs roofline",
         "value": shard_queries_per_s,
@@ -242,7 +243,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "kernel": "svsx::search_kernel<f32,L2,float,96>",
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
@@ -284,6 +286,22 @@ def main():
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(n, nq, window, degree):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_pmc.json, produced by tools/collect_pmc.sh: separate --pmc passes, gfx950 FETCH_SIZE x2 correction
+    calibrated on a known stream).  bench.py cannot host the profiler itself; returns (None, None) if no pass matches."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            if j["workload"] == {"n": n, "d": 96, "nq": nq, "window": window, "degree": degree}:
+                return float(j["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def host_cores():

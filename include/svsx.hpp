@@ -1,0 +1,131 @@
+// svsx.hpp -- header-only C++ facade over the C ABI (svsx.h), shaped like the reference operator for this path.
+//
+// Mirrors (paths relative to the reference root):
+//   svs::index::vamana::VamanaIndex::search(QueryResultView<I>, queries, VamanaSearchParameters, cancel)
+//                                                                          index/vamana/index.h:564-611
+//   svs::index::vamana::VamanaSearchParameters / SearchBufferConfig        search_params.h:28-61, search_buffer.h:39-96
+//   svs::QueryResult<size_t>                                               core/query_result.h:53-172
+//   svs::distance::DistanceL2 / DistanceIP / DistanceCosineSimilarity      core/distance/*.h (compare, implicit_broadcast)
+//   svs::ANNException                                                      lib/exception.h
+// so that a caller written against the reference reads the same:  index.search(result.view(), queries, params).
+#pragma once
+
+#include "svsx.h"
+
+#include <cstdint>
+#include <functional>
+#include <limits>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace svsx {
+
+struct ANNException : std::runtime_error {
+    int code;
+    ANNException(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc) {
+    if (rc != SVSX_SUCCESS) throw ANNException(rc, svsx_last_error());
+}
+
+struct Float16 { uint16_t bits; };
+template <typename T> constexpr int dtype_of();
+template <> constexpr int dtype_of<float>() { return SVSX_F32; }
+template <> constexpr int dtype_of<Float16>() { return SVSX_F16; }
+template <> constexpr int dtype_of<int8_t>() { return SVSX_I8; }
+template <> constexpr int dtype_of<uint8_t>() { return SVSX_U8; }
+
+// distance functors: same static surface as the reference's (compare, implicit_broadcast, name)
+struct DistanceL2 { using compare = std::less<>; static constexpr bool implicit_broadcast = true; static constexpr int metric = SVSX_L2; static constexpr const char* name = "squared_l2"; };
+struct DistanceIP { using compare = std::greater<>; static constexpr bool implicit_broadcast = true; static constexpr int metric = SVSX_IP; static constexpr const char* name = "inner_product"; };
+struct DistanceCosineSimilarity { using compare = std::greater<>; static constexpr bool implicit_broadcast = false; static constexpr bool must_fix_argument = true; static constexpr int metric = SVSX_COSINE; static constexpr const char* name = "cosine_similarity"; };
+
+// distance::compute for every pair (a_i, b_j); out is na x nb
+template <typename Dist, typename Ea, typename Eb>
+void compute(Dist, const Ea* a, size_t na, const Eb* b, size_t nb, size_t d, float* out, int device = 0) {
+    check(svsx_distance_batch(Dist::metric, dtype_of<Ea>(), dtype_of<Eb>(), d, a, na, b, nb, out, device));
+}
+
+class SearchBufferConfig {
+    size_t window_ = 0, capacity_ = 0;
+  public:
+    SearchBufferConfig() = default;
+    SearchBufferConfig(size_t window) : window_(window), capacity_(window) {}
+    SearchBufferConfig(size_t window, size_t capacity) : window_(window), capacity_(capacity) {
+        if (window > capacity)
+            throw ANNException(SVSX_INVALID_ARGUMENT, "Improper configuration for search buffer! Effective size (" + std::to_string(window) +
+                                                          ") cannot be less than capacity (" + std::to_string(capacity) + ").");
+    }
+    size_t get_search_window_size() const { return window_; }
+    size_t get_total_capacity() const { return capacity_; }
+};
+
+struct VamanaSearchParameters {
+    SearchBufferConfig buffer_config_{};
+    bool search_buffer_visited_set_ = false;
+    size_t prefetch_lookahead_ = 4;
+    size_t prefetch_step_ = 1;
+    VamanaSearchParameters& buffer_config(SearchBufferConfig c) { buffer_config_ = c; return *this; }
+    VamanaSearchParameters& search_buffer_visited_set(bool v) { search_buffer_visited_set_ = v; return *this; }
+};
+
+template <typename Idx = size_t> struct QueryResultView {
+    Idx* indices; float* distances; size_t n_queries_, n_neighbors_;
+    size_t n_queries() const { return n_queries_; }
+    size_t n_neighbors() const { return n_neighbors_; }
+};
+
+template <typename Idx = size_t> class QueryResult {
+    std::vector<Idx> ids_; std::vector<float> dists_; size_t nq_, k_;
+  public:
+    QueryResult(size_t nq, size_t k) : ids_(nq * k), dists_(nq * k), nq_(nq), k_(k) {}
+    QueryResultView<Idx> view() { return {ids_.data(), dists_.data(), nq_, k_}; }
+    Idx index(size_t i, size_t j) const { return ids_[i * k_ + j]; }
+    float distance(size_t i, size_t j) const { return dists_[i * k_ + j]; }
+    size_t n_queries() const { return nq_; }
+    size_t n_neighbors() const { return k_; }
+};
+
+// Read-only Vamana index resident in one GPU's HBM.  Graph = SVS rows [deg, ids...] (core/graph/graph.h:32-48).
+template <typename T, typename Dist> class VamanaIndex {
+    svsx_index* h_ = nullptr;
+    VamanaSearchParameters defaults_{};
+  public:
+    VamanaIndex(const uint32_t* graph, size_t graph_row_stride, const T* data, size_t n, size_t d, std::span<const uint32_t> entry_points,
+                Dist = {}, int device = 0, uint64_t id_offset = 0) {
+        svsx_index_desc desc{};
+        desc.metric = Dist::metric; desc.data_dtype = dtype_of<T>(); desc.n = n; desc.d = d; desc.data = data;
+        desc.graph = graph; desc.graph_row_stride_u32 = graph_row_stride; desc.max_degree = static_cast<uint32_t>(graph_row_stride - 1);
+        desc.entry_points = entry_points.data(); desc.n_entry = entry_points.size(); desc.device = device; desc.id_offset = id_offset;
+        check(svsx_index_create(&desc, &h_));
+    }
+    VamanaIndex(const VamanaIndex&) = delete;
+    VamanaIndex& operator=(const VamanaIndex&) = delete;
+    VamanaIndex(VamanaIndex&& o) noexcept : h_(o.h_), defaults_(o.defaults_) { o.h_ = nullptr; }
+    ~VamanaIndex() { svsx_index_destroy(h_); }
+
+    VamanaSearchParameters get_search_parameters() const { return defaults_; }
+    void set_search_parameters(const VamanaSearchParameters& p) { defaults_ = p; }
+
+    // index/vamana/index.h:564-611.  `cancel` is polled once before the batch is enqueued (host-side only).
+    template <typename Q>
+    void search(QueryResultView<size_t> result, const Q* queries, const VamanaSearchParameters& sp,
+                const std::function<bool()>& cancel = [] { return false; }) const {
+        if (cancel()) return;
+        svsx_search_params p{sp.buffer_config_.get_search_window_size(), sp.buffer_config_.get_total_capacity(),
+                             sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
+        static_assert(sizeof(size_t) == sizeof(uint64_t));
+        check(svsx_search(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), &p,
+                          reinterpret_cast<uint64_t*>(result.indices), nullptr, result.distances, nullptr));
+    }
+    template <typename Q> QueryResult<size_t> search(const Q* queries, size_t nq, size_t k) const {
+        QueryResult<size_t> r(nq, k);
+        search(r.view(), queries, defaults_);
+        return r;
+    }
+};
+
+} // namespace svsx

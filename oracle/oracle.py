@@ -43,6 +43,35 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def merge_topk_ref(metric, gathered_d, gathered_i, k):
+    """Checker for the shard merge (SURVEY 8e rule): per query, best k of the S sorted lists by the metric's
+    comparator; ties -> lower shard, then position; padded entries (id == -1 / all-ones) are skipped."""
+    gd = np.asarray(gathered_d)
+    gi = np.asarray(gathered_i).astype(np.int64)
+    S, nq, kk = gd.shape
+    out_d = np.full((nq, k), np.inf, np.float32)
+    out_i = np.full((nq, k), -1, np.int64)
+    greater = metric != L2
+    for q in range(nq):
+        cur = [0] * S
+        for j in range(k):
+            best = -1
+            for s_ in range(S):
+                while cur[s_] < kk and gi[s_, q, cur[s_]] == -1:
+                    cur[s_] = kk
+                if cur[s_] >= kk:
+                    continue
+                dd = gd[s_, q, cur[s_]]
+                if best < 0 or (dd > bd if greater else dd < bd):
+                    best, bd = s_, dd
+            if best < 0:
+                break
+            out_d[q, j] = bd
+            out_i[q, j] = gi[best, q, cur[best]]
+            cur[best] += 1
+    return out_d, out_i
+
+
 class _Index(C.Structure):
     _fields_ = [
         ("metric", C.c_int), ("data_dtype", C.c_int), ("n", C.c_size_t), ("d", C.c_size_t),

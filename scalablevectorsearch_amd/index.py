@@ -148,7 +148,10 @@ class VamanaIndex:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().svsx_index_destroy(h)
+            try:
+                _lib.lib().svsx_index_destroy(h)
+            except Exception:  # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     # -- parameters (index.h:318, get/set_search_parameters) ---------------------------------------------------

@@ -1,0 +1,31 @@
+// Compiles the C++ facade (include/svsx.hpp) the way a reference user would call VamanaIndex::search and, when a GPU
+// is present, runs a tiny search: ring graph of 8 points on a line; the nearest neighbours of q are known.
+#include "svsx.hpp"
+
+#include <cstdio>
+#include <vector>
+
+int main(int argc, char**) {
+    const size_t n = 8, d = 4, R = 2;
+    std::vector<float> data(n * d, 0.0f);
+    for (size_t i = 0; i < n; ++i) data[i * d] = static_cast<float>(i);
+    std::vector<uint32_t> graph(n * (R + 1));
+    for (size_t i = 0; i < n; ++i) { graph[i * 3] = 2; graph[i * 3 + 1] = (i + 1) % n; graph[i * 3 + 2] = (i + n - 1) % n; }
+    const uint32_t entry[1] = {0};
+    std::vector<float> q = {5.2f, 0, 0, 0};
+    try {
+        svsx::SearchBufferConfig bad(10, 9);
+        return 10;
+    } catch (const svsx::ANNException&) {}
+    if (argc > 1) return 0; // compile/argument check only
+    try {
+        svsx::VamanaIndex<float, svsx::DistanceL2> index(graph.data(), R + 1, data.data(), n, d, {entry, 1});
+        svsx::QueryResult<size_t> result(1, 3);
+        index.search(result.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}));
+        std::printf("%zu %zu %zu\n", result.index(0, 0), result.index(0, 1), result.index(0, 2));
+        return (result.index(0, 0) == 5 && result.index(0, 1) == 6 && result.index(0, 2) == 4) ? 0 : 1;
+    } catch (const svsx::ANNException& e) {
+        std::printf("ANNException(%d): %s\n", e.code, e.what());
+        return 2;
+    }
+}

@@ -93,3 +93,31 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("oracle/", "oracle/") or f in ("build.py",) and "import oracle" not in text, (dirpath, f)
                 assert "svs_oracle" not in text and "import oracle" not in text and "from oracle" not in text, (dirpath, f)
+
+
+def _build_facade(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "facade_smoke")
+    pkg = os.path.join(ROOT, "scalablevectorsearch_amd")
+    subprocess.check_call(["g++", "-std=c++20", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "facade_smoke.cpp"),
+                           "-o", exe, "-L", pkg, "-lsvsx", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cxx_facade_compiles_and_validates(lib, tmp_path):
+    """include/svsx.hpp (VamanaIndex::search-shaped facade) builds against libsvsx.so; argument checks run on the host."""
+    import subprocess
+
+    exe = _build_facade(tmp_path)
+    assert subprocess.call([exe, "compile-only"]) == 0
+
+
+@pytest.mark.gpu
+def test_cxx_facade_search_on_gpu(lib, tmp_path):
+    import subprocess
+
+    exe = _build_facade(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.split() == ["5", "6", "4"]
