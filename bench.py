@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--window", type=int, default=128)
     ap.add_argument("--degree", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the multi-GPU code path (RCCL all-gather + merge) even at world size 1")
+    ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph here (lets a profiler run skip the build)")
     args = ap.parse_args()
 
@@ -98,9 +100,11 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     n, d, nq, k, R = args.n, 96, args.nq, 10, args.degree
     t0 = time.time()
@@ -127,12 +131,12 @@ def main():
 
     d_entry = torch.tensor([entry], dtype=torch.int32, device=device)
     index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n, d, np.float32, device=local_rank, id_offset=rank * n)
-    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window))
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window), search_buffer_visited_set=args.visited)
 
     ids = torch.empty((nq, k), dtype=torch.int64, device=device)  # written as uint64
     dists = torch.empty((nq, k), dtype=torch.float32, device=device)
     stats = torch.zeros((nq, 4), dtype=torch.int32, device=device)
-    if world > 1:
+    if multi:
         all_d = torch.empty((world, nq, k), dtype=torch.float32, device=device)
         all_i = torch.empty((world, nq, k), dtype=torch.int64, device=device)
         out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
@@ -144,7 +148,7 @@ def main():
 
     def step(with_stats=False):
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists, d_stats=stats if with_stats else None)
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(all_d.view(-1), dists.view(-1))
             dist.all_gather_into_tensor(all_i.view(-1), ids.view(-1))
             _lib.check(_lib.lib().svsx_merge_topk_device(0, world, nq, k, all_d.data_ptr(), all_i.data_ptr(), out_d.data_ptr(), out_i.data_ptr(),
@@ -154,7 +158,7 @@ def main():
     step(with_stats=True)
     torch.cuda.synchronize()
     gt_local = brute_force_topk(x, q, k) + rank * n
-    if world > 1:
+    if multi:
         # global ground truth = merge of per-shard exact top-k
         gd = ((q[:, None, :] - x[(gt_local - rank * n)]) ** 2).sum(-1)
         g_all_d = torch.empty((world, nq, k), device=device)
@@ -179,7 +183,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -188,31 +192,31 @@ def main():
         ev[i][0].record()
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
         ev[i][1].record()
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(all_d.view(-1), dists.view(-1))
             dist.all_gather_into_tensor(all_i.view(-1), ids.view(-1))
             _lib.check(_lib.lib().svsx_merge_topk_device(0, world, nq, k, all_d.data_ptr(), all_i.data_ptr(), out_d.data_ptr(), out_i.data_ptr(),
                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
     shard_queries_per_s = world * nq * args.steps / elapsed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(n, nq, args.window, R) if world == 1 else (None, None)
+    traffic, traffic_src = measured_traffic(n, nq, args.window, R, args.visited) if not multi else (None, None)
     result = {
         "metric": "QPS at recall@10>=0.9 (batch=10k); achieved HBM GB/s vs roofline",
         "value": shard_queries_per_s,
@@ -236,6 +240,8 @@ def main():
             "expansions_per_query": exp_total / nq,
             "neighbor_slots_per_query": slots_total / nq,
             "build_seconds": t_build,
+            "visited_filter": args.visited,
+            "distance_evals_per_query": int(st[:, 2].sum()) / nq,
         },
         "roofline": {
             "bound": "hbm",
@@ -251,18 +257,18 @@ def main():
         },
     }
 
-    if world == 1:
+    if not multi:
         # smallest window with recall@10 >= 0.9 (binary search of index/vamana/calibrate.h:286-300), timed the same way
         lo_w, hi_w = k, args.window
         while lo_w < hi_w:
             mid = (lo_w + hi_w) // 2
-            index.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(mid)), d_ids64=ids, d_dists=dists)
+            index.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(mid), args.visited), d_ids64=ids, d_dists=dists)
             torch.cuda.synchronize()
             if recall_at(gt, ids, k) >= 0.9:
                 hi_w = mid
             else:
                 lo_w = mid + 1
-        sp_m = svs.VamanaSearchParameters(svs.SearchBufferConfig(lo_w))
+        sp_m = svs.VamanaSearchParameters(svs.SearchBufferConfig(lo_w), args.visited)
         for _ in range(args.warmup):
             index.search_device(q, k, sp_m, d_ids64=ids, d_dists=dists)
         torch.cuda.synchronize()
@@ -276,7 +282,7 @@ def main():
         result["config"]["matched_recall_point"] = matched
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)  # restore window-128 results for the parity sample
         torch.cuda.synchronize()
-    if world == 1 and not args.no_cpu_baseline:
+    if not multi and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(x, q, graph, entry, R, k, args.window, ids)
         cm = cpu_baseline(x, q, graph, entry, R, k, matched["window"], ids_matched)
         matched["cpu_qps"] = cm["value"]
@@ -284,11 +290,11 @@ def main():
         matched["gpu_over_cpu"] = matched["gpu_qps"] / cm["value"]
         matched["ids_identical_on_sample"] = "identical on sample: True" in cm["sample"]
     print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
-def measured_traffic(n, nq, window, degree):
+def measured_traffic(n, nq, window, degree, visited):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_pmc.json, produced by tools/collect_pmc.sh: separate --pmc passes, gfx950 FETCH_SIZE x2 correction
     calibrated on a known stream).  bench.py cannot host the profiler itself; returns (None, None) if no pass matches."""
@@ -297,7 +303,7 @@ def measured_traffic(n, nq, window, degree):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
             j = json.load(open(f))
-            if j["workload"] == {"n": n, "d": 96, "nq": nq, "window": window, "degree": degree}:
+            if j["workload"] == {"n": n, "d": 96, "nq": nq, "window": window, "degree": degree, "visited": visited}:
                 return float(j["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             continue

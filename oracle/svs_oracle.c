@@ -482,7 +482,10 @@ int svso_greedy_search(
         scratch = (float*)malloc(ix->d * sizeof(float));
         if (!scratch) { free(fq.owned); return -2; }
     }
-    svso_stats local = {0, 0, 0, 0};
+    svso_stats local;
+    memset(&local, 0, sizeof(local));
+    static __thread uint32_t sim_filter[4][4096];
+    if (stats) memset(sim_filter, 0, sizeof(sim_filter));
     size_t hlen = 0;
 
     svso_buffer_clear(buf);
@@ -507,8 +510,15 @@ int svso_greedy_search(
         hlen++;
         for (uint32_t j = 0; j < deg; ++j) {
             uint32_t id = row[1 + j];
-            if (stats) { /* analysis counter: how many slots a buffer-membership prefilter would skip */
+            if (stats) { /* analysis counters (not part of the restated path) */
                 for (size_t t = 0; t < buf->size; ++t) if (buf->e[t].id == id) { local.in_buffer++; break; }
+                for (int fs = 0; fs < 4; ++fs) { /* exact-tag direct-mapped filters of 512..4096 entries */
+                    uint32_t mask = (512u << fs) - 1u;
+                    uint32_t h = (id * 2654435761u) >> 7;
+                    uint32_t* slot = &sim_filter[fs][h & mask];
+                    if (*slot == id + 1u) local.small_filter_hits[fs]++;
+                    *slot = id + 1u;
+                }
             }
             if (buf->filter && svso_filter_emplace(buf->filter, id)) continue; /* :191-193 */
             float dd = index_distance(ix, &fq, id, scratch);

@@ -155,7 +155,7 @@ def find_medoid(data_f32) -> int:
 
 
 def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildParameters, data_dtype=np.float32, device: int = 0,
-                        entry_point: int | None = None, progress=None):
+                        entry_point: int | None = None, progress=None, sq=None):
     """Build a Vamana graph over `d_data` (torch tensor on cuda:device in the device layout: rows padded to 16 elements).
 
     Returns (d_graph [n, gstride] int32 with -1 padding, entry_point).
@@ -170,10 +170,13 @@ def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildPar
     gstride = (R + 15) // 16 * 16
     dev = d_data.device
     data_f32 = d_data[:, :d].float() if d_data.dtype != torch.float32 or d_data.shape[1] != d else d_data
+    if sq is not None:  # SQDataset: build over the decompressed vectors (extensions/vamana/scalar.h:46-97)
+        data_f32 = data_f32 * float(sq[0]) + float(sq[1])
     graph = torch.full((n, gstride), INVALID, dtype=torch.int32, device=dev)
     entry = find_medoid(data_f32) if entry_point is None else entry_point
     d_entry = torch.tensor([entry], dtype=torch.int32, device=dev)
-    index = VamanaIndex.from_device(graph, d_data, fn, d_entry, n, d, data_dtype, device=device)
+    index = VamanaIndex.from_device(graph, d_data, fn, d_entry, n, d, data_dtype, device=device, sq=sq)
+    q_code = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int8): 2, np.dtype(np.uint8): 3}[np.dtype(data_dtype)]
     sp = VamanaSearchParameters(SearchBufferConfig(L))
 
     nb = max(40, -(-n // 4096))
@@ -197,8 +200,10 @@ def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildPar
                 continue
             node_ids = torch.arange(lo, hi, device=dev)
             # ---- generate_neighbors: greedy search with the current graph --------------------------------------
-            index.search_device(d_data[lo:hi], 1, sp, d_ids32=out_ids[:B], history=(hist_ids[:B], hist_d[:B], hist_len[:B]),
-                                q_dtype={np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int8): 2, np.dtype(np.uint8): 3}[np.dtype(data_dtype)])
+            if sq is None:
+                index.search_device(d_data[lo:hi], 1, sp, d_ids32=out_ids[:B], history=(hist_ids[:B], hist_d[:B], hist_len[:B]), q_dtype=q_code)
+            else:  # compressed distances take float queries: the decompressed rows
+                index.search_device(data_f32[lo:hi].contiguous(), 1, sp, d_ids32=out_ids[:B], history=(hist_ids[:B], hist_d[:B], hist_len[:B]), q_dtype=0)
             hl = hist_len[:B].clamp_max(H).to(torch.int64)
             hid = torch.where(hcols[None, :] < hl[:, None], hist_ids[:B].to(torch.int64), torch.full((B, H), -1, dtype=torch.int64, device=dev))
             hd = hist_d[:B]

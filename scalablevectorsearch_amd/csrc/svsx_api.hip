@@ -37,6 +37,7 @@ struct svsx_index {
 namespace {
 
 thread_local std::string g_error;
+constexpr uint32_t kDefaultFilterEntries = 2048;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -257,6 +258,17 @@ static int search_common(
     a.window = static_cast<uint32_t>(window);
     a.capacity = static_cast<uint32_t>(capacity);
     a.k = static_cast<uint32_t>(k);
+    // visited_set: 0 = off (reference default, search_params.h:42); 1 = on with the default LDS filter size;
+    // >= 64 = explicit number of filter entries (rounded down to a power of two, at most 16384).
+    if (params && params->visited_set > 0) {
+        uint32_t fe = params->visited_set == 1 ? kDefaultFilterEntries : static_cast<uint32_t>(params->visited_set);
+        if (fe < 64) fe = 64;
+        if (fe > 16384) fe = 16384;
+        while (fe & (fe - 1)) fe &= fe - 1;
+        // 16-bit tags must identify the id exactly: grow the table until (n >> log2 entries) < 0xFFFF, else stay off
+        while (fe <= 16384 && (ix->n >> __builtin_ctz(fe)) >= 0xFFFFu) fe <<= 1;
+        a.filter_entries = fe <= 16384 ? fe : 0;
+    }
     a.ids64 = d_ids64;
     a.ids32 = d_ids32;
     a.dists = d_dists;

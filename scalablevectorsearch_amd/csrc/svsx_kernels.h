@@ -26,6 +26,7 @@ struct SearchArgs {
     uint32_t nq;
     // parameters
     uint32_t window, capacity, k;
+    uint32_t filter_entries;  // 0 = no visited filter; else power of two (exact-tag direct-mapped filter in LDS)
     // outputs
     uint64_t* ids64;
     uint32_t* ids32;

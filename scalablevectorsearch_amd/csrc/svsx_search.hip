@@ -43,6 +43,17 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     const uint32_t buf_bytes = ((a.capacity + 1) * 8u + 15u) & ~15u;
     float* qf = reinterpret_cast<float*>(smem + buf_bytes);          // float path: dpad f32
     uint32_t* qw = reinterpret_cast<uint32_t*>(smem + buf_bytes);    // int path: dpad bytes
+    const uint32_t q_bytes = INTPATH ? static_cast<uint32_t>(dpad) : static_cast<uint32_t>(dpad) * 4u;
+    // VisitedFilter (index/vamana/filter.h:49-130, search_buffer.h:461-463) with the reference's own encoding: slot =
+    // low bits of the id, 16-bit tag = the remaining high bits, 0xFFFF = empty.  The host only enables it when
+    // (n >> log2(entries)) < 0xFFFF, so slot+tag identify the id exactly: no false positives -- a hit means the id was
+    // evaluated earlier in this query and re-inserting it would be a no-op (duplicate, or not better than the worst,
+    // which only improves).  Result-neutral by construction; it only removes vector re-fetches.
+    uint16_t* filt = reinterpret_cast<uint16_t*>(smem + buf_bytes + q_bytes);
+    uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + a.filter_entries * 2u); // 64 ids
+    const uint32_t fmask = a.filter_entries - 1u;
+    const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));
+    for (uint32_t i = lane; i < a.filter_entries; i += 64) filt[i] = 0xFFFFu;
 
     // ---- load + fix the query (maybe_fix_argument, greedy_search.h:140) -------------------------------------
     const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
                 const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
                 ++n_eval;
+                if (a.filter_entries != 0u && lane == 0) filt[id & fmask] = static_cast<uint16_t>(id >> fshift);
                 if (buf.size < buf.capacity) {
                     // push_back + (stable) sort == ordered insert without the duplicate check
                     uint32_t pos = 0;
@@ -118,8 +130,27 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         for (uint32_t gbase = 0; gbase < a.gstride; gbase += 64) {
             uint32_t nid = kInvalidId;
             if (gbase + lane < a.gstride) nid = grow[gbase + lane];
-            const uint32_t cnt = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
-            n_slots += cnt;
+            const uint32_t deg_here = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
+            n_slots += deg_here;
+            uint32_t cnt = deg_here;
+            if (a.filter_entries != 0u) {
+                // emplace_visited (greedy_search.h:191-193): drop ids already evaluated, keep adjacency order
+                bool keep = nid != kInvalidId;
+                if (keep) {
+                    const uint32_t h = nid & fmask;
+                    const uint16_t tag = static_cast<uint16_t>(nid >> fshift);
+                    keep = filt[h] != tag;
+                    filt[h] = tag;
+                }
+                const unsigned long long km = __ballot(keep);
+                cnt = __popcll(km);
+                const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
+                lds_order();
+                if (keep) compact[rank] = nid;
+                lds_order();
+                nid = lane < cnt ? compact[lane] : kInvalidId;
+                lds_order();
+            }
             for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
                 const uint32_t ci = p0 + grp;
                 const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
@@ -141,7 +172,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                     }
                 }
             }
-            if (cnt < 64u) break;
+            if (deg_here < 64u) break;
         }
     }
 
@@ -178,7 +209,8 @@ template <int DT, int METRIC, int QMODE, int DS> static hipError_t launch_one(co
     const int dpad = (d + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
-    const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4);
+    const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
+                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * 2 + 64 * 4 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = search_kernel<DT, METRIC, QMODE, DS>;
     if (lds > 48 * 1024) {

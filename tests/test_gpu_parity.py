@@ -286,3 +286,19 @@ def test_shard_merge_kernel_matches_rule(svs):
         wd, wi = merge_topk_ref(metric, d, i, k)
         assert (gi.cpu().numpy() == wi).all()
         assert (gd.cpu().numpy().view(np.uint32) == wd.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("entries", [1, 64, 256, 4096])
+def test_visited_filter_is_result_neutral(svs, oracle, small_world, entries):
+    """search_buffer_visited_set (greedy_search.h:191-193, filter.h): same ids, distance bits, expansions and
+    neighbour slots; only the number of distance evaluations may drop."""
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    for (w, c) in [(16, 16), (48, 64), (128, 128)]:
+        off, st0 = idx.search(sw["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c)), stats=True)
+        on, st1 = idx.search(sw["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), search_buffer_visited_set=entries), stats=True)
+        assert (off.indices == on.indices).all() and (off.distances.view(np.uint32) == on.distances.view(np.uint32)).all()
+        assert (st0[:, :2] == st1[:, :2]).all()
+        assert (st1[:, 2] <= st0[:, 2]).all() and st1[:, 2].sum() < st0[:, 2].sum()
+        ids, dists = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, w, c, visited_set=True)
+        assert (on.indices == ids.astype(np.uint64)).all()

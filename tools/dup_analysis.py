@@ -20,4 +20,4 @@ xh, qh, gh, eh = x.cpu().numpy(), q.cpu().numpy(), device_graph_to_svs(graph, 64
 for w in (24, 128):
     _, _, s0 = o.search(L2, xh, gh, eh, qh, 10, w, stats=True)
     _, _, s1 = o.search(L2, xh, gh, eh, qh, 10, w, visited_set=True, stats=True)
-    print(f"window {w}: slots/query {s0[:,1].mean():.0f}  in-buffer {s0[:,3].mean():.0f} ({s0[:,3].sum()/s0[:,1].sum():.2%})  evals with 64K visited filter {s1[:,2].mean():.0f} ({s1[:,2].sum()/s1[:,1].sum():.2%} of slots)")
+    print(f"window {w}: slots/query {s0[:,1].mean():.0f}  in-buffer {s0[:,3].mean():.0f} ({s0[:,3].sum()/s0[:,1].sum():.2%})  evals with 64K visited filter {s1[:,2].mean():.0f} ({s1[:,2].sum()/s1[:,1].sum():.2%} of slots)  small exact filters 512/1k/2k/4k hit {[f"{s0[:,4+i].sum()/s0[:,1].sum():.1%}" for i in range(4)]}")
