@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvsx.so")
+LIB_PATH = os.environ.get("SVSX_LIB") or os.path.join(_HERE, "libsvsx.so")  # SVSX_LIB: A/B builds of the same ABI
 
 SUCCESS, UNKNOWN_ERROR, INVALID_ARGUMENT, NOT_IMPLEMENTED, NOT_INITIALIZED, RUNTIME_ERROR = range(6)
 

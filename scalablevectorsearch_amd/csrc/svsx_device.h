@@ -242,6 +242,160 @@ __device__ __forceinline__ void float_row_distance(
     else out_nrm = 0.0f;
 }
 
+// Block-cyclic float-path distance (alternative lane mapping; same arithmetic, operation for operation, as
+// float_row_distance).  Four adjacent lanes own one row; lane j owns the WHOLE accumulator vector s_j (all 16
+// lane-slots) and streams the 16-element blocks 4t+j, so every access is whole aligned dwordx4 loads (int8: 1, f16: 2,
+// f32: 4 per block) and the four lanes of a group read 64*sizeof(T) contiguous bytes per step.  (s0+s1)+(s2+s3) is
+// formed with two quad DPP exchanges per lane-slot; the remaining 16-blocks and the masked tail go into s0 on all four
+// lanes redundantly (same address -> one request), and the _mm512_reduce_add_ps tree is lane-local.
+// Used for f16 and 8-bit rows (see use_block_cyclic below).
+template <int DT> struct BlockRaw { uint4 v[(16 * Elem<DT>::BYTES) / 16]; };
+
+template <int DT> __device__ __forceinline__ void block_to_float(const BlockRaw<DT>& raw, float (&x)[16]) {
+    if constexpr (DT == DT_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[4 * i + 0] = __uint_as_float(raw.v[i].x); x[4 * i + 1] = __uint_as_float(raw.v[i].y);
+            x[4 * i + 2] = __uint_as_float(raw.v[i].z); x[4 * i + 3] = __uint_as_float(raw.v[i].w);
+        }
+    } else if constexpr (DT == DT_F16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const half8_t h = __builtin_bit_cast(half8_t, raw.v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[8 * i + e] = static_cast<float>(h[e]);
+        }
+    } else {
+        const uint32_t w[4] = {raw.v[0].x, raw.v[0].y, raw.v[0].z, raw.v[0].w};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t byte = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+            if constexpr (DT == DT_I8) x[e] = static_cast<float>(static_cast<int>(static_cast<int8_t>(byte)));
+            else x[e] = static_cast<float>(byte);
+        }
+    }
+}
+
+template <int DT, int METRIC, int DS, bool DECOMP>
+__device__ __forceinline__ void float_row_distance_bc(
+    const unsigned char* __restrict__ row, bool active, const float* __restrict__ qf, int d_runtime, int sub,
+    float sq_scale, float sq_bias, float& out_main, float& out_nrm
+) {
+    constexpr int BB = 16 * Elem<DT>::BYTES; // bytes per 16-element block
+    const int d = DS > 0 ? DS : d_runtime;
+    const int nb = d >> 4;
+    const int n64 = nb >> 2;
+    float s[16], n[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.0f; n[e] = 0.0f; }
+
+    auto load_block = [&](int c) -> BlockRaw<DT> {
+        BlockRaw<DT> raw;
+#pragma unroll
+        for (int i = 0; i < BB / 16; ++i) {
+            raw.v[i] = make_uint4(0, 0, 0, 0);
+            if (active) raw.v[i] = *reinterpret_cast<const uint4*>(row + BB * c + 16 * i);
+        }
+        return raw;
+    };
+    auto accumulate = [&](int c, const BlockRaw<DT>& raw, int nvalid) {
+        float x[16];
+        block_to_float<DT>(raw, x);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 qv = *reinterpret_cast<const float4*>(qf + 16 * c + 4 * g4);
+            const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int e = 4 * g4 + b;
+                float xv = x[e];
+                if constexpr (DECOMP) {
+                    const float t = sq_scale * xv;
+                    xv = t + sq_bias;
+                }
+                float ts = s[e], tn = n[e];
+                acc_step<METRIC>(ts, tn, q[b], xv);
+                const bool in = e < nvalid;
+                s[e] = in ? ts : s[e];
+                if constexpr (METRIC == M_COS) n[e] = in ? tn : n[e];
+            }
+        }
+    };
+
+    if (n64 > 0) {
+        if constexpr (DS > 0) {
+            constexpr int N64 = DS >> 6;
+            constexpr int MAXCH = ((METRIC == M_COS ? 4 : 8) / (BB / 16)) > 0 ? (METRIC == M_COS ? 4 : 8) / (BB / 16) : 1; // dwordx4 loads in flight
+            constexpr int CH = N64 < MAXCH ? (N64 > 0 ? N64 : 1) : MAXCH;
+#pragma unroll 1
+            for (int t0 = 0; t0 < N64; t0 += CH) { // rolled: CH blocks in flight per lane, registers bounded
+                BlockRaw<DT> raw[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) if (t0 + i < N64) raw[i] = load_block(4 * (t0 + i) + sub);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) if (t0 + i < N64) accumulate(4 * (t0 + i) + sub, raw[i], 16);
+            }
+        } else {
+            constexpr int CH = 4 / (BB / 16) > 0 ? 4 / (BB / 16) : 1;
+            int t = 0;
+            for (; t + CH <= n64; t += CH) {
+                BlockRaw<DT> raw[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) raw[i] = load_block(4 * (t + i) + sub);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) accumulate(4 * (t + i) + sub, raw[i], 16);
+            }
+            for (; t < n64; ++t) {
+                const BlockRaw<DT> raw = load_block(4 * t + sub);
+                accumulate(4 * t + sub, raw, 16);
+            }
+        }
+        // s0 = (s0 + s1) + (s2 + s3) per lane-slot; afterwards every lane of the group holds the combined vector
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float a = s[e] + xor1f(s[e]);
+            s[e] = a + xor2f(a);
+            if constexpr (METRIC == M_COS) {
+                const float b = n[e] + xor1f(n[e]);
+                n[e] = b + xor2f(b);
+            }
+        }
+    }
+    for (int b = 4 * n64; b < nb; ++b) {
+        const BlockRaw<DT> raw = load_block(b);
+        accumulate(b, raw, 16);
+    }
+    if ((d & 15) != 0) {
+        const BlockRaw<DT> raw = load_block(nb);
+        accumulate(nb, raw, d & 15);
+    }
+    auto tree = [](float (&v)[16]) -> float {
+        float t[8], u[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[j + 8] + v[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = t[j + 4] + t[j];
+        const float w0 = u[0] + u[2];
+        const float w1 = u[1] + u[3];
+        return w0 + w1;
+    };
+    out_main = tree(s);
+    if constexpr (METRIC == M_COS) out_nrm = tree(n);
+    else out_nrm = 0.0f;
+}
+
+#ifndef SVSX_F16_BLOCK_CYCLIC
+#define SVSX_F16_BLOCK_CYCLIC 1
+#endif
+// Which mapping each row type uses on the float path (measured on MI355X, round 1):
+//   f32      slot-cyclic (float_row_distance, G=4): 6 dwordx4 per lane at d=96, 61 VGPRs, 8 waves/SIMD
+//   f16      block-cyclic: 58-60 VGPRs / 8 waves per SIMD at d=128 vs 92 / 5 for the G=2 slot-cyclic mapping;
+//            1M x 128 f16 IP: 3.33 M QPS vs 2.85 M (A/B with -DSVSX_F16_BLOCK_CYCLIC=0)
+//   int8/u8  block-cyclic: 16-B instead of 8-B loads; 500k x 768 SQ-int8 cosine: 754 k QPS vs 377 k
+template <int DT> constexpr bool use_block_cyclic() {
+    return DT == DT_I8 || DT == DT_U8 || (DT == DT_F16 && SVSX_F16_BLOCK_CYCLIC != 0);
+}
+
 // Exact int32 sums of one row against the query bytes in LDS: ab = sum(q*x), bb = sum(x*x).
 // Rows and the LDS query are zero padded to 16 elements, 4 lanes share a row (16-B chunks, any order).
 template <int DT>
@@ -250,10 +404,7 @@ __device__ __forceinline__ void int_row_sums(
 ) {
     const int nch = (d + 15) >> 4;
     int sab = 0, sbb = 0;
-    for (int m = sub4; m < nch; m += 4) {
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (active) x = *reinterpret_cast<const uint4*>(row + 16 * m);
-        const uint4 q = *reinterpret_cast<const uint4*>(qw + 4 * m);
+    auto dots = [&](const uint4& x, const uint4& q) {
         if constexpr (DT == DT_I8) {
             sab = __builtin_amdgcn_sdot4(q.x, x.x, sab, false);
             sab = __builtin_amdgcn_sdot4(q.y, x.y, sab, false);
@@ -273,6 +424,22 @@ __device__ __forceinline__ void int_row_sums(
             sbb = (int)__builtin_amdgcn_udot4(x.z, x.z, (unsigned)sbb, false);
             sbb = (int)__builtin_amdgcn_udot4(x.w, x.w, (unsigned)sbb, false);
         }
+    };
+    int m = sub4;
+    for (; m + 12 < nch; m += 16) { // four 16-B loads in flight per lane
+        uint4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i] = make_uint4(0, 0, 0, 0);
+            if (active) x[i] = *reinterpret_cast<const uint4*>(row + 16 * (m + 4 * i));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dots(x[i], *reinterpret_cast<const uint4*>(qw + 4 * (m + 4 * i)));
+    }
+    for (; m < nch; m += 4) {
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (active) x = *reinterpret_cast<const uint4*>(row + 16 * m);
+        dots(x, *reinterpret_cast<const uint4*>(qw + 4 * m));
     }
     sab += xor1i(sab);
     sab += xor2i(sab);

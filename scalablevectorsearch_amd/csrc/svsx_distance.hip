@@ -15,7 +15,8 @@ template <int DT, int METRIC, int QMODE>
 __global__ __launch_bounds__(64) void distance_kernel(const DistanceArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool INTPATH = (QMODE == QM_INT);
-    constexpr int G = INTPATH ? 4 : 16 / Elem<DT>::E;
+    constexpr bool B8 = !INTPATH && use_block_cyclic<DT>();
+    constexpr int G = (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;
     constexpr int RPP = 64 / G;
     const uint32_t lane = threadIdx.x;
     const uint32_t qi = blockIdx.x;
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(64) void distance_kernel(const DistanceArgs a) {
         float fmain = 0.0f, fnrm = 0.0f;
         int ab = 0, bb = 0;
         if constexpr (INTPATH) int_row_sums<DT>(row, act, qw, d, sub, ab, bb);
+        else if constexpr (B8) float_row_distance_bc<DT, METRIC, 0, false>(row, act, qf, d, sub, 1.0f, 0.0f, fmain, fnrm);
         else float_row_distance<DT, METRIC, 0, false>(row, act, qf, d, sub, 1.0f, 0.0f, fmain, fnrm);
         const float r = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, 1.0f);
         if (act && sub == 0) a.out[static_cast<size_t>(qi) * a.nb + j] = r;

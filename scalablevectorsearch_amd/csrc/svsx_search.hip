@@ -26,7 +26,8 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
     constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
-    constexpr int G = INTPATH ? 4 : 16 / Elem<DT>::E; // lanes per candidate row
+    constexpr bool B8 = !INTPATH && use_block_cyclic<DT>();  // 8-bit rows on the float path: block-cyclic mapping
+    constexpr int G = (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
     constexpr int RPP = 64 / G;                        // rows per pass
 
     const uint32_t lane = threadIdx.x;
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         int ab = 0, bb = 0;
         if constexpr (INTPATH) {
             int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
+        } else if constexpr (B8) {
+            float_row_distance_bc<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         } else {
             float_row_distance<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         }
@@ -225,6 +228,9 @@ template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const Sear
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         if (a.d == 96) return launch_one<DT, METRIC, QMODE, 96>(a, stream);
         if (a.d == 128) return launch_one<DT, METRIC, QMODE, 128>(a, stream);
+    }
+    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && DT == DT_I8) {
+        if (a.d == 768) return launch_one<DT, METRIC, QMODE, 768>(a, stream);
     }
     return launch_one<DT, METRIC, QMODE, 0>(a, stream);
 }
