@@ -155,6 +155,15 @@ int svsx_merge_topk_device(
     uint64_t* d_out_ids, void* hip_stream
 );
 
+/* Builder support ("next" scope): heuristic_prune_neighbors (index/vamana/prune.h:100-246; progressive
+ * strategy for L2, iterative for IP / cosine) for a batch of vertices of `index`.  Device pointers:
+ *   pool_ids [n_nodes][pool_size] candidates sorted best-first by (distance, id), -1 padded at the end,
+ *   pool_dists the matching distances to the vertex, out [n_nodes][out_stride] pruned adjacency (-1 padded). */
+int svsx_prune_device(
+    const svsx_index* index, const int32_t* d_node_ids, const int32_t* d_pool_ids, const float* d_pool_dists, size_t n_nodes,
+    size_t pool_size, size_t max_out, float alpha, int32_t* d_out, size_t out_stride, void* hip_stream
+);
+
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),
  * [5]=data row stride (bytes). */
 int svsx_index_info(const svsx_index* index, uint64_t info[6]);

@@ -194,6 +194,16 @@ class Oracle:
             raise ValueError("svso_build_vamana failed")
         return graph, np.array([entry.value], np.uint32)
 
+    def prune(self, metric, data, node, pool_ids, pool_dists, max_out, alpha):
+        data = np.ascontiguousarray(data)
+        pool_ids = np.ascontiguousarray(pool_ids, np.uint32)
+        pool_dists = np.ascontiguousarray(pool_dists, np.float32)
+        out = np.zeros(max_out, np.uint32)
+        self.lib.svso_prune.restype = C.c_size_t
+        self.lib.svso_prune.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p]
+        r = self.lib.svso_prune(metric, dtype_code(data), _ptr(data), data.shape[0], data.shape[1], int(node), _ptr(pool_ids), _ptr(pool_dists), pool_ids.size, max_out, alpha, _ptr(out))
+        return out[:r]
+
     def recall(self, gt, res, k, n):
         gt = np.ascontiguousarray(gt, dtype=np.uint32)
         res = np.ascontiguousarray(res, dtype=np.uint32)

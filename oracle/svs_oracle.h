@@ -124,6 +124,10 @@ double svso_k_recall_at_n(const uint32_t* gt, size_t gt_stride, const uint32_t* 
 /* index/flat/flat.h exhaustive search (ground truth), total order = (distance, then position). */
 int svso_flat_search(const svso_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, uint32_t* ids, float* dists);
 
+/* index/vamana/prune.h:100-246 on one explicit, sorted pool; returns the number of ids written to out. */
+size_t svso_prune(int metric, int data_dtype, const void* data, size_t n, size_t d, uint32_t node, const uint32_t* pool_ids,
+                  const float* pool_dists, size_t np, size_t max_out, float alpha, uint32_t* out);
+
 /* index/vamana/vamana_build.h restated (single-threaded, deterministic); graph: n x (R+1) u32 SVS rows. */
 int svso_build_vamana(
     int metric, int data_dtype, const void* data, size_t n, size_t d, size_t R, size_t L, size_t C, size_t prune_to,

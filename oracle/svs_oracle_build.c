@@ -251,6 +251,19 @@ static void one_pass(svso_index* ix, uint32_t* graph, size_t R, size_t L, size_t
     free(hist); free(hist_d); free(pool); free(mark); free(updates); free(ov);
 }
 
+/* heuristic_prune_neighbors on one explicit pool (checker for the HIP prune kernel). */
+size_t svso_prune(int metric, int data_dtype, const void* data, size_t n, size_t d, uint32_t node, const uint32_t* pool_ids,
+                  const float* pool_dists, size_t np, size_t max_out, float alpha, uint32_t* out) {
+    svso_index ix;
+    memset(&ix, 0, sizeof(ix));
+    ix.metric = metric; ix.data_dtype = data_dtype; ix.n = n; ix.d = d; ix.data = data;
+    cand* pool = (cand*)malloc((np + 1) * sizeof(cand));
+    for (size_t i = 0; i < np; ++i) { pool[i].id = pool_ids[i]; pool[i].dist = pool_dists[i]; }
+    size_t r = prune(&ix, node, pool, np, max_out, alpha, out);
+    free(pool);
+    return r;
+}
+
 /* Builds an SVS-layout graph (n x (R+1) u32, slot 0 = degree) into `graph`; returns the entry point. */
 int svso_build_vamana(
     int metric, int data_dtype, const void* data, size_t n, size_t d, size_t R, size_t L, size_t C, size_t prune_to,

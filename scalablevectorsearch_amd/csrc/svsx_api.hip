@@ -385,6 +385,35 @@ int svsx_distance_batch(
     return SVSX_SUCCESS;
 }
 
+int svsx_prune_device(
+    const svsx_index* ix, const int32_t* d_node_ids, const int32_t* d_pool_ids, const float* d_pool_dists, size_t n_nodes,
+    size_t pool_size, size_t max_out, float alpha, int32_t* d_out, size_t out_stride, void* hip_stream
+) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (n_nodes == 0) return SVSX_SUCCESS;
+    if (!d_node_ids || !d_pool_ids || !d_pool_dists || !d_out) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    if (pool_size == 0 || max_out == 0 || out_stride < max_out) return fail(SVSX_INVALID_ARGUMENT, "pool_size, max_out must be positive and out_stride >= max_out");
+    HIP_TRY(hipSetDevice(ix->device));
+    PruneArgs a;
+    a.data = ix->d_data;
+    a.row_bytes = ix->row_bytes;
+    a.d = static_cast<uint32_t>(ix->d);
+    a.sq_scale = ix->sq_scale;
+    a.sq_bias = ix->sq_bias;
+    a.node_ids = d_node_ids;
+    a.pool_ids = d_pool_ids;
+    a.pool_dists = d_pool_dists;
+    a.n_nodes = static_cast<uint32_t>(n_nodes);
+    a.pool_size = static_cast<uint32_t>(pool_size);
+    a.max_out = static_cast<uint32_t>(max_out);
+    a.alpha = alpha;
+    a.out = d_out;
+    a.out_stride = static_cast<uint32_t>(out_stride);
+    hipError_t e = launch_prune(ix->data_dtype, ix->metric, ix->sq_enabled != 0, a, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "prune kernel launch failed: %s", hipGetErrorString(e));
+    return SVSX_SUCCESS;
+}
+
 int svsx_merge_topk_device(
     int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, const uint64_t* d_ids, float* d_out_dists,
     uint64_t* d_out_ids, void* hip_stream

@@ -59,6 +59,22 @@ struct MergeArgs {
 };
 hipError_t launch_merge(int metric, const MergeArgs& a, hipStream_t stream);
 
+// builder: heuristic_prune_neighbors for a batch of vertices (index/vamana/prune.h:100-246)
+struct PruneArgs {
+    const void* data;
+    size_t row_bytes;
+    uint32_t d;
+    float sq_scale, sq_bias;
+    const int32_t* node_ids;    // n_nodes
+    const int32_t* pool_ids;    // n_nodes x pool_size, sorted best-first, -1 padded at the end
+    const float* pool_dists;    // n_nodes x pool_size, distance(vertex, candidate)
+    uint32_t n_nodes, pool_size, max_out;
+    float alpha;
+    int32_t* out;               // n_nodes x out_stride, packed from slot 0, -1 padded
+    uint32_t out_stride;
+};
+hipError_t launch_prune(int data_dtype, int metric, bool decomp, const PruneArgs& a, hipStream_t stream);
+
 // layout conversion kernels (index creation)
 hipError_t launch_pack_graph(const uint32_t* d_svs_graph, uint32_t svs_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, hipStream_t stream);
 

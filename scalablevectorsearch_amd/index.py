@@ -200,6 +200,18 @@ class VamanaIndex:
         res = QueryResult(ids, dists)
         return (res, st) if stats else res
 
+    def prune_device(self, d_node_ids, d_pool_ids, d_pool_dists, max_out: int, alpha: float, out_stride: int, stream=None):
+        """heuristic_prune_neighbors (index/vamana/prune.h:100-246) for a batch of vertices, on torch CUDA tensors:
+        node ids int32 [B], pool ids int32 [B,P] (sorted best-first, -1 padded), pool dists f32 [B,P] -> int32 [B,out_stride]."""
+        import torch
+
+        B, P = d_pool_ids.shape
+        out = torch.empty((B, out_stride), dtype=torch.int32, device=d_pool_ids.device)
+        s = stream if stream is not None else torch.cuda.current_stream(d_pool_ids.device).cuda_stream
+        _lib.check(_lib.lib().svsx_prune_device(self._h, d_node_ids.data_ptr(), d_pool_ids.data_ptr(), d_pool_dists.data_ptr(), B, P, max_out,
+                                                float(alpha), out.data_ptr(), out_stride, C.c_void_p(s)))
+        return out
+
     def search_device(self, d_queries, num_neighbors: int, search_parameters: VamanaSearchParameters | None = None,
                       d_ids64=None, d_ids32=None, d_dists=None, d_stats=None, history=None, q_dtype=None, stream=None):
         """Enqueue a batch search on torch CUDA tensors (no synchronisation).  ``history`` = (ids, dists, len) tensors."""

@@ -302,3 +302,36 @@ def test_visited_filter_is_result_neutral(svs, oracle, small_world, entries):
         assert (st1[:, 2] <= st0[:, 2]).all() and st1[:, 2].sum() < st0[:, 2].sum()
         ids, dists = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, w, c, visited_set=True)
         assert (on.indices == ids.astype(np.uint64)).all()
+
+
+@pytest.mark.parametrize("metric,alpha", [(L2, 1.2), (L2, 1.0), (IP, 0.95), (COS, 0.95)])
+def test_prune_kernel_matches_oracle(svs, oracle, small_world, metric, alpha):
+    """svsx_prune_device (index/vamana/prune.h:100-246) against the C oracle's prune on identical pools."""
+    import torch
+
+    sw = small_world
+    x = sw["x"]
+    fn = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}[metric]
+    idx = svs.VamanaIndex(sw["graph"], x, fn, sw["entry"])
+    rng = np.random.default_rng(4)
+    B, P, R = 48, 70, 16
+    nodes = rng.integers(0, 1500, B).astype(np.int32)
+    pools = np.full((B, P), -1, np.int32)
+    dists = np.zeros((B, P), np.float32)
+    for b in range(B):
+        npool = int(rng.integers(1, P + 1))
+        ids = rng.choice(1500, npool, replace=False).astype(np.int32)
+        if b % 5 == 0:
+            ids[0] = nodes[b]  # the vertex itself may be in its pool (excluded by the prune)
+        dd = oracle.distance_batch(metric, x[nodes[b] : nodes[b] + 1], x[ids])[0]
+        order = np.lexsort((ids, -dd if metric != L2 else dd))
+        pools[b, :npool], dists[b, :npool] = ids[order], dd[order]
+        dists[b, npool:] = -np.inf if metric != L2 else np.inf
+    out = idx.prune_device(torch.from_numpy(nodes).cuda(), torch.from_numpy(pools).cuda(), torch.from_numpy(dists).cuda(), R, alpha, 16)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for b in range(B):
+        npool = int((pools[b] >= 0).sum())
+        want = oracle.prune(metric, x, nodes[b], pools[b, :npool], dists[b, :npool], R, alpha)
+        got = out[b][out[b] >= 0]
+        assert (got == want.astype(np.int32)).all(), (b, got, want)

@@ -68,3 +68,25 @@ def test_distance_functor_surface():
         svs.compute(svs.DistanceL2(), np.zeros((1, 4), np.float64), np.zeros((1, 4), np.float32))
     with pytest.raises(svs.SvsxError):
         svs.compute(svs.DistanceL2(), np.zeros((1, 4), np.float32), np.zeros((1, 5), np.float32))
+
+
+def test_vecs_and_native_readers(tmp_path):
+    """core/io/vecs.h + core/io/native.h v1: the reference's own tiny fixtures data/test_dataset/known_f32.{fvecs,svs}
+    (copied as data into tests/golden/) hold the same matrix; round-trip through our writers."""
+    import os
+
+    from scalablevectorsearch_amd import io
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    a = io.read_fvecs(os.path.join(gold, "known_f32.fvecs"))
+    b = io.read_svs_native(os.path.join(gold, "known_f32.svs"), np.float32)
+    assert a.shape == b.shape and a.shape[0] > 0 and (a == b).all()
+    io.write_fvecs(tmp_path / "x.fvecs", a)
+    io.write_svs_native(tmp_path / "x.svs", a)
+    assert (io.read_fvecs(tmp_path / "x.fvecs") == a).all() and (io.read_svs_native(tmp_path / "x.svs", np.float32) == a).all()
+    assert open(tmp_path / "x.fvecs", "rb").read() == open(os.path.join(gold, "known_f32.fvecs"), "rb").read()
+    g = np.arange(12, dtype=np.uint32).reshape(3, 4)
+    io.write_svs_native(tmp_path / "g.svs", g)
+    assert (io.read_svs_native(tmp_path / "g.svs", np.uint32) == g).all()
+    with pytest.raises(ValueError):
+        io.read_svs_native(os.path.join(gold, "known_f32.fvecs"), np.float32)
