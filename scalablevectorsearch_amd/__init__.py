@@ -8,11 +8,12 @@ The compute lives in libsvsx.so (hand-written HIP for gfx950); there is no CPU f
 """
 from ._lib import SvsxError, build, lib  # noqa: F401
 from .distance import DistanceCosineSimilarity, DistanceIP, DistanceL2, DistanceType, compute  # noqa: F401
+from .calibrate import CalibrationParameters, calibrate  # noqa: F401
 from .index import (  # noqa: F401
     QueryResult, SearchBufferConfig, VamanaIndex, VamanaSearchParameters, k_recall_at_n,
 )
 
 __all__ = [
     "SvsxError", "build", "lib", "DistanceType", "DistanceL2", "DistanceIP", "DistanceCosineSimilarity", "compute",
-    "VamanaIndex", "VamanaSearchParameters", "SearchBufferConfig", "QueryResult", "k_recall_at_n",
+    "VamanaIndex", "VamanaSearchParameters", "SearchBufferConfig", "QueryResult", "k_recall_at_n", "calibrate", "CalibrationParameters",
 ]

@@ -335,3 +335,20 @@ def test_prune_kernel_matches_oracle(svs, oracle, small_world, metric, alpha):
         want = oracle.prune(metric, x, nodes[b], pools[b, :npool], dists[b, :npool], R, alpha)
         got = out[b][out[b] >= 0]
         assert (got == want.astype(np.int32)).all(), (b, got, want)
+
+
+def test_calibrate_reaches_target_recall(svs, oracle, small_world):
+    """calibrate(): smallest window reaching the target on the GPU index; one less misses it (calibrate.h:286-300)."""
+    from scalablevectorsearch_amd.calibrate import calibrate
+
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    gt, _ = oracle.flat_search(L2, sw["x"], sw["q"], 10)
+    best = calibrate(idx, sw["q"], gt, 10, 0.95)
+    w = best.buffer_config.search_window_size
+    assert idx.get_search_parameters() == best
+    r = svs.k_recall_at_n(gt, idx.search(sw["q"], 10).indices, 10, 10)
+    assert r >= 0.95
+    if w > 10:
+        r1 = svs.k_recall_at_n(gt, idx.search(sw["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(w - 1))).indices, 10, 10)
+        assert r1 < 0.95

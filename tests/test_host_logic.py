@@ -90,3 +90,28 @@ def test_vecs_and_native_readers(tmp_path):
     assert (io.read_svs_native(tmp_path / "g.svs", np.uint32) == g).all()
     with pytest.raises(ValueError):
         io.read_svs_native(os.path.join(gold, "known_f32.fvecs"), np.float32)
+
+
+def test_calibration_binary_search_logic():
+    """index/vamana/calibrate.h:249-343 with a synthetic monotone recall model (no GPU)."""
+    from scalablevectorsearch_amd.calibrate import CalibrationParameters, optimize_search_buffer
+
+    calls = []
+
+    def recall_model(p):  # recall grows with the window; capacity helps a little
+        w, c = p.buffer_config.search_window_size, p.buffer_config.total_capacity
+        calls.append((w, c))
+        return min(1.0, 0.5 + 0.02 * w + 0.001 * (c - w))
+
+    best, ok = optimize_search_buffer(CalibrationParameters(), svs.VamanaSearchParameters(), 10, 0.9, recall_model)
+    assert ok and best.buffer_config == svs.SearchBufferConfig(20, 20)  # 0.5 + 0.02*20 = 0.9
+    assert len(calls) <= 12  # binary search over [10, 1000)
+    # unreachable target: not converged, returns the largest window tried by lower_bound
+    best, ok = optimize_search_buffer(CalibrationParameters(search_window_size_upper=30), svs.VamanaSearchParameters(), 10, 1.5, recall_model)
+    assert not ok and best.buffer_config.search_window_size == 29
+    # window == k already enough ("maybe oversized") -> split buffer: window below k, capacity k
+    best, ok = optimize_search_buffer(CalibrationParameters(), svs.VamanaSearchParameters(), 10, 0.6, recall_model)
+    assert ok and best.buffer_config.total_capacity == 10 and best.buffer_config.search_window_size == 5  # 0.5+0.1+0.005>=0.6
+    # ROIOnly never splits
+    best, ok = optimize_search_buffer(CalibrationParameters(search_buffer_optimization="ROIOnly"), svs.VamanaSearchParameters(), 10, 0.6, recall_model)
+    assert best.buffer_config == svs.SearchBufferConfig(10, 10)
