@@ -157,7 +157,13 @@ def main():
     # ---- correctness of what is being timed: recall against exact ground truth ---------------------------------
     step(with_stats=True)
     torch.cuda.synchronize()
-    gt_local = brute_force_topk(x, q, k) + rank * n
+    # exact ground truth by this repo's exhaustive search (MFMA f16 shortlist + exact re-rank, svsx_flat_search_device);
+    # ids are local to the shard here (a fresh view without id_offset)
+    flat = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n, d, np.float32, device=local_rank)
+    gt_local, _ = flat.flat_search_device(q, k)
+    torch.cuda.synchronize()
+    del flat
+    gt_local = gt_local + rank * n
     if multi:
         # global ground truth = merge of per-shard exact top-k
         gd = ((q[:, None, :] - x[(gt_local - rank * n)]) ** 2).sum(-1)

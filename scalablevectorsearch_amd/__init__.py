@@ -10,10 +10,10 @@ from ._lib import SvsxError, build, lib  # noqa: F401
 from .distance import DistanceCosineSimilarity, DistanceIP, DistanceL2, DistanceType, compute  # noqa: F401
 from .calibrate import CalibrationParameters, calibrate  # noqa: F401
 from .index import (  # noqa: F401
-    QueryResult, SearchBufferConfig, VamanaIndex, VamanaSearchParameters, k_recall_at_n,
+    FlatIndex, QueryResult, SearchBufferConfig, VamanaIndex, VamanaSearchParameters, k_recall_at_n,
 )
 
 __all__ = [
     "SvsxError", "build", "lib", "DistanceType", "DistanceL2", "DistanceIP", "DistanceCosineSimilarity", "compute",
-    "VamanaIndex", "VamanaSearchParameters", "SearchBufferConfig", "QueryResult", "k_recall_at_n", "calibrate", "CalibrationParameters",
+    "VamanaIndex", "FlatIndex", "VamanaSearchParameters", "SearchBufferConfig", "QueryResult", "k_recall_at_n", "calibrate", "CalibrationParameters",
 ]

@@ -59,7 +59,7 @@ class SearchAux(C.Structure):
 
 EXPORTS = [
     "svsx_index_create", "svsx_index_create_device_view", "svsx_index_destroy", "svsx_search", "svsx_search_device",
-    "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_index_info", "svsx_last_error", "svsx_version",
+    "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def lib() -> C.CDLL:
         L.svsx_distance_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.svsx_merge_topk_device.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_prune_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.svsx_flat_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -32,6 +33,10 @@ struct svsx_index {
     int device = 0;
     uint64_t id_offset = 0;
     bool owns = true;
+    // lazily built float16 shadow for the MFMA flat-search filter (svsx_flat.hip)
+    mutable std::mutex shadow_mutex;
+    mutable void* d_half = nullptr;
+    mutable float* d_norm2 = nullptr;
 };
 
 namespace {
@@ -101,12 +106,14 @@ int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
     if (!desc || !out) return fail(SVSX_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (int rc = validate_common(desc->metric, desc->data_dtype, desc->n, desc->d)) return rc;
-    if (!desc->data || !desc->graph || !desc->entry_points || desc->n_entry == 0)
+    const bool flat_only = desc->graph == nullptr; // FlatIndex (index/flat/flat.h): data only
+    if (!desc->data) return fail(SVSX_INVALID_ARGUMENT, "data is required");
+    if (!flat_only && (!desc->entry_points || desc->n_entry == 0))
         return fail(SVSX_INVALID_ARGUMENT, "data, graph and at least one entry point are required");
-    if (desc->graph_row_stride_u32 < 2) return fail(SVSX_INVALID_ARGUMENT, "graph row stride must be >= 2 (degree slot + ids)");
+    if (!flat_only && desc->graph_row_stride_u32 < 2) return fail(SVSX_INVALID_ARGUMENT, "graph row stride must be >= 2 (degree slot + ids)");
     if (desc->sq_enabled && desc->data_dtype != SVSX_I8 && desc->data_dtype != SVSX_U8)
         return fail(SVSX_INVALID_ARGUMENT, "scalar-quantized data must be int8 or uint8");
-    for (size_t i = 0; i < desc->n_entry; ++i)
+    for (size_t i = 0; !flat_only && i < desc->n_entry; ++i)
         if (desc->entry_points[i] >= desc->n) return fail(SVSX_INVALID_ARGUMENT, "entry point %u out of range", desc->entry_points[i]);
     HIP_TRY(hipSetDevice(desc->device));
 
@@ -116,7 +123,7 @@ int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
     ix->data_dtype = desc->data_dtype;
     ix->n = desc->n;
     ix->d = desc->d;
-    ix->n_entry = desc->n_entry;
+    ix->n_entry = flat_only ? 0 : desc->n_entry;
     ix->sq_enabled = desc->sq_enabled;
     ix->sq_scale = desc->sq_scale;
     ix->sq_bias = desc->sq_bias;
@@ -141,6 +148,10 @@ int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
     if (hipMemcpy2D(ix->d_data, ix->row_bytes, desc->data, src_stride, desc->d * es, desc->n, hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail(SVSX_RUNTIME_ERROR, "copying data to the device failed"));
 
+    if (flat_only) {
+        *out = ix;
+        return SVSX_SUCCESS;
+    }
     // graph: SVS rows -> packed rows of `gstride` ids (multiple of 16 u32 = 64 B) padded with 0xFFFFFFFF
     size_t maxdeg = desc->max_degree ? desc->max_degree : desc->graph_row_stride_u32 - 1;
     if (maxdeg > desc->graph_row_stride_u32 - 1) maxdeg = desc->graph_row_stride_u32 - 1;
@@ -206,6 +217,8 @@ void svsx_index_destroy(svsx_index* ix) {
         if (ix->d_graph) (void)hipFree(ix->d_graph);
         if (ix->d_entry) (void)hipFree(ix->d_entry);
     }
+    if (ix->d_half) (void)hipFree(ix->d_half);
+    if (ix->d_norm2) (void)hipFree(ix->d_norm2);
     delete ix;
 }
 
@@ -284,8 +297,9 @@ static int search_common(
     return SVSX_SUCCESS;
 }
 
-static int check_search_args(const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k) {
+static int check_search_args(const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, bool need_graph = true) {
     if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (need_graph && !ix->d_graph) return fail(SVSX_INVALID_ARGUMENT, "this index was created without a graph (flat search only)");
     if (k == 0) return fail(SVSX_INVALID_ARGUMENT, "k must be greater than 0");
     if (dtype_size(q_dtype) == 0) return fail(SVSX_INVALID_ARGUMENT, "unknown query dtype %d", q_dtype);
     if (nq > 0 && !queries) return fail(SVSX_INVALID_ARGUMENT, "null queries");
@@ -382,6 +396,74 @@ int svsx_distance_batch(
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "distance kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, na * nb * 4, hipMemcpyDeviceToHost));
+    return SVSX_SUCCESS;
+}
+
+int svsx_flat_search_device(
+    const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream
+) {
+    if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k, false)) return rc;
+    if (nq == 0) return SVSX_SUCCESS;
+    if (k > 128) return fail(SVSX_INVALID_ARGUMENT, "flat search supports k <= 128");
+    const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
+    if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const uint32_t dpad = static_cast<uint32_t>((ix->d + 15) & ~size_t(15));
+    {   // float16 shadow of the database + squared norms, built once
+        std::lock_guard<std::mutex> lock(ix->shadow_mutex);
+        if (!ix->d_half) {
+            void* h = nullptr;
+            float* nrm = nullptr;
+            HIP_TRY(hipMalloc(&h, ix->n * dpad * 2 + 64));
+            if (hipMalloc(reinterpret_cast<void**>(&nrm), ix->n * 4) != hipSuccess) { (void)hipFree(h); return fail(SVSX_RUNTIME_ERROR, "hipMalloc failed"); }
+            hipError_t e = launch_to_half(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), dpad,
+                                          ix->sq_enabled, ix->sq_scale, ix->sq_bias, h, nrm, stream);
+            if (e != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(h); (void)hipFree(nrm); return fail(SVSX_RUNTIME_ERROR, "float16 shadow conversion failed"); }
+            ix->d_half = h;
+            ix->d_norm2 = nrm;
+        }
+    }
+    size_t kk = 4 * k > k + 32 ? 4 * k : k + 32;
+    if (kk > 128) kk = 128;
+    if (kk < k) kk = k;
+    if (kk > ix->n) kk = ix->n < k ? k : ix->n;
+    const size_t nqb = (nq + 63) / 64;
+    size_t slices = (1024 + nqb - 1) / nqb; // ~4 resident waves per CU (LDS-limited); fewer slices = fewer shortlist inserts
+    if (slices > 64) slices = 64;
+    const size_t max_slices = (ix->n + 255) / 256;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    void *qh = nullptr, *sk = nullptr, *si = nullptr, *mk = nullptr, *mi = nullptr;
+    const size_t q_stride = ix->d * dtype_size(q_dtype);
+    HIP_TRY(hipMallocAsync(&qh, nq * dpad * 2 + 64, stream));
+    HIP_TRY(hipMallocAsync(&sk, slices * nq * kk * 4, stream));
+    HIP_TRY(hipMallocAsync(&si, slices * nq * kk * 8, stream));
+    HIP_TRY(hipMallocAsync(&mk, nq * kk * 4, stream));
+    HIP_TRY(hipMallocAsync(&mi, nq * kk * 8, stream));
+    auto release = [&]() {
+        (void)hipFreeAsync(qh, stream); (void)hipFreeAsync(sk, stream); (void)hipFreeAsync(si, stream);
+        (void)hipFreeAsync(mk, stream); (void)hipFreeAsync(mi, stream);
+    };
+    hipError_t e = launch_to_half(q_dtype, d_queries, q_stride, static_cast<uint32_t>(nq), static_cast<uint32_t>(ix->d), dpad, 0, 1.0f, 0.0f, qh, nullptr, stream);
+    FlatArgs fa;
+    fa.xh = ix->d_half; fa.xnorm2 = ix->d_norm2; fa.n = static_cast<uint32_t>(ix->n); fa.dpad = dpad; fa.qh = qh;
+    fa.nq = static_cast<uint32_t>(nq); fa.kk = static_cast<uint32_t>(kk); fa.n_slices = static_cast<uint32_t>(slices);
+    fa.out_keys = static_cast<float*>(sk); fa.out_ids = static_cast<uint64_t*>(si);
+    if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
+    MergeArgs ma;
+    ma.dists = static_cast<const float*>(sk); ma.ids = static_cast<const uint64_t*>(si);
+    ma.out_dists = static_cast<float*>(mk); ma.out_ids = static_cast<uint64_t*>(mi);
+    ma.n_shards = static_cast<uint32_t>(slices); ma.nq = static_cast<uint32_t>(nq); ma.k = static_cast<uint32_t>(kk);
+    if (e == hipSuccess) e = launch_merge(M_L2, ma, stream); // keys: smaller is better for every metric
+    RerankArgs ra;
+    ra.data = ix->d_data; ra.row_bytes = ix->row_bytes; ra.d = static_cast<uint32_t>(ix->d); ra.sq_scale = ix->sq_scale; ra.sq_bias = ix->sq_bias;
+    ra.id_offset = ix->id_offset; ra.queries = d_queries; ra.q_row_bytes = q_stride; ra.q_dtype = q_dtype;
+    ra.nq = static_cast<uint32_t>(nq); ra.kk = static_cast<uint32_t>(kk); ra.k = static_cast<uint32_t>(k);
+    ra.cand_ids = static_cast<const uint64_t*>(mi); ra.ids64 = d_ids64; ra.dists = d_dists;
+    if (e == hipSuccess) e = launch_rerank(ix->data_dtype, ix->metric, qmode, ra, stream);
+    release();
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "flat search launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
 }
 

@@ -1,0 +1,404 @@
+// svsx_flat.hip -- exhaustive (flat) search: the dense, MFMA-shaped case of this code base.
+//
+// Reference operator: svs::index::flat::FlatIndex::search (index/flat/flat.h:322-460): every query against every
+// vector, k best by the metric's comparator.  Here it is a two-stage pipeline:
+//   1. flat_mfma_kernel   float16 "batched-query x candidate-block" products on the matrix cores
+//                         (v_mfma_f32_32x32x16_f16, f32 accumulate): a wave owns 64 queries (two 32-row A tiles held in
+//                         LDS) and streams a slice of the database in 32-row tiles whose B fragments are 16-B loads
+//                         straight from the row-major f16 shadow copy; a per-query sorted shortlist of kk >= k
+//                         candidates lives in LDS and is updated with ballot + wave-serial inserts (accepts become
+//                         rare once the shortlists warm up: ~kk ln(n/kk) per query).
+//   2. merge_kernel       (svsx_distance.hip) merges the per-slice shortlists.
+//   3. rerank_kernel      recomputes the shortlisted distances with the SAME exact-order routines as the graph search
+//                         (bit-identical to the reference's distance kernels) and emits the k best by
+//                         (distance, then id).
+// The f16 stage is only a filter (kk = max(4k, k+32) <= 128), so the final ids/distances do not depend on f16
+// rounding unless a true neighbour is pushed out of the shortlist, which needs an f16 error larger than the gap to
+// the kk-th candidate.  Values must fit float16 (|x| < 65504).
+#include "svsx_device.h"
+#include "svsx_kernels.h"
+
+namespace svsx {
+
+typedef float float16v_t __attribute__((ext_vector_type(16)));
+
+// ---- shadow conversion: any stored row type (optionally SQ-decompressed) -> f16 rows padded to 16 + squared norms ----
+template <int DT>
+__global__ __launch_bounds__(64) void to_half_kernel(const void* __restrict__ src, size_t src_row_bytes, uint32_t n, uint32_t d, uint32_t dpad,
+                                                     int decomp, float scale, float bias, _Float16* __restrict__ dst, float* __restrict__ norm2) {
+    const uint32_t row = blockIdx.x;
+    if (row >= n) return;
+    const unsigned char* s = static_cast<const unsigned char*>(src) + static_cast<size_t>(row) * src_row_bytes;
+    float acc = 0.0f;
+    for (uint32_t i = threadIdx.x; i < dpad; i += 64) {
+        float x = 0.0f;
+        if (i < d) {
+            if constexpr (DT == DT_F32) x = reinterpret_cast<const float*>(s)[i];
+            else if constexpr (DT == DT_F16) x = static_cast<float>(reinterpret_cast<const _Float16*>(s)[i]);
+            else if constexpr (DT == DT_I8) x = static_cast<float>(static_cast<int>(reinterpret_cast<const int8_t*>(s)[i]));
+            else x = static_cast<float>(static_cast<unsigned>(s[i]));
+            if (decomp) x = scale * x + bias;
+        }
+        const _Float16 h = static_cast<_Float16>(x);
+        dst[static_cast<size_t>(row) * dpad + i] = h;
+        const float hf = static_cast<float>(h);
+        acc = __builtin_fmaf(hf, hf, acc);
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (norm2 != nullptr && threadIdx.x == 0) norm2[row] = acc;
+}
+
+hipError_t launch_to_half(int dtype, const void* src, size_t src_row_bytes, uint32_t n, uint32_t d, uint32_t dpad, int decomp, float scale,
+                          float bias, void* dst, float* norm2, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    _Float16* o = static_cast<_Float16*>(dst);
+    switch (dtype) {
+        case DT_F32: hipLaunchKernelGGL(to_half_kernel<DT_F32>, dim3(n), dim3(64), 0, stream, src, src_row_bytes, n, d, dpad, decomp, scale, bias, o, norm2); break;
+        case DT_F16: hipLaunchKernelGGL(to_half_kernel<DT_F16>, dim3(n), dim3(64), 0, stream, src, src_row_bytes, n, d, dpad, decomp, scale, bias, o, norm2); break;
+        case DT_I8: hipLaunchKernelGGL(to_half_kernel<DT_I8>, dim3(n), dim3(64), 0, stream, src, src_row_bytes, n, d, dpad, decomp, scale, bias, o, norm2); break;
+        case DT_U8: hipLaunchKernelGGL(to_half_kernel<DT_U8>, dim3(n), dim3(64), 0, stream, src, src_row_bytes, n, d, dpad, decomp, scale, bias, o, norm2); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- stage 1: MFMA shortlist ---------------------------------------------------------------------------------------------
+// key (smaller = better): L2: |x|^2 - 2 q.x   IP: -q.x   cosine: -q.x / |x|      (per-query constants dropped)
+// KS > 0: compile-time number of 16-element k-steps (<= 8): the B fragments of the NEXT tile are loaded while the
+// current tile's MFMAs run (software pipeline); KS == 0: runtime k loop.
+template <int METRIC, int KS>
+__global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q0 = blockIdx.x * 64u;
+    const uint32_t slice = blockIdx.y;
+    const uint32_t dpad = a.dpad;
+    const uint32_t ks = dpad >> 4;
+    const uint32_t astride = dpad * 2u + 16u; // bytes; +16 shifts consecutive rows by 4 banks
+    unsigned char* A = smem;
+    float* lkey = reinterpret_cast<float*>(smem + 64u * astride);   // 64 x kk
+    uint32_t* lid = reinterpret_cast<uint32_t*>(lkey + 64u * a.kk); // 64 x kk
+    float* tau = reinterpret_cast<float*>(lid + 64u * a.kk);        // 64
+    const uint32_t kk = a.kk;
+
+    // A tile: 64 query rows (f16, zero padded), coalesced 16-B copies
+    const uint32_t chunks_per_row = dpad / 8u;
+    for (uint32_t c = lane; c < 64u * chunks_per_row; c += 64) {
+        const uint32_t r = c / chunks_per_row, cc = c % chunks_per_row;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q0 + r < a.nq) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.qh) + (static_cast<size_t>(q0 + r) * dpad + cc * 8u) * 2u);
+        *reinterpret_cast<uint4*>(A + r * astride + cc * 16u) = v;
+    }
+    for (uint32_t i = lane; i < 64u * kk; i += 64) {
+        lkey[i] = __builtin_inff();
+        lid[i] = kInvalidId;
+    }
+    tau[lane] = __builtin_inff();
+    lds_order();
+
+    const uint32_t rows_per_slice = ((a.n + a.n_slices - 1) / a.n_slices + 31u) & ~31u;
+    const uint32_t x_lo = slice * rows_per_slice;
+    const uint32_t x_hi = (x_lo + rows_per_slice) < a.n ? (x_lo + rows_per_slice) : a.n;
+    const uint32_t half = lane >> 5, col = lane & 31u;
+    const _Float16* xh = static_cast<const _Float16*>(a.xh);
+
+    float tl[2][16]; // register copies of tau for this lane's 32 (query tile, C/D row) cells
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tl[qt][r] = __builtin_inff();
+    }
+    constexpr int NB = KS > 0 ? KS : 1;
+    half8_t bcur[NB], bnext[NB];
+    half8_t afr0[NB], afr1[NB]; // static KS: the wave's two A tiles stay in registers for the whole slice
+    float xn_cur = 0.0f, xn_next = 0.0f;
+    auto load_tile = [&](uint32_t xt, half8_t (&dst)[NB], float& xnv) {
+        const uint32_t r = xt + col;
+        const uint32_t rr = r < x_hi ? r : x_lo;
+        const _Float16* p = xh + static_cast<size_t>(rr) * dpad + 8u * half;
+#pragma unroll
+        for (int s2 = 0; s2 < NB; ++s2) dst[s2] = *reinterpret_cast<const half8_t*>(p + 16 * s2);
+        if constexpr (METRIC != M_IP) xnv = a.xnorm2[rr];
+    };
+    if constexpr (KS > 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            afr0[s2] = *reinterpret_cast<const half8_t*>(A + col * astride + (16u * s2 + 8u * half) * 2u);
+            afr1[s2] = *reinterpret_cast<const half8_t*>(A + (32u + col) * astride + (16u * s2 + 8u * half) * 2u);
+        }
+        if (x_lo < x_hi) load_tile(x_lo, bcur, xn_cur);
+    }
+    for (uint32_t x0 = x_lo; x0 < x_hi; x0 += 32) {
+        const uint32_t row = x0 + col;
+        const bool valid = row < x_hi;
+        float16v_t acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+        if constexpr (KS > 0) {
+            if (x0 + 32 < x_hi) load_tile(x0 + 32, bnext, xn_next); // in flight during this tile's MFMAs
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[s2], bcur[s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr1[s2], bcur[s2], acc1, 0, 0, 0);
+            }
+        } else {
+            const _Float16* xr = xh + static_cast<size_t>(valid ? row : x_lo) * dpad + 8u * half;
+            for (uint32_t s2 = 0; s2 < ks; ++s2) {
+                const half8_t b = *reinterpret_cast<const half8_t*>(xr + 16u * s2);
+                const half8_t a0 = *reinterpret_cast<const half8_t*>(A + col * astride + (16u * s2 + 8u * half) * 2u);
+                const half8_t a1 = *reinterpret_cast<const half8_t*>(A + (32u + col) * astride + (16u * s2 + 8u * half) * 2u);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc1, 0, 0, 0);
+            }
+        }
+        float xn = 0.0f;
+        if constexpr (KS > 0) {
+            xn = xn_cur;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) bcur[s2] = bnext[s2];
+            xn_cur = xn_next;
+        } else if constexpr (METRIC != M_IP) {
+            xn = valid ? a.xnorm2[row] : 0.0f;
+        }
+        float rinv = 1.0f;
+        if constexpr (METRIC == M_COS) rinv = 1.0f / sqrtf(xn > 0.0f ? xn : 1.0f);
+
+        // keys for this lane's 32 (query, row) cells; accept test against the thresholds cached in registers
+        float key[2][16];
+        bool any = false;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc = qt == 0 ? acc0[r] : acc1[r];
+                float kv;
+                if constexpr (METRIC == M_L2) kv = xn - 2.0f * sc;
+                else if constexpr (METRIC == M_IP) kv = -sc;
+                else kv = -sc * rinv;
+                if (!valid) kv = __builtin_inff();
+                key[qt][r] = kv;
+                any = any || (kv < tl[qt][r]);
+            }
+        }
+        if (__ballot(any) == 0ull) continue; // common case once the shortlists are warm: nothing to insert
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t qi = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * half; // C/D row map
+                unsigned long long m = __ballot(key[qt][r] < tau[qi]);
+                while (m != 0ull) {
+                    const int bl = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const float kq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[qt][r]), bl));
+                    const uint32_t bq = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * static_cast<uint32_t>(bl >> 5);
+                    if (!(kq < tau[bq])) continue;
+                    const uint32_t id = x0 + static_cast<uint32_t>(bl & 31);
+                    float* kl = lkey + bq * kk;
+                    uint32_t* il = lid + bq * kk;
+                    if (kk <= 64u) {
+                        // one entry per lane: position by ballot, shift by one lane (DPP wave_shr:1), single write-back
+                        float ek = __builtin_inff();
+                        uint32_t ei = kInvalidId;
+                        if (lane < kk) { ek = kl[lane]; ei = il[lane]; }
+                        const uint32_t pos = __popcll(__ballot(lane < kk && ek <= kq)); // ties: existing entries first
+                        const float pk = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ek), 0x138, 0xf, 0xf, false));
+                        const uint32_t pi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(ei), 0x138, 0xf, 0xf, false));
+                        const float nk = lane < pos ? ek : (lane == pos ? kq : pk);
+                        const uint32_t ni = lane < pos ? ei : (lane == pos ? id : pi);
+                        lds_order();
+                        if (lane < kk && lane >= pos) { kl[lane] = nk; il[lane] = ni; }
+                        const float nt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nk), static_cast<int>(kk - 1u)));
+                        if (lane == 0) tau[bq] = nt;
+                        lds_order();
+                        continue;
+                    }
+                    // general path (kk > 64): sorted insert through LDS
+                    uint32_t pos = 0;
+                    for (uint32_t c0 = 0; c0 < kk; c0 += 64) {
+                        const uint32_t i = c0 + lane;
+                        pos += __popcll(__ballot(i < kk && kl[i] <= kq));
+                    }
+                    lds_order();
+                    for (int c = static_cast<int>((kk - 1u - pos + 63u) >> 6) - 1; c >= 0; --c) {
+                        const uint32_t i = pos + (static_cast<uint32_t>(c) << 6) + lane;
+                        float kv = 0.0f;
+                        uint32_t iv = 0;
+                        const bool mv = i + 1u < kk;
+                        if (mv) { kv = kl[i]; iv = il[i]; }
+                        lds_order();
+                        if (mv) { kl[i + 1] = kv; il[i + 1] = iv; }
+                        lds_order();
+                    }
+                    if (lane == 0) {
+                        kl[pos] = kq;
+                        il[pos] = id;
+                    }
+                    lds_order();
+                    if (lane == 0) tau[bq] = kl[kk - 1];
+                    lds_order();
+                }
+            }
+        }
+        // thresholds changed: refresh the register copies
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tl[qt][r] = tau[static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * half];
+        }
+    }
+    // per-slice shortlists out: [slice][q][kk]
+    for (uint32_t i = lane; i < 64u * kk; i += 64) {
+        const uint32_t r = i / kk, t = i % kk;
+        if (q0 + r < a.nq) {
+            const size_t o = (static_cast<size_t>(slice) * a.nq + (q0 + r)) * kk + t;
+            a.out_keys[o] = lkey[i];
+            a.out_ids[o] = lid[i] == kInvalidId ? ~0ull : static_cast<uint64_t>(lid[i]);
+        }
+    }
+}
+
+hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
+    const size_t lds = 64u * (static_cast<size_t>(a.dpad) * 2 + 16) + 64u * static_cast<size_t>(a.kk) * 8 + 256;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((a.nq + 63) / 64, a.n_slices);
+    auto go = [&](auto kern) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a);
+        return hipGetLastError();
+    };
+    const uint32_t ks = a.dpad >> 4;
+#define SVSX_FLAT_CASE(M)                                                   \
+    if (ks == 6) return go(flat_mfma_kernel<M, 6>);                         \
+    if (ks == 8) return go(flat_mfma_kernel<M, 8>);                         \
+    if (ks == 4) return go(flat_mfma_kernel<M, 4>);                         \
+    return go(flat_mfma_kernel<M, 0>);
+    switch (metric) {
+        case M_L2: SVSX_FLAT_CASE(M_L2)
+        case M_IP: SVSX_FLAT_CASE(M_IP)
+        case M_COS: SVSX_FLAT_CASE(M_COS)
+    }
+#undef SVSX_FLAT_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---- stage 3: exact re-rank of the shortlist --------------------------------------------------------------------------------
+template <int DT, int METRIC, int QMODE>
+__global__ __launch_bounds__(64) void rerank_kernel(const RerankArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool GREATER = METRIC != M_L2;
+    constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    constexpr bool BC = !INTPATH && use_block_cyclic<DT>();
+    constexpr int G = (INTPATH || BC) ? 4 : 16 / Elem<DT>::E;
+    constexpr int RPP = 64 / G;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const int d = static_cast<int>(a.d);
+    const int dpad = (d + 15) & ~15;
+    float* qf = reinterpret_cast<float*>(smem);
+    uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t q_bytes = INTPATH ? static_cast<uint32_t>(dpad) : static_cast<uint32_t>(dpad) * 4u;
+    float* cd = reinterpret_cast<float*>(smem + q_bytes);      // kk exact distances
+    uint32_t* ci = reinterpret_cast<uint32_t*>(cd + a.kk);     // kk ids
+    const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
+    const QueryFix fx = prepare_query<DT, METRIC, QMODE>(qptr, a.q_dtype, d, dpad, qf, qw, a.sq_scale, a.sq_bias, lane);
+    const int sub = static_cast<int>(lane) & (G - 1);
+    const uint32_t grp = lane / G;
+    const unsigned char* data = static_cast<const unsigned char*>(a.data);
+    const float worst = GREATER ? -__builtin_inff() : __builtin_inff();
+    for (uint32_t c0 = 0; c0 < a.kk; c0 += RPP) {
+        const uint32_t c = c0 + grp;
+        uint64_t id64 = ~0ull;
+        if (c < a.kk) id64 = a.cand_ids[static_cast<size_t>(qi) * a.kk + c];
+        const bool act = id64 != ~0ull;
+        const uint32_t id = act ? static_cast<uint32_t>(id64) : 0u;
+        const unsigned char* row = data + static_cast<size_t>(id) * a.row_bytes;
+        float fmain = 0.0f, fnrm = 0.0f;
+        int ab = 0, bb = 0;
+        if constexpr (INTPATH) int_row_sums<DT>(row, act, qw, d, sub, ab, bb);
+        else if constexpr (BC) float_row_distance_bc<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+        else float_row_distance<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+        const float dist = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
+        if (c < a.kk && sub == 0) {
+            cd[c] = act ? dist : worst;
+            ci[c] = act ? id : kInvalidId;
+        }
+    }
+    lds_order();
+    // rank by (distance with the metric's comparator, then id); invalid entries last
+    for (uint32_t c = lane; c < a.kk; c += 64) {
+        const float dc = cd[c];
+        const uint32_t ic = ci[c];
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < a.kk; ++o) {
+            const float dd = cd[o];
+            const uint32_t io = ci[o];
+            const bool o_valid = io != kInvalidId, c_valid = ic != kInvalidId;
+            bool before;
+            if (o_valid != c_valid) before = o_valid;
+            else before = cmpf<GREATER>(dd, dc) || (!cmpf<GREATER>(dc, dd) && (io < ic || (io == ic && o < c)));
+            rank += (o != c && before) ? 1u : 0u;
+        }
+        if (rank < a.k) {
+            const size_t o = static_cast<size_t>(qi) * a.k + rank;
+            const bool have = ic != kInvalidId;
+            if (a.ids64 != nullptr) a.ids64[o] = have ? static_cast<uint64_t>(ic) + a.id_offset : ~0ull;
+            if (a.dists != nullptr) a.dists[o] = have ? dc : __builtin_inff();
+        }
+    }
+}
+
+template <int DT, int METRIC, int QMODE> static hipError_t launch_rerank_one(const RerankArgs& a, hipStream_t stream) {
+    const int dpad = (static_cast<int>(a.d) + 15) & ~15;
+    const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + static_cast<size_t>(a.kk) * 8;
+    hipLaunchKernelGGL((rerank_kernel<DT, METRIC, QMODE>), dim3(a.nq), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int DT, int QMODE> static hipError_t launch_rerank_metric(int metric, const RerankArgs& a, hipStream_t stream) {
+    switch (metric) {
+        case M_L2:
+            if constexpr (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_rerank_one<DT, M_L2, QMODE>(a, stream);
+        case M_IP:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_rerank_one<DT, M_IP, QMODE>(a, stream);
+        case M_COS:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_IP) return hipErrorInvalidValue;
+            else return launch_rerank_one<DT, M_COS, QMODE>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream) {
+    switch (qmode) {
+        case QM_FLOAT:
+            switch (data_dtype) {
+                case DT_F32: return launch_rerank_metric<DT_F32, QM_FLOAT>(metric, a, stream);
+                case DT_F16: return launch_rerank_metric<DT_F16, QM_FLOAT>(metric, a, stream);
+                case DT_I8: return launch_rerank_metric<DT_I8, QM_FLOAT>(metric, a, stream);
+                case DT_U8: return launch_rerank_metric<DT_U8, QM_FLOAT>(metric, a, stream);
+            }
+            break;
+        case QM_INT:
+            if (data_dtype == DT_I8) return launch_rerank_metric<DT_I8, QM_INT>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank_metric<DT_U8, QM_INT>(metric, a, stream);
+            break;
+        case QM_SQ_IP:
+            if (data_dtype == DT_I8) return launch_rerank_metric<DT_I8, QM_SQ_IP>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank_metric<DT_U8, QM_SQ_IP>(metric, a, stream);
+            break;
+        case QM_SQ_COS:
+            if (data_dtype == DT_I8) return launch_rerank_metric<DT_I8, QM_SQ_COS>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank_metric<DT_U8, QM_SQ_COS>(metric, a, stream);
+            break;
+        case QM_SQ_L2:
+            if (data_dtype == DT_I8) return launch_rerank_metric<DT_I8, QM_SQ_L2>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank_metric<DT_U8, QM_SQ_L2>(metric, a, stream);
+            break;
+    }
+    return hipErrorInvalidValue;
+}
+
+} // namespace svsx

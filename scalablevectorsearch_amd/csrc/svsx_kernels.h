@@ -75,6 +75,35 @@ struct PruneArgs {
 };
 hipError_t launch_prune(int data_dtype, int metric, bool decomp, const PruneArgs& a, hipStream_t stream);
 
+// flat (exhaustive) search: f16 shadow conversion, MFMA shortlist, exact re-rank (svsx_flat.hip)
+hipError_t launch_to_half(int dtype, const void* src, size_t src_row_bytes, uint32_t n, uint32_t d, uint32_t dpad, int decomp, float scale,
+                          float bias, void* dst, float* norm2, hipStream_t stream);
+struct FlatArgs {
+    const void* xh;         // n x dpad f16 (zero padded rows)
+    const float* xnorm2;    // n
+    uint32_t n, dpad;
+    const void* qh;         // nq x dpad f16
+    uint32_t nq, kk, n_slices;
+    float* out_keys;        // [n_slices][nq][kk]
+    uint64_t* out_ids;      // [n_slices][nq][kk]
+};
+hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream);
+struct RerankArgs {
+    const void* data;
+    size_t row_bytes;
+    uint32_t d;
+    float sq_scale, sq_bias;
+    uint64_t id_offset;
+    const void* queries;
+    size_t q_row_bytes;
+    int q_dtype;
+    uint32_t nq, kk, k;
+    const uint64_t* cand_ids;   // [nq][kk], ~0 = empty
+    uint64_t* ids64;            // [nq][k]
+    float* dists;               // [nq][k]
+};
+hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
+
 // layout conversion kernels (index creation)
 hipError_t launch_pack_graph(const uint32_t* d_svs_graph, uint32_t svs_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, hipStream_t stream);
 

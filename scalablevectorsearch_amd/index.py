@@ -200,6 +200,21 @@ class VamanaIndex:
         res = QueryResult(ids, dists)
         return (res, st) if stats else res
 
+    def flat_search_device(self, d_queries, num_neighbors: int, d_ids64=None, d_dists=None, q_dtype=None, stream=None):
+        """Exhaustive search (FlatIndex::search, index/flat/flat.h:322-460) on torch CUDA tensors: MFMA f16 shortlist +
+        exact re-rank.  Returns (ids int64 [nq,k], dists f32 [nq,k])."""
+        import torch
+
+        nq = d_queries.shape[0]
+        code = q_dtype if q_dtype is not None else {torch.float32: 0, torch.float16: 1, torch.int8: 2, torch.uint8: 3}[d_queries.dtype]
+        if d_ids64 is None:
+            d_ids64 = torch.empty((nq, num_neighbors), dtype=torch.int64, device=d_queries.device)
+        if d_dists is None:
+            d_dists = torch.empty((nq, num_neighbors), dtype=torch.float32, device=d_queries.device)
+        s = stream if stream is not None else torch.cuda.current_stream(d_queries.device).cuda_stream
+        _lib.check(_lib.lib().svsx_flat_search_device(self._h, d_queries.data_ptr(), code, nq, num_neighbors, d_ids64.data_ptr(), d_dists.data_ptr(), C.c_void_p(s)))
+        return d_ids64, d_dists
+
     def prune_device(self, d_node_ids, d_pool_ids, d_pool_dists, max_out: int, alpha: float, out_stride: int, stream=None):
         """heuristic_prune_neighbors (index/vamana/prune.h:100-246) for a batch of vertices, on torch CUDA tensors:
         node ids int32 [B], pool ids int32 [B,P] (sorted best-first, -1 padded), pool dists f32 [B,P] -> int32 [B,out_stride]."""
@@ -234,3 +249,35 @@ class VamanaIndex:
             self._h, d_queries.data_ptr(), code, nq, num_neighbors, C.byref(sp),
             d_ids64.data_ptr() if d_ids64 is not None else None, d_ids32.data_ptr() if d_ids32 is not None else None,
             d_dists.data_ptr() if d_dists is not None else None, C.byref(aux), C.c_void_p(s)))
+
+
+class FlatIndex:
+    """svs::index::flat::FlatIndex (index/flat/flat.h:322-460): exhaustive search over a dataset resident in HBM.
+    The dense query x database products run on the matrix cores (float16 MFMA shortlist), the returned distances are
+    recomputed with the exact reference-order kernels."""
+
+    def __init__(self, data, distance, device: int = 0, sq=None):
+        self.distance = as_functor(distance)
+        data = np.ascontiguousarray(data)
+        desc = _lib.IndexDesc(
+            int(self.distance.metric), dtype_code(data), data.shape[0], data.shape[1], data.ctypes.data, 0,
+            None, 0, 0, None, 0, int(sq is not None), float(sq[0]) if sq else 1.0, float(sq[1]) if sq else 0.0, device, 0,
+        )
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().svsx_index_create(C.byref(desc), C.byref(self._h)))
+        self.device = device
+        self.n, self.d = data.shape
+
+    __del__ = VamanaIndex.__del__
+    flat_search_device = VamanaIndex.flat_search_device
+
+    def search(self, queries, num_neighbors: int) -> QueryResult:
+        import torch
+
+        queries = np.ascontiguousarray(np.atleast_2d(queries))
+        if queries.shape[1] != self.d:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Query dimension {queries.shape[1]} does not match index dimension {self.d}")
+        dq = torch.from_numpy(queries.view(np.int8) if queries.dtype == np.int8 else queries).to(torch.device("cuda", self.device))
+        ids, dists = self.flat_search_device(dq, num_neighbors, q_dtype=dtype_code(queries))
+        torch.cuda.synchronize(self.device)
+        return QueryResult(ids.cpu().numpy().view(np.uint64), dists.cpu().numpy())

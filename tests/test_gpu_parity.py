@@ -352,3 +352,86 @@ def test_calibrate_reaches_target_recall(svs, oracle, small_world):
     if w > 10:
         r1 = svs.k_recall_at_n(gt, idx.search(sw["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(w - 1))).indices, 10, 10)
         assert r1 < 0.95
+
+
+def test_config1_plumbing_shape(svs, oracle):
+    """BASELINE config 1 / SURVEY 8d C1: 10 000 x 128 f32 L2, graph with the build parameters of
+    data/test_dataset/vamana_config.toml:19-27 (R=128, L=200, alpha=1.2, C=1000, prune_to=128; built here by the GPU
+    builder because the reference's base vectors/graph are missing blobs), 1 000 queries searched as ONE batch and as
+    a batch=1 loop at windows {10, 20, 50, 100}: ids and distance bits equal the oracle's either way."""
+    import torch
+
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
+
+    x = deep_like(10_000, 128, 32, seed=1, normalize=False)
+    q = deep_like(1_000, 128, 32, seed=2, normalize=False)
+    dx = torch.from_numpy(x).cuda()
+    bp = VamanaBuildParameters(alpha=1.2, graph_max_degree=128, window_size=200, max_candidate_pool_size=1000, prune_to=128)
+    graph, entry = build_vamana_device(dx, 10_000, 128, svs.DistanceL2(), bp)
+    g = device_graph_to_svs(graph, 128)
+    assert g[:, 0].max() <= 128 and g[:, 0].mean() > 32
+    idx = svs.VamanaIndex(g, x, svs.DistanceL2(), [entry])
+    gt, _ = oracle.flat_search(L2, x, q[:100], 10)
+    for w in (10, 20, 50, 100):
+        sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w))
+        res = idx.search(q, 10, sp)
+        ids, dists = oracle.search(L2, x, g, np.array([entry], np.uint32), q, 10, w)
+        assert (res.indices == ids.astype(np.uint64)).all() and (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+        for i in range(0, 1000, 97):  # batch = 1
+            one = idx.search(q[i : i + 1], 10, sp)
+            assert (one.indices[0] == res.indices[i]).all() and (one.distances[0] == res.distances[i]).all()
+    assert oracle.recall(gt, idx.search(q[:100], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(100))).indices.astype(np.uint32), 10, 10) > 0.95
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("ddt,qdt", [(F32, F32), (F16, F32), (F16, F16), (I8, F32), (I8, I8), (U8, U8)])
+def test_flat_search_matches_exhaustive_oracle(svs, oracle, metric, ddt, qdt):
+    """FlatIndex::search (index/flat/flat.h:322-460): MFMA f16 shortlist + exact re-rank == the oracle's exhaustive
+    search (ids and distance bits; ties by lower id)."""
+    rng = np.random.default_rng(17)
+    fn = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}[metric]
+
+    def conv(a, dt):
+        if dt == F32:
+            return a
+        if dt == F16:
+            return a.astype(np.float16)
+        if dt == I8:
+            return np.clip(np.round(a * 300), -128, 127).astype(np.int8)
+        return np.clip(np.round(a * 300 + 128), 0, 255).astype(np.uint8)
+
+    x = conv(deep_like(3000, 100, 16, seed=5), ddt)
+    q = conv(deep_like(70, 100, 16, seed=6), qdt)
+    idx = svs.FlatIndex(x, fn)
+    for k in (1, 10, 32):
+        res = idx.search(q, k)
+        ids, dists = oracle.flat_search(metric, x, q, k)
+        same = res.indices == ids.astype(np.uint64)
+        # a shortlist miss or an id swap is only legitimate between candidates of EQUAL exact distance
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all(), (metric, ddt, qdt, k)
+        assert same.mean() > 0.999 or (same | (res.distances == dists)).all()
+
+
+def test_flat_search_large_and_sq(svs, oracle):
+    import torch
+
+    from bench import brute_force_topk, deep_like_device
+
+    dev = torch.device("cuda", 0)
+    n, d, nq, k = 150_000, 96, 3000, 10
+    x = deep_like_device(n, d, 24, 1, dev)
+    q = deep_like_device(nq, d, 24, 2, dev)
+    idx = svs.FlatIndex(x.cpu().numpy(), svs.DistanceL2())
+    ids, dists = idx.flat_search_device(q, k)
+    torch.cuda.synchronize()
+    gt = brute_force_topk(x, q, k)
+    assert (ids == gt).float().mean().item() > 0.9995
+    assert (dists[:, 1:] >= dists[:, :-1]).all()
+    # scalar-quantized database, cosine
+    xs = deep_like(4000, 64, 16, seed=8, normalize=False)
+    qs = deep_like(50, 64, 16, seed=9, normalize=False)
+    codes, scale, bias = oracle.sq_compress(xs, I8)
+    f = svs.FlatIndex(codes, svs.DistanceCosineSimilarity(), sq=(scale, bias))
+    r = f.search(qs, 5)
+    oi, od = oracle.flat_search(COS, codes, qs, 5, sq=(scale, bias))
+    assert (r.indices == oi.astype(np.uint64)).mean() > 0.99 and (r.distances.view(np.uint32) == od.view(np.uint32)).mean() > 0.99
