@@ -72,7 +72,24 @@ def recall_at(gt, ids, k):
     return hit / (gt.shape[0] * k)
 
 
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    """Keep fd 1 for the ONE JSON line: everything else that writes to stdout (RCCL's version banner, C libraries)
+    is redirected to stderr for the lifetime of the process."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(line: str):
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -295,7 +312,7 @@ def main():
         matched["cpu_cores"] = cm["cores"]
         matched["gpu_over_cpu"] = matched["gpu_qps"] / cm["value"]
         matched["ids_identical_on_sample"] = "identical on sample: True" in cm["sample"]
-    print(json.dumps(result), flush=True)
+    _emit(json.dumps(result))
     if multi:
         dist.destroy_process_group()
 
