@@ -274,13 +274,21 @@ static int search_common(
     // visited_set: 0 = off (reference default, search_params.h:42); 1 = on with the default LDS filter size;
     // >= 64 = explicit number of filter entries (rounded down to a power of two, at most 16384).
     if (params && params->visited_set > 0) {
-        uint32_t fe = params->visited_set == 1 ? kDefaultFilterEntries : static_cast<uint32_t>(params->visited_set);
-        if (fe < 64) fe = 64;
-        if (fe > 16384) fe = 16384;
-        while (fe & (fe - 1)) fe &= fe - 1;
-        // 16-bit tags must identify the id exactly: grow the table until (n >> log2 entries) < 0xFFFF, else stay off
+        uint32_t fe;
+        if (params->visited_set == 1) {
+            // default: 4 KB of LDS per wave (the measured optimum): 4096 entries with 8-bit tags when they identify the
+            // id exactly ((n >> 12) < 255), else 2048 entries with 16-bit tags
+            fe = (ix->n >> 12) < 0xFFu ? 4096u : kDefaultFilterEntries;
+        } else {
+            fe = static_cast<uint32_t>(params->visited_set);
+            if (fe < 64) fe = 64;
+            if (fe > 16384) fe = 16384;
+            while (fe & (fe - 1)) fe &= fe - 1;
+        }
+        // tags must identify the id exactly: grow the table until (n >> log2 entries) < 0xFFFF, else stay off
         while (fe <= 16384 && (ix->n >> __builtin_ctz(fe)) >= 0xFFFFu) fe <<= 1;
         a.filter_entries = fe <= 16384 ? fe : 0;
+        a.filter_tag8 = (a.filter_entries && (ix->n >> __builtin_ctz(a.filter_entries)) < 0xFFu) ? 1u : 0u;
     }
     a.ids64 = d_ids64;
     a.ids32 = d_ids32;

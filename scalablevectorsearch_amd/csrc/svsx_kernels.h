@@ -27,6 +27,7 @@ struct SearchArgs {
     // parameters
     uint32_t window, capacity, k;
     uint32_t filter_entries;  // 0 = no visited filter; else power of two (exact-tag direct-mapped filter in LDS)
+    uint32_t filter_tag8;     // 1: 8-bit tags (host guarantees (n >> log2 entries) < 255), 0: 16-bit tags
     // outputs
     uint64_t* ids64;
     uint32_t* ids32;

@@ -50,11 +50,15 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     // (n >> log2(entries)) < 0xFFFF, so slot+tag identify the id exactly: no false positives -- a hit means the id was
     // evaluated earlier in this query and re-inserting it would be a no-op (duplicate, or not better than the worst,
     // which only improves).  Result-neutral by construction; it only removes vector re-fetches.
+    // When (n >> log2 entries) < 255 the tag fits 8 bits (0xFF = empty) and the same LDS holds twice the entries.
     uint16_t* filt = reinterpret_cast<uint16_t*>(smem + buf_bytes + q_bytes);
-    uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + a.filter_entries * 2u); // 64 ids
+    uint8_t* filt8 = reinterpret_cast<uint8_t*>(filt);
+    const bool tag8 = a.filter_tag8 != 0u;
+    const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
+    uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
     const uint32_t fmask = a.filter_entries - 1u;
     const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));
-    for (uint32_t i = lane; i < a.filter_entries; i += 64) filt[i] = 0xFFFFu;
+    for (uint32_t i = lane; i < filt_bytes / 4u; i += 64) reinterpret_cast<uint32_t*>(filt)[i] = 0xFFFFFFFFu;
 
     // ---- load + fix the query (maybe_fix_argument, greedy_search.h:140) -------------------------------------
     const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
@@ -95,7 +99,10 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
                 const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
                 ++n_eval;
-                if (a.filter_entries != 0u && lane == 0) filt[id & fmask] = static_cast<uint16_t>(id >> fshift);
+                if (a.filter_entries != 0u && lane == 0) {
+                    if (tag8) filt8[id & fmask] = static_cast<uint8_t>(id >> fshift);
+                    else filt[id & fmask] = static_cast<uint16_t>(id >> fshift);
+                }
                 if (buf.size < buf.capacity) {
                     // push_back + (stable) sort == ordered insert without the duplicate check
                     uint32_t pos = 0;
@@ -141,9 +148,14 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 bool keep = nid != kInvalidId;
                 if (keep) {
                     const uint32_t h = nid & fmask;
-                    const uint16_t tag = static_cast<uint16_t>(nid >> fshift);
-                    keep = filt[h] != tag;
-                    filt[h] = tag;
+                    const uint32_t tag = nid >> fshift;
+                    if (tag8) {
+                        keep = static_cast<uint32_t>(filt8[h]) != tag;
+                        filt8[h] = static_cast<uint8_t>(tag);
+                    } else {
+                        keep = static_cast<uint32_t>(filt[h]) != tag;
+                        filt[h] = static_cast<uint16_t>(tag);
+                    }
                 }
                 const unsigned long long km = __ballot(keep);
                 cnt = __popcll(km);
@@ -213,7 +225,7 @@ template <int DT, int METRIC, int QMODE, int DS> static hipError_t launch_one(co
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
-                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * 2 + 64 * 4 : 0);
+                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) + 64 * 4 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = search_kernel<DT, METRIC, QMODE, DS>;
     if (lds > 48 * 1024) {
