@@ -87,6 +87,28 @@ struct DeviceBuffer {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
+// Temporary buffer allocated and released in stream order (no device-wide synchronisation).
+struct StreamBuffer {
+    void* p = nullptr;
+    hipStream_t s = nullptr;
+    ~StreamBuffer() {
+        if (p) (void)hipFreeAsync(p, s);
+    }
+    hipError_t alloc(size_t bytes, hipStream_t stream) {
+        s = stream;
+        return hipMallocAsync(&p, bytes ? bytes : 1, stream);
+    }
+};
+
+// A private stream per host call: concurrent callers (index.h:541-545 contract) never serialise on the default stream.
+struct CallStream {
+    hipStream_t s = nullptr;
+    ~CallStream() {
+        if (s) (void)hipStreamDestroy(s);
+    }
+    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+};
+
 int validate_common(int metric, int dtype, size_t n, size_t d) {
     if (metric < 0 || metric > 2) return fail(SVSX_INVALID_ARGUMENT, "unknown metric %d", metric);
     if (dtype_size(dtype) == 0) return fail(SVSX_INVALID_ARGUMENT, "unknown data dtype %d", dtype);
@@ -340,34 +362,36 @@ int svsx_search(
     if (nq == 0) return SVSX_SUCCESS;
     HIP_TRY(hipSetDevice(ix->device));
     const size_t q_stride = (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype);
-    DeviceBuffer dq, d64, d32, dd, dst, dhi, dhd, dhl;
-    HIP_TRY(dq.alloc(q_stride * nq));
-    HIP_TRY(hipMemcpy(dq.p, queries, q_stride * nq, hipMemcpyHostToDevice));
-    if (ids64) HIP_TRY(d64.alloc(nq * k * 8));
-    if (ids32) HIP_TRY(d32.alloc(nq * k * 4));
-    if (dists) HIP_TRY(dd.alloc(nq * k * 4));
+    CallStream cs;
+    HIP_TRY(cs.create());
+    StreamBuffer dq, d64, d32, dd, dst, dhi, dhd, dhl;
+    HIP_TRY(dq.alloc(q_stride * nq, cs.s));
+    HIP_TRY(hipMemcpyAsync(dq.p, queries, q_stride * nq, hipMemcpyHostToDevice, cs.s));
+    if (ids64) HIP_TRY(d64.alloc(nq * k * 8, cs.s));
+    if (ids32) HIP_TRY(d32.alloc(nq * k * 4, cs.s));
+    if (dists) HIP_TRY(dd.alloc(nq * k * 4, cs.s));
     svsx_search_aux daux;
     memset(&daux, 0, sizeof(daux));
     daux.query_row_stride_bytes = q_stride;
     if (aux) {
         daux.history_cap = aux->history_cap;
-        if (aux->stats) { HIP_TRY(dst.alloc(nq * 16)); daux.stats = static_cast<uint32_t*>(dst.p); }
-        if (aux->history_ids && aux->history_cap) { HIP_TRY(dhi.alloc(nq * aux->history_cap * 4)); daux.history_ids = static_cast<uint32_t*>(dhi.p); }
-        if (aux->history_dists && aux->history_cap) { HIP_TRY(dhd.alloc(nq * aux->history_cap * 4)); daux.history_dists = static_cast<float*>(dhd.p); }
-        if (aux->history_len) { HIP_TRY(dhl.alloc(nq * 4)); daux.history_len = static_cast<uint32_t*>(dhl.p); }
+        if (aux->stats) { HIP_TRY(dst.alloc(nq * 16, cs.s)); daux.stats = static_cast<uint32_t*>(dst.p); }
+        if (aux->history_ids && aux->history_cap) { HIP_TRY(dhi.alloc(nq * aux->history_cap * 4, cs.s)); daux.history_ids = static_cast<uint32_t*>(dhi.p); }
+        if (aux->history_dists && aux->history_cap) { HIP_TRY(dhd.alloc(nq * aux->history_cap * 4, cs.s)); daux.history_dists = static_cast<float*>(dhd.p); }
+        if (aux->history_len) { HIP_TRY(dhl.alloc(nq * 4, cs.s)); daux.history_len = static_cast<uint32_t*>(dhl.p); }
     }
-    if (int rc = search_common(ix, dq.p, q_dtype, nq, k, params, static_cast<uint64_t*>(d64.p), static_cast<uint32_t*>(d32.p), static_cast<float*>(dd.p), &daux, nullptr))
+    if (int rc = search_common(ix, dq.p, q_dtype, nq, k, params, static_cast<uint64_t*>(d64.p), static_cast<uint32_t*>(d32.p), static_cast<float*>(dd.p), &daux, cs.s))
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if (ids64) HIP_TRY(hipMemcpy(ids64, d64.p, nq * k * 8, hipMemcpyDeviceToHost));
-    if (ids32) HIP_TRY(hipMemcpy(ids32, d32.p, nq * k * 4, hipMemcpyDeviceToHost));
-    if (dists) HIP_TRY(hipMemcpy(dists, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
+    if (ids64) HIP_TRY(hipMemcpyAsync(ids64, d64.p, nq * k * 8, hipMemcpyDeviceToHost, cs.s));
+    if (ids32) HIP_TRY(hipMemcpyAsync(ids32, d32.p, nq * k * 4, hipMemcpyDeviceToHost, cs.s));
+    if (dists) HIP_TRY(hipMemcpyAsync(dists, dd.p, nq * k * 4, hipMemcpyDeviceToHost, cs.s));
     if (aux) {
-        if (aux->stats) HIP_TRY(hipMemcpy(aux->stats, dst.p, nq * 16, hipMemcpyDeviceToHost));
-        if (daux.history_ids) HIP_TRY(hipMemcpy(aux->history_ids, dhi.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost));
-        if (daux.history_dists) HIP_TRY(hipMemcpy(aux->history_dists, dhd.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost));
-        if (aux->history_len) HIP_TRY(hipMemcpy(aux->history_len, dhl.p, nq * 4, hipMemcpyDeviceToHost));
+        if (aux->stats) HIP_TRY(hipMemcpyAsync(aux->stats, dst.p, nq * 16, hipMemcpyDeviceToHost, cs.s));
+        if (daux.history_ids) HIP_TRY(hipMemcpyAsync(aux->history_ids, dhi.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost, cs.s));
+        if (daux.history_dists) HIP_TRY(hipMemcpyAsync(aux->history_dists, dhd.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost, cs.s));
+        if (aux->history_len) HIP_TRY(hipMemcpyAsync(aux->history_len, dhl.p, nq * 4, hipMemcpyDeviceToHost, cs.s));
     }
+    HIP_TRY(hipStreamSynchronize(cs.s));
     return SVSX_SUCCESS;
 }
 
@@ -442,17 +466,14 @@ int svsx_flat_search_device(
     const size_t max_slices = (ix->n + 255) / 256;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
-    void *qh = nullptr, *sk = nullptr, *si = nullptr, *mk = nullptr, *mi = nullptr;
     const size_t q_stride = ix->d * dtype_size(q_dtype);
-    HIP_TRY(hipMallocAsync(&qh, nq * dpad * 2 + 64, stream));
-    HIP_TRY(hipMallocAsync(&sk, slices * nq * kk * 4, stream));
-    HIP_TRY(hipMallocAsync(&si, slices * nq * kk * 8, stream));
-    HIP_TRY(hipMallocAsync(&mk, nq * kk * 4, stream));
-    HIP_TRY(hipMallocAsync(&mi, nq * kk * 8, stream));
-    auto release = [&]() {
-        (void)hipFreeAsync(qh, stream); (void)hipFreeAsync(sk, stream); (void)hipFreeAsync(si, stream);
-        (void)hipFreeAsync(mk, stream); (void)hipFreeAsync(mi, stream);
-    };
+    StreamBuffer bqh, bsk, bsi, bmk, bmi;
+    HIP_TRY(bqh.alloc(nq * dpad * 2 + 64, stream));
+    HIP_TRY(bsk.alloc(slices * nq * kk * 4, stream));
+    HIP_TRY(bsi.alloc(slices * nq * kk * 8, stream));
+    HIP_TRY(bmk.alloc(nq * kk * 4, stream));
+    HIP_TRY(bmi.alloc(nq * kk * 8, stream));
+    void *qh = bqh.p, *sk = bsk.p, *si = bsi.p, *mk = bmk.p, *mi = bmi.p;
     hipError_t e = launch_to_half(q_dtype, d_queries, q_stride, static_cast<uint32_t>(nq), static_cast<uint32_t>(ix->d), dpad, 0, 1.0f, 0.0f, qh, nullptr, stream);
     FlatArgs fa;
     fa.xh = ix->d_half; fa.xnorm2 = ix->d_norm2; fa.n = static_cast<uint32_t>(ix->n); fa.dpad = dpad; fa.qh = qh;
@@ -470,7 +491,6 @@ int svsx_flat_search_device(
     ra.nq = static_cast<uint32_t>(nq); ra.kk = static_cast<uint32_t>(kk); ra.k = static_cast<uint32_t>(k);
     ra.cand_ids = static_cast<const uint64_t*>(mi); ra.ids64 = d_ids64; ra.dists = d_dists;
     if (e == hipSuccess) e = launch_rerank(ix->data_dtype, ix->metric, qmode, ra, stream);
-    release();
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "flat search launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
 }

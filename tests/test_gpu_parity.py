@@ -435,3 +435,31 @@ def test_flat_search_large_and_sq(svs, oracle):
     r = f.search(qs, 5)
     oi, od = oracle.flat_search(COS, codes, qs, 5, sq=(scale, bias))
     assert (r.indices == oi.astype(np.uint64)).mean() > 0.99 and (r.distances.view(np.uint32) == od.view(np.uint32)).mean() > 0.99
+
+
+def test_concurrent_host_callers(svs, oracle, small_world):
+    """index/vamana/index.h:541-545: search is const / re-entrant -- several host threads share one index."""
+    import threading
+
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    want = {}
+    for w in (8, 24, 64, 100):
+        want[w] = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, w)
+    errors = []
+
+    def worker(w, reps):
+        try:
+            for _ in range(reps):
+                r = idx.search(sw["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(w), search_buffer_visited_set=bool(w % 16)))
+                assert (r.indices == want[w][0].astype(np.uint64)).all()
+                assert (r.distances.view(np.uint32) == want[w][1].view(np.uint32)).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append((w, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(w, 15)) for w in (8, 24, 64, 100) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
