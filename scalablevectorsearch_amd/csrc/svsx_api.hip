@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -461,7 +462,15 @@ int svsx_flat_search_device(
     if (kk < k) kk = k;
     if (kk > ix->n) kk = ix->n < k ? k : ix->n;
     const size_t nqb = (nq + 63) / 64;
-    size_t slices = (1024 + nqb - 1) / nqb; // ~4 resident waves per CU (LDS-limited); fewer slices = fewer shortlist inserts
+    // one round of resident waves: LDS (64 shortlists of kk entries) bounds the waves per CU; a second round would
+    // double the time, more slices than needed only add shortlist inserts (measured: 14.1 ms at 80 % of the slots)
+    const size_t flat_lds = 64 * kk * 8 + 256;
+    size_t waves_per_cu = (160 * 1024) / flat_lds;
+    if (waves_per_cu > 8) waves_per_cu = 8;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    size_t target_waves = 256 * waves_per_cu * 4 / 5;
+    if (const char* ev = getenv("SVSX_FLAT_TARGET_WAVES")) target_waves = static_cast<size_t>(atoi(ev)) > 0 ? static_cast<size_t>(atoi(ev)) : target_waves;
+    size_t slices = (target_waves + nqb - 1) / nqb; // thresholds are shared across the slices of a query block
     if (slices > 64) slices = 64;
     const size_t max_slices = (ix->n + 255) / 256;
     if (slices > max_slices) slices = max_slices;
@@ -479,6 +488,10 @@ int svsx_flat_search_device(
     fa.xh = ix->d_half; fa.xnorm2 = ix->d_norm2; fa.n = static_cast<uint32_t>(ix->n); fa.dpad = dpad; fa.qh = qh;
     fa.nq = static_cast<uint32_t>(nq); fa.kk = static_cast<uint32_t>(kk); fa.n_slices = static_cast<uint32_t>(slices);
     fa.out_keys = static_cast<float*>(sk); fa.out_ids = static_cast<uint64_t*>(si);
+    StreamBuffer bgt;
+    HIP_TRY(bgt.alloc(nq * 4, stream));
+    fa.gtau = static_cast<uint32_t*>(bgt.p);
+    if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream); // +inf, order-encoded
     if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
     MergeArgs ma;
     ma.dists = static_cast<const float*>(sk); ma.ids = static_cast<const uint64_t*>(si);

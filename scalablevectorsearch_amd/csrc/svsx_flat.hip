@@ -22,6 +22,13 @@ namespace svsx {
 
 typedef float float16v_t __attribute__((ext_vector_type(16)));
 
+// order-preserving float <-> uint32 map (for atomicMin on thresholds that may be negative)
+__device__ __forceinline__ uint32_t enc_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_key(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
 // ---- shadow conversion: any stored row type (optionally SQ-decompressed) -> f16 rows padded to 16 + squared norms ----
 template <int DT>
 __global__ __launch_bounds__(64) void to_half_kernel(const void* __restrict__ src, size_t src_row_bytes, uint32_t n, uint32_t d, uint32_t dpad,
@@ -75,19 +82,23 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
     const uint32_t dpad = a.dpad;
     const uint32_t ks = dpad >> 4;
     const uint32_t astride = dpad * 2u + 16u; // bytes; +16 shifts consecutive rows by 4 banks
-    unsigned char* A = smem;
-    float* lkey = reinterpret_cast<float*>(smem + 64u * astride);   // 64 x kk
+    unsigned char* A = smem;                                         // runtime-k path only
+    const uint32_t a_bytes = KS > 0 ? 0u : 64u * astride;
+    float* lkey = reinterpret_cast<float*>(smem + a_bytes);          // 64 x kk
     uint32_t* lid = reinterpret_cast<uint32_t*>(lkey + 64u * a.kk); // 64 x kk
     float* tau = reinterpret_cast<float*>(lid + 64u * a.kk);        // 64
     const uint32_t kk = a.kk;
 
-    // A tile: 64 query rows (f16, zero padded), coalesced 16-B copies
-    const uint32_t chunks_per_row = dpad / 8u;
-    for (uint32_t c = lane; c < 64u * chunks_per_row; c += 64) {
-        const uint32_t r = c / chunks_per_row, cc = c % chunks_per_row;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q0 + r < a.nq) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.qh) + (static_cast<size_t>(q0 + r) * dpad + cc * 8u) * 2u);
-        *reinterpret_cast<uint4*>(A + r * astride + cc * 16u) = v;
+    // A tile: 64 query rows (f16, zero padded), coalesced 16-B copies (runtime-k path; the static path keeps its
+    // fragments in registers, loaded straight from global memory below)
+    if constexpr (KS == 0) {
+        const uint32_t chunks_per_row = dpad / 8u;
+        for (uint32_t c = lane; c < 64u * chunks_per_row; c += 64) {
+            const uint32_t r = c / chunks_per_row, cc = c % chunks_per_row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q0 + r < a.nq) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.qh) + (static_cast<size_t>(q0 + r) * dpad + cc * 8u) * 2u);
+            *reinterpret_cast<uint4*>(A + r * astride + cc * 16u) = v;
+        }
     }
     for (uint32_t i = lane; i < 64u * kk; i += 64) {
         lkey[i] = __builtin_inff();
@@ -121,14 +132,34 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
         if constexpr (METRIC != M_IP) xnv = a.xnorm2[rr];
     };
     if constexpr (KS > 0) {
+        const _Float16* qh = static_cast<const _Float16*>(a.qh);
+        const uint32_t r0 = q0 + col, r1 = q0 + 32u + col;
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) {
-            afr0[s2] = *reinterpret_cast<const half8_t*>(A + col * astride + (16u * s2 + 8u * half) * 2u);
-            afr1[s2] = *reinterpret_cast<const half8_t*>(A + (32u + col) * astride + (16u * s2 + 8u * half) * 2u);
+            half8_t z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = static_cast<_Float16>(0.0f);
+            afr0[s2] = r0 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r0) * dpad + 16 * s2 + 8u * half) : z;
+            afr1[s2] = r1 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r1) * dpad + 16 * s2 + 8u * half) : z;
         }
         if (x_lo < x_hi) load_tile(x_lo, bcur, xn_cur);
     }
-    for (uint32_t x0 = x_lo; x0 < x_hi; x0 += 32) {
+    uint32_t tile_no = 0;
+    for (uint32_t x0 = x_lo; x0 < x_hi; x0 += 32, ++tile_no) {
+        if (a.gtau != nullptr && (tile_no & 7u) == 0u) {
+            // every slice of the same query block publishes its kk-th best key; the minimum over slices is a valid
+            // pruning threshold for all of them (that slice alone holds kk better candidates)
+            if (q0 + lane < a.nq) {
+                const float g = dec_key(a.gtau[q0 + lane]);
+                if (g < tau[lane]) tau[lane] = g;
+            }
+            lds_order();
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tl[qt][r] = tau[static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * half];
+            }
+        }
         const uint32_t row = x0 + col;
         const bool valid = row < x_hi;
         float16v_t acc0, acc1;
@@ -186,7 +217,7 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t qi = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * half; // C/D row map
-                unsigned long long m = __ballot(key[qt][r] < tau[qi]);
+                unsigned long long m = __ballot(key[qt][r] < tl[qt][r]); // register-cached threshold: no LDS on this path
                 while (m != 0ull) {
                     const int bl = __builtin_ctzll(m);
                     m &= m - 1ull;
@@ -209,7 +240,10 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
                         lds_order();
                         if (lane < kk && lane >= pos) { kl[lane] = nk; il[lane] = ni; }
                         const float nt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nk), static_cast<int>(kk - 1u)));
-                        if (lane == 0) tau[bq] = nt;
+                        if (lane == 0) {
+                            if (nt < tau[bq]) tau[bq] = nt;
+                            if (a.gtau != nullptr && q0 + bq < a.nq) atomicMin(a.gtau + q0 + bq, enc_key(nt));
+                        }
                         lds_order();
                         continue;
                     }
@@ -235,7 +269,11 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
                         il[pos] = id;
                     }
                     lds_order();
-                    if (lane == 0) tau[bq] = kl[kk - 1];
+                    if (lane == 0) {
+                        const float nt = kl[kk - 1];
+                        if (nt < tau[bq]) tau[bq] = nt;
+                        if (a.gtau != nullptr && q0 + bq < a.nq) atomicMin(a.gtau + q0 + bq, enc_key(nt));
+                    }
                     lds_order();
                 }
             }
@@ -259,7 +297,9 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
 }
 
 hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
-    const size_t lds = 64u * (static_cast<size_t>(a.dpad) * 2 + 16) + 64u * static_cast<size_t>(a.kk) * 8 + 256;
+    const uint32_t ks0 = a.dpad >> 4;
+    const bool static_ks = ks0 == 4 || ks0 == 6 || ks0 == 8;
+    const size_t lds = (static_ks ? 0 : 64u * (static_cast<size_t>(a.dpad) * 2 + 16)) + 64u * static_cast<size_t>(a.kk) * 8 + 256;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((a.nq + 63) / 64, a.n_slices);
     auto go = [&](auto kern) {

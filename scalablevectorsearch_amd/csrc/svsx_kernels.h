@@ -85,6 +85,7 @@ struct FlatArgs {
     uint32_t n, dpad;
     const void* qh;         // nq x dpad f16
     uint32_t nq, kk, n_slices;
+    uint32_t* gtau;         // nq order-encoded thresholds shared by the slices of a query block (init 0xFF800000 = +inf), or NULL
     float* out_keys;        // [n_slices][nq][kk]
     uint64_t* out_ids;      // [n_slices][nq][kk]
 };

@@ -68,6 +68,8 @@ def main():
         s = 127.0 / float(xf.abs().max())
         x = torch.clamp(torch.round(xf * s), -128, 127).to(torch.int8); q = torch.clamp(torch.round(qf * s), -128, 127).to(torch.int8); np_dt = np.int8
         xf, qf = x.float(), q.float()
+    if a.d % 16:  # device layout: rows zero padded to a multiple of 16 elements (include/svsx.h)
+        x = torch.nn.functional.pad(x, (0, 16 - a.d % 16)).contiguous()
     alpha = 1.2 if a.metric == "l2" else 0.95
     t0 = time.time()
     graph, entry = build_vamana_device(x, a.n, a.d, fn, VamanaBuildParameters(alpha=alpha, graph_max_degree=a.degree, window_size=2 * a.degree, prune_to=a.degree - 4),
@@ -95,7 +97,7 @@ def main():
     if a.cpu:
         from oracle.oracle import COS, IP, L2, Oracle, Ref
         m = {"l2": L2, "ip": IP, "cos": COS}[a.metric]
-        xh, qh, gh = x.cpu().numpy(), q.cpu().numpy(), device_graph_to_svs(graph, a.degree)
+        xh, qh, gh = np.ascontiguousarray(x[:, :a.d].cpu().numpy()), q.cpu().numpy(), device_graph_to_svs(graph, a.degree)
         ns = min(a.nq, 2000); th = host_cores()
         if sq is None and Ref.available():
             r = Ref(); run = lambda: r.search(m, xh, gh, np.array([entry], np.uint32), qh[:ns], k, a.window, nthreads=th)[0]; kind = f"reference x{th}"
