@@ -152,7 +152,7 @@ def main():
 
     ids = torch.empty((nq, k), dtype=torch.int64, device=device)  # written as uint64
     dists = torch.empty((nq, k), dtype=torch.float32, device=device)
-    stats = torch.zeros((nq, 4), dtype=torch.int32, device=device)
+    stats = torch.zeros((nq, 6), dtype=torch.int32, device=device)
     if multi:
         all_d = torch.empty((world, nq, k), dtype=torch.float32, device=device)
         all_i = torch.empty((world, nq, k), dtype=torch.int64, device=device)
@@ -265,6 +265,7 @@ def main():
             "build_seconds": t_build,
             "visited_filter": args.visited,
             "distance_evals_per_query": int(st[:, 2].sum()) / nq,
+            "partial_distance_rejects_per_query": int(st[:, 4].sum()) / nq,
         },
         "roofline": {
             "bound": "hbm",
@@ -274,6 +275,10 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_src,
+            "traffic_rate": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+            "note": "achieved = ALGORITHMIC bytes (reference traversal: visited set off, whole rows; SURVEY 8d) / kernel time; "
+                    "the kernel skips result-neutral work (visited filter, partial-distance rejection), so measured traffic "
+                    "is below the algorithmic bytes and frac can exceed 1; traffic_rate = measured fabric bytes / kernel time",
             "kernel": "svsx::search_kernel<f32,L2,float,96>",
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": alg_bytes,

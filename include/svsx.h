@@ -99,8 +99,9 @@ typedef struct {
 } svsx_search_params;
 
 /* Optional side outputs of a search (device pointers for svsx_search_device, host for svsx_search).
- *   stats        nq x 4 u32: {expansions, neighbour slots, distance evaluations, accepted inserts}
- *                = the GreedySearchTracker counts of greedy_search.h:165 / search_tracker.h:29-62
+ *   stats        nq x 6 u32: {expansions, neighbour slots, distance evaluations started, accepted inserts,
+ *                candidates rejected after a partial (lower-bound) distance, reserved}; the first two are
+ *                the GreedySearchTracker counts of greedy_search.h:165 / search_tracker.h:29-62
  *   history_*    per query, the expanded nodes in order (id, distance) -- the builder's
  *                use_full_search_history pool (vamana_build.h:54-91); history_len may exceed history_cap. */
 typedef struct {

@@ -163,7 +163,7 @@ class Oracle:
         nq = queries.shape[0]
         ids = np.empty((nq, k), np.uint32)
         dists = np.empty((nq, k), np.float32)
-        st = np.zeros((nq, 8), np.uint64)
+        st = np.zeros((nq, 9), np.uint64)
         rc = self.lib.svso_search_batch(C.byref(ix), _ptr(queries), dtype_code(queries), nq, k, window, capacity, int(visited_set), _ptr(ids), _ptr(dists), _ptr(st))
         if rc:
             raise ValueError(f"svso_search_batch failed rc={rc}")

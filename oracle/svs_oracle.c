@@ -522,6 +522,14 @@ int svso_greedy_search(
             }
             if (buf->filter && svso_filter_emplace(buf->filter, id)) continue; /* :191-193 */
             float dd = index_distance(ix, &fq, id, scratch);
+            if (stats && ix->metric == SVSO_L2 && ix->data_dtype == SVSO_F32 && q_dtype == SVSO_F32 && !ix->sq_enabled && ix->d > 64 &&
+                buf->size == buf->capacity) { /* analysis: would a first-64-dims partial distance already exceed the worst? */
+                const float* qv = (const float*)query;
+                const float* xv = (const float*)ix->data + (size_t)id * ix->d;
+                float part = 0.0f;
+                for (size_t t = 0; t < 64; ++t) { float c = qv[t] - xv[t]; part += c * c; }
+                if (part > buf->e[buf->size - 1].dist * 1.00004f) local.partial_rejects++;
+            }
             local.distance_evals++;
             svso_buffer_insert(buf, id, dd);
         }

@@ -99,6 +99,7 @@ typedef struct {
     uint64_t distance_evals;    /* distances actually computed            */
     uint64_t in_buffer;         /* neighbour slots whose id was already in the buffer (analysis only) */
     uint64_t small_filter_hits[4]; /* hits of simulated 512/1024/2048/4096-entry exact-tag filters (analysis only) */
+    uint64_t partial_rejects;   /* f32 L2, d > 64: first-64-dims partial distance already above the worst (analysis only) */
 } svso_stats;
 
 /* index/vamana/greedy_search.h:124-203 on one query; leaves the result in `buf`. */

@@ -376,7 +376,7 @@ int svsx_search(
     daux.query_row_stride_bytes = q_stride;
     if (aux) {
         daux.history_cap = aux->history_cap;
-        if (aux->stats) { HIP_TRY(dst.alloc(nq * 16, cs.s)); daux.stats = static_cast<uint32_t*>(dst.p); }
+        if (aux->stats) { HIP_TRY(dst.alloc(nq * 24, cs.s)); daux.stats = static_cast<uint32_t*>(dst.p); }
         if (aux->history_ids && aux->history_cap) { HIP_TRY(dhi.alloc(nq * aux->history_cap * 4, cs.s)); daux.history_ids = static_cast<uint32_t*>(dhi.p); }
         if (aux->history_dists && aux->history_cap) { HIP_TRY(dhd.alloc(nq * aux->history_cap * 4, cs.s)); daux.history_dists = static_cast<float*>(dhd.p); }
         if (aux->history_len) { HIP_TRY(dhl.alloc(nq * 4, cs.s)); daux.history_len = static_cast<uint32_t*>(dhl.p); }
@@ -387,7 +387,7 @@ int svsx_search(
     if (ids32) HIP_TRY(hipMemcpyAsync(ids32, d32.p, nq * k * 4, hipMemcpyDeviceToHost, cs.s));
     if (dists) HIP_TRY(hipMemcpyAsync(dists, dd.p, nq * k * 4, hipMemcpyDeviceToHost, cs.s));
     if (aux) {
-        if (aux->stats) HIP_TRY(hipMemcpyAsync(aux->stats, dst.p, nq * 16, hipMemcpyDeviceToHost, cs.s));
+        if (aux->stats) HIP_TRY(hipMemcpyAsync(aux->stats, dst.p, nq * 24, hipMemcpyDeviceToHost, cs.s));
         if (daux.history_ids) HIP_TRY(hipMemcpyAsync(aux->history_ids, dhi.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost, cs.s));
         if (daux.history_dists) HIP_TRY(hipMemcpyAsync(aux->history_dists, dhd.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost, cs.s));
         if (aux->history_len) HIP_TRY(hipMemcpyAsync(aux->history_len, dhl.p, nq * 4, hipMemcpyDeviceToHost, cs.s));

@@ -242,6 +242,86 @@ __device__ __forceinline__ void float_row_distance(
     else out_nrm = 0.0f;
 }
 
+// Two-phase squared-L2 for the slot-cyclic mapping with a compile-time dimension DS in (64, 128]: after the first
+// 64-element block (two cache lines of an f32 row) the partial sum  reduce((s0+s1)+(s2+s3))  is a lower bound of the
+// full distance (every later term is a square).  If it already exceeds `thr` = worst * (1 + 4e-5) the candidate cannot
+// enter the full buffer -- SearchBuffer::can_skip (search_buffer.h:338-340) would drop it -- and the rest of the row is
+// never fetched.  The margin covers the rounding of both summations (each is a sum of <= 128 non-negative terms:
+// relative error <= 128 * 2^-24 = 7.6e-6), so a candidate the reference would insert is never rejected; survivors
+// continue with exactly the reference's operation order, so their distance bits are unchanged.
+template <int DT, int DS>
+__device__ __forceinline__ float l2_row_distance_two_phase(
+    const unsigned char* __restrict__ row, bool active, const float* __restrict__ qf, int sub, float thr, bool& rejected
+) {
+    static_assert(DS > 64 && DS <= 128 && (DS & 15) == 0, "one leading 64-block plus full 16-blocks");
+    constexpr int E = Elem<DT>::E;
+    constexpr int CB = E * Elem<DT>::BYTES;
+    constexpr int NB64 = (DS >> 6) * 4, B1 = DS >> 4;
+    const unsigned char* lane_row = row + sub * CB;
+    const float* lane_q = qf + sub * E;
+    auto fetch = [&](int block, bool pred, float (&x)[E]) {
+        zero_chunk<E>(x);
+        if (pred) load_chunk<DT>(lane_row + block * (16 * Elem<DT>::BYTES), x);
+    };
+    auto fetch_q = [&](int block, float (&q)[E]) {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(lane_q + block * 16 + e);
+            q[e] = v.x; q[e + 1] = v.y; q[e + 2] = v.z; q[e + 3] = v.w;
+        }
+    };
+    float s[4][E];
+    float dummy = 0.0f;
+    {
+        float x[4][E];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetch(j, active, x[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float q[E];
+            fetch_q(j, q);
+            zero_chunk<E>(s[j]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc_step<M_L2>(s[j][e], dummy, q[e], x[j][e]);
+        }
+    }
+    float p[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) p[e] = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+    const float partial = reduce_slots<E>(p); // identical on all lanes of the group
+    rejected = partial > thr;
+    const bool need = active && !rejected;
+    if (__ballot(need) == 0ull) return __builtin_inff();
+    if constexpr (NB64 > 4) { // d = 128: the second 64-block continues the four accumulators before the combine
+        float x[4][E];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetch(4 + j, need, x[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float q[E];
+            fetch_q(4 + j, q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc_step<M_L2>(s[j][e], dummy, q[e], x[j][e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[0][e] = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+    if constexpr (B1 > NB64) {
+        float x[B1 - NB64][E];
+#pragma unroll
+        for (int i = NB64; i < B1; ++i) fetch(i, need, x[i - NB64]);
+#pragma unroll
+        for (int i = NB64; i < B1; ++i) {
+            float q[E];
+            fetch_q(i, q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc_step<M_L2>(s[0][e], dummy, q[e], x[i - NB64][e]);
+        }
+    }
+    const float full = reduce_slots<E>(s[0]);
+    return need ? full : __builtin_inff();
+}
+
 // Block-cyclic float-path distance (alternative lane mapping; same arithmetic, operation for operation, as
 // float_row_distance).  Four adjacent lanes own one row; lane j owns the WHOLE accumulator vector s_j (all 16
 // lane-slots) and streams the 16-element blocks 4t+j, so every access is whole aligned dwordx4 loads (int8: 1, f16: 2,

@@ -68,12 +68,22 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     const int sub = static_cast<int>(lane) & (G - 1);
     const uint32_t grp = lane / G;
 
-    // distance of the candidate whose id each lane-group holds; every lane of the wave participates
-    auto group_distance = [&](uint32_t cid, bool active) -> float {
+    // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
+    // candidate out (l2_row_distance_two_phase); result-neutral, removes the third line of most rows at d = 96
+    constexpr bool TWO_PHASE = QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && DS > 64 && DS <= 128;
+    uint32_t n_early = 0;
+    // distance of the candidate whose id each lane-group holds; every lane of the wave participates.
+    // `thr`: +inf while the buffer is not full, else worst * (1 + 4e-5).
+    auto group_distance = [&](uint32_t cid, bool active, float thr) -> float {
         const unsigned char* row = data + static_cast<size_t>(active ? cid : 0u) * a.row_bytes;
         float fmain = 0.0f, fnrm = 0.0f;
         int ab = 0, bb = 0;
-        if constexpr (INTPATH) {
+        if constexpr (TWO_PHASE) {
+            bool rejected = false;
+            const float dd = l2_row_distance_two_phase<DT, (DS > 64 && DS <= 128) ? DS : 96>(row, active, qf, sub, thr, rejected);
+            n_early += __popcll(__ballot(active && rejected && sub == 0));
+            return dd;
+        } else if constexpr (INTPATH) {
             int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
         } else if constexpr (B8) {
             float_row_distance_bc<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
             const uint32_t ci = base + grp;
             const bool act = ci < a.n_entry;
             const uint32_t cid = act ? a.entry[ci] : 0u;
-            const float dist = group_distance(cid, act);
+            const float dist = group_distance(cid, act, __builtin_inff());
             unsigned long long m = __ballot(act && sub == 0);
             while (m != 0ull) {
                 const int bl = __builtin_ctzll(m);
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 const uint32_t ci = p0 + grp;
                 const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
                 const bool act = ci < cnt;
-                const float dist = group_distance(cid, act);
+                const float dist = group_distance(cid, act, full ? worst * 1.00004f : __builtin_inff());
                 const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
                 unsigned long long m = __ballot(act && sub == 0 && !skip);
                 n_eval += (cnt - p0) < static_cast<uint32_t>(RPP) ? (cnt - p0) : static_cast<uint32_t>(RPP);
@@ -208,11 +218,13 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     }
     if (lane == 0) {
         if (a.stats != nullptr) {
-            uint32_t* st = a.stats + static_cast<size_t>(qi) * 4;
+            uint32_t* st = a.stats + static_cast<size_t>(qi) * 6;
             st[0] = n_exp;
             st[1] = n_slots;
             st[2] = n_eval;
             st[3] = n_ins;
+            st[4] = n_early;
+            st[5] = 0;
         }
         if (a.history_len != nullptr) a.history_len[qi] = n_exp;
     }
@@ -241,7 +253,7 @@ template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const Sear
         if (a.d == 96) return launch_one<DT, METRIC, QMODE, 96>(a, stream);
         if (a.d == 128) return launch_one<DT, METRIC, QMODE, 128>(a, stream);
     }
-    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && DT == DT_I8) {
+    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && (DT == DT_I8 || DT == DT_U8)) {
         if (a.d == 768) return launch_one<DT, METRIC, QMODE, 768>(a, stream);
     }
     return launch_one<DT, METRIC, QMODE, 0>(a, stream);

@@ -193,7 +193,7 @@ class VamanaIndex:
         aux = _lib.SearchAux()
         st = None
         if stats:
-            st = np.zeros((nq, 4), np.uint32)
+            st = np.zeros((nq, 6), np.uint32)
             aux.stats = st.ctypes.data
         _lib.check(_lib.lib().svsx_search(self._h, queries.ctypes.data, dtype_code(queries), nq, num_neighbors, C.byref(sp),
                                           ids.ctypes.data, None, dists.ctypes.data, C.byref(aux)))

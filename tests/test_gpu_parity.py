@@ -463,3 +463,16 @@ def test_concurrent_host_callers(svs, oracle, small_world):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_partial_distance_rejection_matches_analysis(svs, oracle, small_world):
+    """f32 L2, 64 < d <= 128: the kernel stops after the first 64 dimensions when the partial sum already exceeds the
+    worst buffer entry (result-neutral; parity is covered by every f32-L2 test above).  The number of such rejections
+    must stay below the oracle's count of candidates whose 64-dim partial exceeds the worst (the kernel's threshold is
+    per pass, hence slightly staler) and be substantial."""
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    res, st = idx.search(sw["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(48)), stats=True)
+    _, _, so = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 48, stats=True)
+    assert (st[:, 2] == so[:, 2]).all()  # both count the entry-point evaluation
+    assert st[:, 4].sum() <= so[:, 8].sum() and st[:, 4].sum() > 0.5 * so[:, 8].sum()

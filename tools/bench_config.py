@@ -78,7 +78,7 @@ def main():
     idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), a.n, a.d, np_dt, sq=sq)
     k = 10
     ids = torch.empty((a.nq, k), dtype=torch.int64, device=dev); dists = torch.empty((a.nq, k), device=dev)
-    stats = torch.zeros((a.nq, 4), dtype=torch.int32, device=dev)
+    stats = torch.zeros((a.nq, 6), dtype=torch.int32, device=dev)
     sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(a.window))
     idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists, d_stats=stats); torch.cuda.synchronize()
     gt = exact_topk(xf if sq is None else xf, qf, k, a.metric)
