@@ -123,11 +123,15 @@ template <int E> __device__ __forceinline__ float reduce_slots(float (&v)[E]) {
 // All 64 lanes execute this in lock-step; `active` only predicates the global loads.
 //   DS > 0: compile-time dimension (fully unrolled, all row loads issued up front); DS == 0: runtime d.
 //   DECOMP: apply the SQ decompression scale*float(v)+bias to every loaded element (scalar.h:44-46,175-184).
-template <int DT, int METRIC, int DS, bool DECOMP>
+// PRUNE (squared L2, runtime dimension only): after every 64-element block the partial sum is a lower bound of the
+// distance; groups whose bound already exceeds `thr` (= worst * (1 + 4e-5), see l2_row_distance_two_phase) stop
+// fetching, and the loop ends once every group of the wave has stopped.  out_main = +inf for a rejected group.
+template <int DT, int METRIC, int DS, bool DECOMP, bool PRUNE = false>
 __device__ __forceinline__ void float_row_distance(
     const unsigned char* __restrict__ row, bool active, const float* __restrict__ qf, int d_runtime, int sub,
-    float sq_scale, float sq_bias, float& out_main, float& out_nrm
+    float sq_scale, float sq_bias, float& out_main, float& out_nrm, float thr = 0.0f, bool* rejected_out = nullptr
 ) {
+    static_assert(!PRUNE || (METRIC == M_L2 && DS == 0 && !DECOMP), "partial-distance rejection: runtime-d squared L2 only");
     constexpr int E = Elem<DT>::E;
     constexpr int CB = E * Elem<DT>::BYTES; // bytes per chunk
     const int d = DS > 0 ? DS : d_runtime;
@@ -142,6 +146,7 @@ __device__ __forceinline__ void float_row_distance(
         zero_chunk<E>(s[j]);
         zero_chunk<E>(n[j]);
     }
+    bool rejected = false;
 
     auto fetch = [&](int block, float (&x)[E]) {
         zero_chunk<E>(x);
@@ -189,6 +194,19 @@ __device__ __forceinline__ void float_row_distance(
                     fetch_q(4 * t + j, q);
 #pragma unroll
                     for (int e = 0; e < E; ++e) acc_step<METRIC>(s[j][e], n[j][e], q[e], x[j][e]);
+                }
+                if constexpr (PRUNE) {
+                    if (16 * (4 * t + 4) < d) { // something is left to skip
+                        float p[E];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) p[e] = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+                        const float partial = reduce_slots<E>(p);
+                        if (partial > thr) {
+                            rejected = true;
+                            active = false; // no further loads for this group
+                        }
+                        if (__ballot(active) == 0ull) break;
+                    }
                 }
             }
             b = 4 * n64;
@@ -240,14 +258,19 @@ __device__ __forceinline__ void float_row_distance(
     out_main = reduce_slots<E>(s[0]);
     if constexpr (METRIC == M_COS) out_nrm = reduce_slots<E>(n[0]);
     else out_nrm = 0.0f;
+    if constexpr (PRUNE) {
+        if (rejected) out_main = __builtin_inff();
+        if (rejected_out != nullptr) *rejected_out = rejected;
+    }
 }
 
 // Two-phase squared-L2 for the slot-cyclic mapping with a compile-time dimension DS in (64, 128]: after the first
 // 64-element block (two cache lines of an f32 row) the partial sum  reduce((s0+s1)+(s2+s3))  is a lower bound of the
 // full distance (every later term is a square).  If it already exceeds `thr` = worst * (1 + 4e-5) the candidate cannot
 // enter the full buffer -- SearchBuffer::can_skip (search_buffer.h:338-340) would drop it -- and the rest of the row is
-// never fetched.  The margin covers the rounding of both summations (each is a sum of <= 128 non-negative terms:
-// relative error <= 128 * 2^-24 = 7.6e-6), so a candidate the reference would insert is never rejected; survivors
+// never fetched.  The margin covers the rounding of both summations: sums of non-negative terms through per-slot fma
+// chains of d/64 links plus a 7-level tree have relative error <= (d/64 + 8) * 2^-24 (1.2e-6 at d = 768), so a
+// candidate the reference would insert is never rejected; survivors
 // continue with exactly the reference's operation order, so their distance bits are unchanged.
 template <int DT, int DS>
 __device__ __forceinline__ float l2_row_distance_two_phase(

@@ -83,6 +83,12 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
             const float dd = l2_row_distance_two_phase<DT, (DS > 64 && DS <= 128) ? DS : 96>(row, active, qf, sub, thr, rejected);
             n_early += __popcll(__ballot(active && rejected && sub == 0));
             return dd;
+        } else if constexpr (QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && DS == 0) {
+            // runtime dimension: progressive partial-distance rejection after every 64-element block
+            bool rejected = false;
+            float_row_distance<DT, METRIC, 0, false, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm, thr, &rejected);
+            n_early += __popcll(__ballot(active && rejected && sub == 0));
+            return fmain;
         } else if constexpr (INTPATH) {
             int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
         } else if constexpr (B8) {
