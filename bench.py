@@ -236,6 +236,20 @@ def main():
             dist.destroy_process_group()
         return
 
+    # practical roof: device-to-device copy bandwidth on this box (read + write bytes / time)
+    cp_src = torch.empty(1 << 29, dtype=torch.float32, device=device)  # 2 GiB
+    cp_dst = torch.empty_like(cp_src)
+    cp_dst.copy_(cp_src)
+    torch.cuda.synchronize()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(5):
+        cp_dst.copy_(cp_src)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * cp_src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del cp_src, cp_dst
+
     ms_per_step = 1e3 * elapsed / args.steps
     shard_queries_per_s = world * nq * args.steps / elapsed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -276,6 +290,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_src,
             "traffic_rate": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+            "measured_copy_GBs": copy_gbs,
             "note": "achieved = ALGORITHMIC bytes (reference traversal: visited set off, whole rows; SURVEY 8d) / kernel time; "
                     "the kernel skips result-neutral work (visited filter, partial-distance rejection), so measured traffic "
                     "is below the algorithmic bytes and frac can exceed 1; traffic_rate = measured fabric bytes / kernel time",
@@ -392,10 +407,19 @@ def cpu_baseline(x, q, graph, entry, R, k, window, gpu_ids):
         if time.perf_counter() - t_all > 20:
             break
     same = bool((gpu_ids[:ns].cpu().numpy().astype(np.uint64) == ids_cpu.astype(np.uint64)).all())
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": ns / best,
         "unit": "queries/s",
         "cores": threads,
+        "host": {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": ncores},
         "kind": kind,
         "sample": f"first {ns} of the {len(qh)} queries, same graph/data/window, best of <=3 runs; GPU ids identical on sample: {same}",
     }

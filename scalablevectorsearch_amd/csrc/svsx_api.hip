@@ -10,7 +10,6 @@
 
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -469,7 +468,6 @@ int svsx_flat_search_device(
     if (waves_per_cu > 8) waves_per_cu = 8;
     if (waves_per_cu < 1) waves_per_cu = 1;
     size_t target_waves = 256 * waves_per_cu * 4 / 5;
-    if (const char* ev = getenv("SVSX_FLAT_TARGET_WAVES")) target_waves = static_cast<size_t>(atoi(ev)) > 0 ? static_cast<size_t>(atoi(ev)) : target_waves;
     size_t slices = (target_waves + nqb - 1) / nqb; // thresholds are shared across the slices of a query block
     if (slices > 64) slices = 64;
     const size_t max_slices = (ix->n + 255) / 256;

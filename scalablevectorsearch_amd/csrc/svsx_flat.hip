@@ -216,7 +216,6 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
         for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t qi = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * half; // C/D row map
                 unsigned long long m = __ballot(key[qt][r] < tl[qt][r]); // register-cached threshold: no LDS on this path
                 while (m != 0ull) {
                     const int bl = __builtin_ctzll(m);
