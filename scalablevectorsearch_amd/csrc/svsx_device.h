@@ -403,11 +403,20 @@ __device__ __forceinline__ void float_row_distance_bc(
     };
     auto accumulate = [&](int c, const BlockRaw<DT>& raw, int nvalid) {
         float x[16];
-        block_to_float<DT>(raw, x);
+        if constexpr (DT != DT_I8 && DT != DT_U8) block_to_float<DT>(raw, x);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 qv = *reinterpret_cast<const float4*>(qf + 16 * c + 4 * g4);
             const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            if constexpr (DT == DT_I8 || DT == DT_U8) { // widen one 4-byte word at a time: short live ranges
+                const uint32_t w = g4 == 0 ? raw.v[0].x : g4 == 1 ? raw.v[0].y : g4 == 2 ? raw.v[0].z : raw.v[0].w;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t byte = (w >> (8 * b)) & 0xFFu;
+                    if constexpr (DT == DT_I8) x[4 * g4 + b] = static_cast<float>(static_cast<int>(static_cast<int8_t>(byte)));
+                    else x[4 * g4 + b] = static_cast<float>(byte);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int e = 4 * g4 + b;
@@ -428,7 +437,14 @@ __device__ __forceinline__ void float_row_distance_bc(
     if (n64 > 0) {
         if constexpr (DS > 0) {
             constexpr int N64 = DS >> 6;
-            constexpr int MAXCH = ((METRIC == M_COS ? 4 : 8) / (BB / 16)) > 0 ? (METRIC == M_COS ? 4 : 8) / (BB / 16) : 1; // dwordx4 loads in flight
+#ifndef SVSX_BC_CH_COS
+#define SVSX_BC_CH_COS 4
+#endif
+#ifndef SVSX_BC_CH_OTHER
+#define SVSX_BC_CH_OTHER 4
+#endif
+            constexpr int MAXQ = METRIC == M_COS ? SVSX_BC_CH_COS : SVSX_BC_CH_OTHER; // dwordx4 loads in flight per lane
+            constexpr int MAXCH = (MAXQ / (BB / 16)) > 0 ? MAXQ / (BB / 16) : 1;
             constexpr int CH = N64 < MAXCH ? (N64 > 0 ? N64 : 1) : MAXCH;
 #pragma unroll 1
             for (int t0 = 0; t0 < N64; t0 += CH) { // rolled: CH blocks in flight per lane, registers bounded
