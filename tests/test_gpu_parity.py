@@ -476,3 +476,31 @@ def test_partial_distance_rejection_matches_analysis(svs, oracle, small_world):
     _, _, so = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 48, stats=True)
     assert (st[:, 2] == so[:, 2]).all()  # both count the entry-point evaluation
     assert st[:, 4].sum() <= so[:, 8].sum() and st[:, 4].sum() > 0.5 * so[:, 8].sum()
+
+
+def test_search_index_cli_round_trip(svs, oracle, small_world, tmp_path):
+    """utils/search_index.cpp:54-178: positional CLI over files written in the reference's formats (native v1 blobs,
+    svs_config.toml entry point, fvecs queries) -> <prefix>_idx.ivecs with the oracle's ids."""
+    import subprocess
+    import sys
+
+    from scalablevectorsearch_amd import io
+
+    sw = small_world
+    os.makedirs(tmp_path / "data"); os.makedirs(tmp_path / "graph"); os.makedirs(tmp_path / "config")
+    io.write_svs_native(tmp_path / "data" / "data_0.svs", sw["x"])
+    io.write_svs_native(tmp_path / "graph" / "graph_0.svs", sw["graph"])
+    io.write_fvecs(tmp_path / "q.fvecs", sw["q"])
+    (tmp_path / "config" / "svs_config.toml").write_text(
+        '__version__ = "v0.0.3"\n[object]\n__schema__ = "vamana_index_parameters"\nentry_point = %d\nname = "vamana config parameters"\n' % int(sw["entry"][0]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "scalablevectorsearch_amd.search_index", "float", "float", str(tmp_path / "q.fvecs"), "32", "10", "4",
+                          str(tmp_path / "config"), str(tmp_path / "graph"), str(tmp_path / "data"), str(tmp_path / "res"), "L2"],
+                         cwd=root, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Global search time" in out.stdout
+    got = io.read_ivecs(str(tmp_path / "res_idx.ivecs"))
+    ids, _ = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 32)
+    assert (got == ids).all()
+    bad = subprocess.run([sys.executable, "-m", "scalablevectorsearch_amd.search_index", "float"], cwd=root, capture_output=True, text=True)
+    assert bad.returncode == 1 and "Expected 11 arguments" in bad.stdout
