@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000); ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--dtype", default="f16", choices=["f32", "f16", "sq8", "i8"]); ap.add_argument("--metric", default="ip", choices=["l2", "ip", "cos"])
     ap.add_argument("--nq", type=int, default=10_000); ap.add_argument("--window", type=int, default=128); ap.add_argument("--degree", type=int, default=64)
-    ap.add_argument("--latent", type=int, default=32); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--cpu", type=int, default=1)
+    ap.add_argument("--latent", type=int, default=32); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--cpu", type=int, default=1); ap.add_argument("--visited", type=int, default=1)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     fn = {"l2": svs.DistanceL2(), "ip": svs.DistanceIP(), "cos": svs.DistanceCosineSimilarity()}[a.metric]
@@ -79,7 +79,7 @@ def main():
     k = 10
     ids = torch.empty((a.nq, k), dtype=torch.int64, device=dev); dists = torch.empty((a.nq, k), device=dev)
     stats = torch.zeros((a.nq, 6), dtype=torch.int32, device=dev)
-    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(a.window))
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(a.window), search_buffer_visited_set=a.visited)
     idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists, d_stats=stats); torch.cuda.synchronize()
     gt = exact_topk(xf if sq is None else xf, qf, k, a.metric)
     rec = recall_at(gt, ids, k)
