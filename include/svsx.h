@@ -123,7 +123,8 @@ void svsx_index_destroy(svsx_index* index);
 /* Batch search, host pointers, synchronous.
  *   VamanaIndex::search(QueryResultView<I>, queries, VamanaSearchParameters, cancel)  index/vamana/index.h:564-611
  *   runtime VamanaIndex::search(n, x, k, distances, labels, params, filter)           runtime/vamana_index.h:75-83
- * ids64 (size_t labels as in QueryResult<size_t>, core/query_result.h:53-172) and/or ids32 may be NULL.
+ * ids64 (size_t labels as in QueryResult<size_t>, core/query_result.h:53-172) and/or ids32 (low 32 bits of
+ * id + id_offset) may be NULL.
  * Rows with fewer than k results are padded with id = all-ones, dist = +inf (vamana_index_impl.h:205-209).
  * If capacity < k both window and capacity are raised to k (index.h:590-592).
  * Errors: k == 0, window > capacity (search_buffer.h:84-93), unsupported (query, data) type pair

@@ -186,10 +186,15 @@ int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
             return cleanup(fail(SVSX_RUNTIME_ERROR, "copying graph to the device failed"));
         if (hipMalloc(reinterpret_cast<void**>(&ix->d_graph), desc->n * ix->gstride * sizeof(uint32_t)) != hipSuccess)
             return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMalloc for graph failed"));
+        DeviceBuffer bad;
+        if (bad.alloc(8) != hipSuccess || hipMemset(bad.p, 0, 8) != hipSuccess) return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMalloc failed"));
         if (launch_pack_graph(static_cast<const uint32_t*>(tmp.p), static_cast<uint32_t>(desc->graph_row_stride_u32), static_cast<uint32_t>(desc->n),
-                              ix->d_graph, static_cast<uint32_t>(ix->gstride), nullptr) != hipSuccess)
+                              ix->d_graph, static_cast<uint32_t>(ix->gstride), static_cast<uint32_t*>(bad.p), nullptr) != hipSuccess)
             return cleanup(fail(SVSX_RUNTIME_ERROR, "graph re-layout kernel failed: %s", hipGetErrorString(hipGetLastError())));
-        if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(SVSX_RUNTIME_ERROR, "graph re-layout kernel failed"));
+        uint32_t hbad[2] = {0, 0};
+        if (hipMemcpy(hbad, bad.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return cleanup(fail(SVSX_RUNTIME_ERROR, "graph re-layout kernel failed"));
+        if (hbad[0] || hbad[1])
+            return cleanup(fail(SVSX_INVALID_ARGUMENT, "malformed graph: %u rows with a degree larger than the row, %u neighbour ids >= n", hbad[0], hbad[1]));
     }
     if (hipMalloc(reinterpret_cast<void**>(&ix->d_entry), desc->n_entry * sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(SVSX_RUNTIME_ERROR, "hipMalloc for entry points failed"));

@@ -118,18 +118,26 @@ hipError_t launch_merge(int metric, const MergeArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void pack_graph_kernel(const uint32_t* __restrict__ in, uint32_t in_stride, uint32_t n, uint32_t* __restrict__ out, uint32_t out_stride) {
+// bad[0] counts rows whose degree exceeds the row, bad[1] counts neighbour ids >= n (both make the graph unusable)
+__global__ void pack_graph_kernel(const uint32_t* __restrict__ in, uint32_t in_stride, uint32_t n, uint32_t* __restrict__ out, uint32_t out_stride,
+                                  uint32_t* __restrict__ bad) {
     const uint32_t row = blockIdx.x;
     if (row >= n) return;
     const uint32_t* r = in + static_cast<size_t>(row) * in_stride;
     const uint32_t deg = r[0];
+    if (threadIdx.x == 0 && (deg > in_stride - 1 || deg > out_stride)) atomicAdd(bad, 1u);
     for (uint32_t j = threadIdx.x; j < out_stride; j += blockDim.x) {
-        out[static_cast<size_t>(row) * out_stride + j] = (j < deg && j + 1 < in_stride) ? r[1 + j] : kInvalidId;
+        uint32_t id = (j < deg && j + 1 < in_stride) ? r[1 + j] : kInvalidId;
+        if (id != kInvalidId && id >= n) {
+            atomicAdd(bad + 1, 1u);
+            id = kInvalidId;
+        }
+        out[static_cast<size_t>(row) * out_stride + j] = id;
     }
 }
 
-hipError_t launch_pack_graph(const uint32_t* d_in, uint32_t in_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_graph_kernel, dim3(n), dim3(64), 0, stream, d_in, in_stride, n, d_out, out_stride);
+hipError_t launch_pack_graph(const uint32_t* d_in, uint32_t in_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, uint32_t* d_bad, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_graph_kernel, dim3(n), dim3(64), 0, stream, d_in, in_stride, n, d_out, out_stride, d_bad);
     return hipGetLastError();
 }
 

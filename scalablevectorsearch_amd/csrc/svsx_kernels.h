@@ -107,6 +107,7 @@ struct RerankArgs {
 hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
 
 // layout conversion kernels (index creation)
-hipError_t launch_pack_graph(const uint32_t* d_svs_graph, uint32_t svs_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, hipStream_t stream);
+hipError_t launch_pack_graph(const uint32_t* d_svs_graph, uint32_t svs_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, uint32_t* d_bad2,
+                             hipStream_t stream);
 
 } // namespace svsx

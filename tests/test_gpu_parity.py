@@ -504,3 +504,17 @@ def test_search_index_cli_round_trip(svs, oracle, small_world, tmp_path):
     assert (got == ids).all()
     bad = subprocess.run([sys.executable, "-m", "scalablevectorsearch_amd.search_index", "float"], cwd=root, capture_output=True, text=True)
     assert bad.returncode == 1 and "Expected 11 arguments" in bad.stdout
+
+
+def test_malformed_graph_is_rejected(svs):
+    x = np.zeros((4, 8), np.float32)
+    g = np.zeros((4, 3), np.uint32)
+    g[:, 0] = 1
+    g[:, 1] = (1, 2, 3, 9)  # id 9 >= n
+    with pytest.raises(svs.SvsxError) as e:
+        svs.VamanaIndex(g, x, svs.DistanceL2(), [0])
+    assert e.value.code == 2 and "malformed graph" in e.value.message
+    g[3, 1] = 0
+    g[2, 0] = 7  # degree larger than the row
+    with pytest.raises(svs.SvsxError):
+        svs.VamanaIndex(g, x, svs.DistanceL2(), [0])
