@@ -290,6 +290,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_src,
             "traffic_rate": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+            "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "measured_copy_GBs": copy_gbs,
             "note": "achieved = ALGORITHMIC bytes (reference traversal: visited set off, whole rows; SURVEY 8d) / kernel time; "
                     "the kernel skips result-neutral work (visited filter, partial-distance rejection), so measured traffic "
