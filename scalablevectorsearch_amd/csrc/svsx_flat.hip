@@ -222,7 +222,10 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
                     m &= m - 1ull;
                     const float kq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[qt][r]), bl));
                     const uint32_t bq = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * static_cast<uint32_t>(bl >> 5);
-                    if (!(kq < tau[bq])) continue;
+                    // current threshold of that cell: the register copy held by lane bl (kept up to date below)
+                    const float tq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl[qt][r]), bl));
+                    if (!(kq < tq)) continue;
+                    if (kk > 64u && !(kq < tau[bq])) continue; // the general path keeps its thresholds in LDS only
                     const uint32_t id = x0 + static_cast<uint32_t>(bl & 31);
                     float* kl = lkey + bq * kk;
                     uint32_t* il = lid + bq * kk;
@@ -239,6 +242,8 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
                         lds_order();
                         if (lane < kk && lane >= pos) { kl[lane] = nk; il[lane] = ni; }
                         const float nt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nk), static_cast<int>(kk - 1u)));
+                        // the lanes of that half-wave hold this cell's threshold in tl[qt][r]: update in place (no LDS refresh)
+                        if (half == static_cast<uint32_t>(bl >> 5) && nt < tl[qt][r]) tl[qt][r] = nt;
                         if (lane == 0) {
                             if (nt < tau[bq]) tau[bq] = nt;
                             if (a.gtau != nullptr && q0 + bq < a.nq) atomicMin(a.gtau + q0 + bq, enc_key(nt));
@@ -277,11 +282,12 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
                 }
             }
         }
-        // thresholds changed: refresh the register copies
+        if (kk > 64u) { // the general insert path only updates the LDS thresholds: refresh the register copies
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tl[qt][r] = tau[static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * half];
+                for (int r = 0; r < 16; ++r) tl[qt][r] = tau[static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) + 4u * half];
+            }
         }
     }
     // per-slice shortlists out: [slice][q][kk]
