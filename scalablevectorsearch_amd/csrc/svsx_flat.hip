@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
 
 hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
     const uint32_t ks0 = a.dpad >> 4;
-    const bool static_ks = ks0 == 4 || ks0 == 6 || ks0 == 8;
+    const bool static_ks = ks0 >= 1 && ks0 <= 8;
     const size_t lds = (static_ks ? 0 : 64u * (static_cast<size_t>(a.dpad) * 2 + 16)) + 64u * static_cast<size_t>(a.kk) * 8 + 256;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((a.nq + 63) / 64, a.n_slices);
@@ -317,6 +317,11 @@ hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
     if (ks == 6) return go(flat_mfma_kernel<M, 6>);                         \
     if (ks == 8) return go(flat_mfma_kernel<M, 8>);                         \
     if (ks == 4) return go(flat_mfma_kernel<M, 4>);                         \
+    if (ks == 7) return go(flat_mfma_kernel<M, 7>);                         \
+    if (ks == 5) return go(flat_mfma_kernel<M, 5>);                         \
+    if (ks == 3) return go(flat_mfma_kernel<M, 3>);                         \
+    if (ks == 2) return go(flat_mfma_kernel<M, 2>);                         \
+    if (ks == 1) return go(flat_mfma_kernel<M, 1>);                         \
     return go(flat_mfma_kernel<M, 0>);
     switch (metric) {
         case M_L2: SVSX_FLAT_CASE(M_L2)
