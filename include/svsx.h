@@ -174,6 +174,43 @@ int svsx_prune_device(
     size_t pool_size, size_t max_out, float alpha, int32_t* d_out, size_t out_stride, void* hip_stream
 );
 
+/* Batched BatchIterator: svs::index::vamana::BatchIterator (index/vamana/iterator.h:81-339), one independent iterator
+ * per query of the batch, advanced together by one kernel launch per next().  Each next() widens every live query's
+ * search window and capacity by its batch size, RESUMES the graph search from the buffer left by the previous call
+ * (RestartInitializer, iterator.h:36-63) and hands out the best buffer entries not handed out before
+ * (copy_from_scratch, :104-124).  This is what the reference's runtime builds filtered and range search on
+ * (bindings/cpp/src/vamana_index_impl.h:140-320).  Per-query state (search buffer, yielded ids) stays in HBM.
+ *   extra_search_buffer_capacity  SIZE_MAX = svs::ITERATOR_EXTRA_BUFFER_CAPACITY_DEFAULT (100)  (iterator.h:154-170)
+ * Not thread-safe: one caller at a time per iterator (as for the reference's object). */
+typedef struct svsx_batch_iterator svsx_batch_iterator;
+
+/* VamanaIndex::make_batch_iterator (index/vamana/index.h:936), one per row of `queries` (host pointer). */
+int svsx_iterator_create(
+    const svsx_index* index, const void* queries, int q_dtype, size_t nq, size_t extra_search_buffer_capacity,
+    svsx_batch_iterator** out
+);
+void svsx_iterator_destroy(svsx_batch_iterator* it);
+/* BatchIterator::update (iterator.h:177-190): new queries (same count and type), all state reset. */
+int svsx_iterator_update(svsx_batch_iterator* it, const void* queries);
+/* BatchIterator::restart_next_search (iterator.h:233) for every query. */
+int svsx_iterator_restart_next_search(svsx_batch_iterator* it);
+/* BatchIterator::next (iterator.h:249-317).  Outputs (host pointers): ids64/dists [nq][batch_size] (unused slots
+ * all-ones / +inf), counts [nq] = size() of each query's new batch.  batch_sizes (optional, host, nq entries <=
+ * batch_size): per-query batch size, 0xFFFFFFFF = leave that query untouched.  A query that is done() yields nothing
+ * and keeps its state (iterator.h:253-256). */
+int svsx_iterator_next(
+    svsx_batch_iterator* it, size_t batch_size, const uint32_t* batch_sizes, uint64_t* ids64, float* dists, uint32_t* counts
+);
+/* Same with device pointers, enqueued on hip_stream (state growth, if needed, synchronises the device first). */
+int svsx_iterator_next_device(
+    svsx_batch_iterator* it, size_t batch_size, const uint32_t* d_batch_sizes, uint64_t* d_ids64, float* d_dists,
+    uint32_t* d_counts, void* hip_stream
+);
+/* Per-query state, 8 u32 each (host pointer): [0] buffer size, [1] best_unvisited, [2] search window, [3] capacity
+ * (parameters_for_current_iteration, iterator.h:236-245), [4] ids yielded so far, [5] batch_number() (:227),
+ * [6] flags: 1 = next search restarts from the entry points, 2 = exhausted; done() (:230) = [4] == n || flags & 2. */
+int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
+
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),
  * [5]=data row stride (bytes). */
 int svsx_index_info(const svsx_index* index, uint64_t info[6]);

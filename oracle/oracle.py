@@ -85,11 +85,24 @@ class _Neighbor(C.Structure):
     _fields_ = [("id", C.c_uint32), ("dist", C.c_float), ("visited", C.c_uint8)]
 
 
+class _Iterator(C.Structure):
+    pass  # fields set after _Buffer
+
+
 class _Buffer(C.Structure):
     _fields_ = [
         ("greater", C.c_int), ("size", C.c_size_t), ("best_unvisited", C.c_size_t), ("window", C.c_size_t),
         ("capacity", C.c_size_t), ("e", C.POINTER(_Neighbor)), ("filter", C.c_void_p),
     ]
+
+
+_Iterator._fields_ = [
+    ("ix", C.c_void_p), ("query", C.c_void_p), ("q_dtype", C.c_int), ("extra", C.c_size_t), ("buf", _Buffer),
+    ("yielded", C.c_void_p), ("n_yielded", C.c_size_t), ("yielded_cap", C.c_size_t), ("iteration", C.c_size_t),
+    ("restart", C.c_int), ("exhausted", C.c_int),
+]
+
+PLACEHOLDER = (1 << 64) - 1  # svs::UNSIGNED_INTEGER_PLACEHOLDER (lib/preprocessor.h:177)
 
 
 class Oracle:
@@ -217,9 +230,68 @@ class Oracle:
         self.lib.svso_sq_compress(_ptr(data), data.size, code_dtype, scale, bias, _ptr(codes))
         return codes, float(scale.value), float(bias.value)
 
+    def iterator(self, metric, data, graph, entry, query, extra=PLACEHOLDER, sq=None):
+        return OracleIterator(self, metric, data, graph, entry, query, extra, sq)
+
+    def iterate(self, metric, data, graph, entry, query, batch_sizes, extra=PLACEHOLDER, restart_before=None, sq=None):
+        """BatchIterator (index/vamana/iterator.h) over one query: returns (list of (ids, dists) per next() call,
+        done-after flags, iteration count, final (window, capacity))."""
+        it = self.iterator(metric, data, graph, entry, query, extra, sq)
+        out, done = [], []
+        for b, bs in enumerate(batch_sizes):
+            if restart_before is not None and restart_before[b]:
+                it.restart_next_search()
+            out.append(it.next(bs))
+            done.append(it.done())
+        return out, done, it.batch_number(), it.config()
+
     # -- search buffer (op-by-op) ----------------------------------------------------------------------------
     def buffer(self, window, capacity, greater=False, visited_set=False):
         return OracleBuffer(self, window, capacity, greater, visited_set)
+
+
+class OracleIterator:
+    """svso_iterator: BatchIterator (index/vamana/iterator.h:81-339) over one query."""
+
+    def __init__(self, oracle, metric, data, graph, entry, query, extra=PLACEHOLDER, sq=None):
+        L = self.L = oracle.lib
+        L.svso_iterator_init.argtypes = [C.POINTER(_Iterator), C.POINTER(_Index), C.c_void_p, C.c_int, C.c_size_t]
+        L.svso_iterator_next.restype = C.c_long
+        L.svso_iterator_next.argtypes = [C.POINTER(_Iterator), C.c_size_t, C.c_void_p, C.c_void_p]
+        L.svso_iterator_update.argtypes = [C.POINTER(_Iterator), C.c_void_p]
+        for f in ("svso_iterator_free", "svso_iterator_done", "svso_iterator_restart_next_search"):
+            getattr(L, f).argtypes = [C.POINTER(_Iterator)]
+        self.ix, self._keep = oracle._index(metric, data, graph, entry, sq)
+        self.query = np.ascontiguousarray(query)
+        self.it = _Iterator()
+        self._live = False
+        if L.svso_iterator_init(C.byref(self.it), C.byref(self.ix), _ptr(self.query), dtype_code(self.query), extra):
+            raise ValueError("svso_iterator_init failed")
+        self._live = True
+
+    def __del__(self):
+        if getattr(self, "_live", False):
+            self.L.svso_iterator_free(C.byref(self.it))
+            self._live = False
+
+    def next(self, batch_size):
+        ids = np.empty(max(batch_size, 1), np.uint32)
+        dd = np.empty(max(batch_size, 1), np.float32)
+        got = self.L.svso_iterator_next(C.byref(self.it), batch_size, _ptr(ids), _ptr(dd))
+        if got < 0:
+            raise ValueError(f"svso_iterator_next rc={got}")
+        return ids[:got].copy(), dd[:got].copy()
+
+    def update(self, query):
+        self.query = np.ascontiguousarray(query)
+        if self.L.svso_iterator_update(C.byref(self.it), _ptr(self.query)):
+            raise ValueError("svso_iterator_update failed")
+
+    def done(self): return bool(self.L.svso_iterator_done(C.byref(self.it)))
+    def restart_next_search(self): self.L.svso_iterator_restart_next_search(C.byref(self.it))
+    def batch_number(self): return int(self.it.iteration)
+    def config(self): return int(self.it.buf.window), int(self.it.buf.capacity)
+    def n_yielded(self): return int(self.it.n_yielded)
 
 
 class OracleBuffer:
@@ -326,6 +398,33 @@ class Ref:
         if rc:
             raise ValueError(f"svsref_search_batch rc={rc}")
         return (ids, dists, st) if stats else (ids, dists)
+
+    def iterate(self, metric, data, graph, entry, query, batch_sizes, extra=PLACEHOLDER, restart_before=None):
+        """The reference's SearchBuffer / greedy_search driven with BatchIterator's control flow (ref_driver.cpp)."""
+        data = np.ascontiguousarray(data)
+        graph = np.ascontiguousarray(graph, dtype=np.uint32)
+        entry = np.ascontiguousarray(entry, dtype=np.uint32)
+        query = np.ascontiguousarray(query)
+        bs = np.ascontiguousarray(batch_sizes, dtype=np.uint64)
+        rb = np.zeros(bs.size, np.uint8) if restart_before is None else np.ascontiguousarray(restart_before, dtype=np.uint8)
+        total = int(bs.sum())
+        ids = np.empty(max(total, 1), np.uint32)
+        dd = np.empty(max(total, 1), np.float32)
+        counts = np.zeros(bs.size, np.uint64)
+        done = np.zeros(bs.size, np.uint8)
+        self.lib.svsref_iterate.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = self.lib.svsref_iterate(metric, dtype_code(data), _ptr(data), data.shape[0], data.shape[1], _ptr(graph), graph.shape[1],
+                                     _ptr(entry), entry.size, _ptr(query), dtype_code(query), extra, _ptr(bs), _ptr(rb), bs.size,
+                                     _ptr(ids), _ptr(dd), _ptr(counts), _ptr(done))
+        if rc:
+            raise ValueError(f"svsref_iterate rc={rc}")
+        out, off = [], 0
+        for b in range(bs.size):
+            c = int(counts[b])
+            out.append((ids[off:off + c].copy(), dd[off:off + c].copy()))
+            off += int(bs[b])
+        return out, [bool(x) for x in done]
 
     def buffer(self, window, capacity, greater=False, visited_set=False):
         return RefBuffer(self, window, capacity, greater, visited_set)

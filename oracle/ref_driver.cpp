@@ -39,6 +39,7 @@
 #include <limits>
 #include <span>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -309,9 +310,106 @@ int search_typed(
     return 0;
 }
 
+// BatchIterator (index/vamana/iterator.h:81-339) for a static index, on the REAL SearchBuffer / greedy_search /
+// EntryPointInitializer.  iterator.h itself pulls in index.h and dynamic_index.h (unbuildable here), so its ~40 lines of
+// control flow are restated: RestartInitializer (:36-63), initialize_buffer (:127-131), increment_buffer (:135-139),
+// next (:249-317), copy_from_scratch (:104-124), done (:230).
+struct RestartInit {
+    std::span<const uint32_t> entry_points;
+    bool hard_restart;
+    template <typename Buffer, typename Computer, typename Graph, typename Builder, typename Tracker>
+    void operator()(Buffer& buffer, const Computer& computer, const Graph& graph, const Builder& builder, Tracker& tracker) const {
+        if (hard_restart) {
+            vamana::EntryPointInitializer<uint32_t>{entry_points}(buffer, computer, graph, builder, tracker);
+            return;
+        }
+        buffer.sort();
+    }
+};
+
+template <typename Q, typename T, typename Cmp>
+int iterate_typed(
+    int metric, const T* data, size_t n, size_t d, const uint32_t* graph, size_t stride, const uint32_t* entry,
+    size_t n_entry, const Q* query, size_t extra, const size_t* batch_sizes, const uint8_t* restart_before,
+    size_t n_batches, uint32_t* ids, float* dists, size_t* counts, uint8_t* done_after
+) {
+    RowData<T> ds{data, n, d};
+    RowGraph g{graph, n, stride};
+    if (extra == std::numeric_limits<size_t>::max()) extra = 100;
+    auto buffer = vamana::SearchBuffer<uint32_t, Cmp>{vamana::SearchBufferConfig(0, extra), Cmp{}, false};
+    buffer.clear();
+    std::unordered_set<uint32_t> yielded;
+    bool restart = true, exhausted = false;
+    Functor<Q, T, Cmp> fn{metric};
+    auto accessor = svs::data::GetDatumAccessor{};
+    std::span<const Q> q{query, d};
+    size_t out = 0;
+    for (size_t b = 0; b < n_batches; ++b) {
+        const size_t bs = batch_sizes[b];
+        if (restart_before && restart_before[b]) restart = true; // restart_next_search()
+        size_t got = 0;
+        if (!(yielded.size() == n || exhausted)) {
+            auto config = buffer.config();
+            config.increment(bs);
+            buffer.change_maxsize(config);
+            bool restart_copy = std::exchange(restart, true);
+            vamana::NullTracker tracker{};
+            vamana::greedy_search(
+                g, ds, accessor, q, fn, buffer, RestartInit{std::span<const uint32_t>(entry, n_entry), restart_copy},
+                vamana::NeighborBuilder{}, tracker
+            );
+            restart = false;
+            for (size_t i = 0, imax = buffer.size(); i < imax; ++i) {
+                auto neighbor = buffer[i];
+                if (yielded.insert(neighbor.id()).second) {
+                    ids[out + got] = neighbor.id();
+                    dists[out + got] = neighbor.distance();
+                    ++got;
+                }
+                if (got == bs) break;
+            }
+            if (got == 0 && bs > 0) exhausted = true;
+        }
+        counts[b] = got;
+        out += bs;
+        done_after[b] = (yielded.size() == n || exhausted) ? 1 : 0;
+    }
+    return 0;
+}
+
 } // namespace
 
 extern "C" {
+
+// One query driven through a list of next(batch_size) calls.  ids/dists: sum(batch_sizes) slots, batch b's results at
+// offset sum(batch_sizes[:b]); counts[b] = results of batch b; done_after[b] = done() after that call.
+int svsref_iterate(
+    int metric, int data_dtype, const void* data, size_t n, size_t d, const uint32_t* graph, size_t graph_stride,
+    const uint32_t* entry, size_t n_entry, const void* query, int q_dtype, size_t extra, const size_t* batch_sizes,
+    const uint8_t* restart_before, size_t n_batches, uint32_t* ids, float* dists, size_t* counts, uint8_t* done_after
+) {
+    try {
+        return with_type(q_dtype, [&](auto* tq) {
+            using Q = std::remove_cv_t<std::remove_pointer_t<decltype(tq)>>;
+            return with_type(data_dtype, [&](auto* tt) {
+                using T = std::remove_cv_t<std::remove_pointer_t<decltype(tt)>>;
+                constexpr bool ok = (std::is_same_v<Q, T> && is_small_int<Q>::value) || float_simd_pair<Q, T>();
+                if constexpr (!ok) {
+                    return -3;
+                } else {
+                    auto run = [&](auto cmp) {
+                        return iterate_typed<Q, T, decltype(cmp)>(
+                            metric, static_cast<const T*>(data), n, d, graph, graph_stride, entry, n_entry,
+                            static_cast<const Q*>(query), extra, batch_sizes, restart_before, n_batches, ids, dists, counts,
+                            done_after
+                        );
+                    };
+                    return metric == L2 ? run(std::less<>{}) : run(std::greater<>{});
+                }
+            });
+        });
+    } catch (...) { return -9; }
+}
 
 int svsref_has_avx512() {
     return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&

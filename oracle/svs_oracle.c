@@ -295,15 +295,89 @@ void svso_buffer_push_back(svso_buffer* b, uint32_t id, float dist) { /* :306-31
     }
 }
 
-void svso_buffer_sort(svso_buffer* b) { /* :408 std::sort(cmp); implemented stably (insertion sort) */
-    for (size_t i = 1; i < b->size; ++i) {
-        svso_neighbor x = b->e[i];
-        size_t j = i;
-        while (j > 0 && cmp(b, x.dist, b->e[j - 1].dist)) {
-            b->e[j] = b->e[j - 1];
-            --j;
+/* :408 std::sort(begin(), end(), compare_).  std::sort is not stable: entries of exactly equal distance come out in an
+ * order fixed by the library's algorithm, and BatchIterator re-sorts an already sorted buffer on every resumed search
+ * (iterator.h:61).  To stay id-exact through ties this restates libstdc++'s algorithm (GCC 11 bits/stl_algo.h:
+ * __sort = __introsort_loop(depth 2*lg n; threshold 16; median of {first+1, mid, last-1} swapped to first; unguarded
+ * partition of (first+1, last) around *first) followed by __final_insertion_sort).  The heapsort fallback at depth 0 is
+ * not restated; it cannot trigger on sorted input (the median is the middle value, so ranges halve) and is reported
+ * through svso_sort_depth_exhausted for anything else. */
+static int g_sort_depth_exhausted = 0;
+int svso_sort_depth_exhausted(void) { return g_sort_depth_exhausted; }
+
+static inline int nb_cmp(const svso_buffer* b, const svso_neighbor* x, const svso_neighbor* y) { return cmp(b, x->dist, y->dist); }
+static inline void nb_swap(svso_neighbor* x, svso_neighbor* y) { svso_neighbor t = *x; *x = *y; *y = t; }
+
+static void unguarded_linear_insert(const svso_buffer* b, svso_neighbor* a, size_t last) {
+    svso_neighbor val = a[last];
+    size_t next = last - 1;
+    while (nb_cmp(b, &val, &a[next])) {
+        a[last] = a[next];
+        last = next;
+        --next; /* never read below the guard: a smaller-or-equal element stops the loop first */
+    }
+    a[last] = val;
+}
+
+static void insertion_sort(const svso_buffer* b, svso_neighbor* a, size_t first, size_t last) {
+    if (first == last) return;
+    for (size_t i = first + 1; i != last; ++i) {
+        if (nb_cmp(b, &a[i], &a[first])) {
+            svso_neighbor val = a[i];
+            memmove(&a[first + 1], &a[first], (i - first) * sizeof(svso_neighbor));
+            a[first] = val;
+        } else {
+            unguarded_linear_insert(b, a, i);
         }
-        b->e[j] = x;
+    }
+}
+
+void svso_buffer_sort(svso_buffer* b) {
+    svso_neighbor* a = b->e;
+    const size_t n = b->size;
+    if (n == 0) return;
+    struct { size_t first, last; unsigned depth; } stack[128];
+    int sp = 0;
+    unsigned lg = 0;
+    for (size_t t = n; t > 1; t >>= 1) ++lg;
+    stack[sp].first = 0; stack[sp].last = n; stack[sp].depth = 2 * lg; ++sp;
+    while (sp > 0) {
+        --sp;
+        size_t first = stack[sp].first, last = stack[sp].last;
+        unsigned depth = stack[sp].depth;
+        while (last - first > 16) {
+            if (depth == 0) { g_sort_depth_exhausted = 1; break; }
+            --depth;
+            /* __move_median_to_first(first, first + 1, mid, last - 1) */
+            svso_neighbor *r = &a[first], *x = &a[first + 1], *y = &a[first + (last - first) / 2], *z = &a[last - 1];
+            if (nb_cmp(b, x, y)) {
+                if (nb_cmp(b, y, z)) nb_swap(r, y);
+                else if (nb_cmp(b, x, z)) nb_swap(r, z);
+                else nb_swap(r, x);
+            } else if (nb_cmp(b, x, z)) nb_swap(r, x);
+            else if (nb_cmp(b, y, z)) nb_swap(r, z);
+            else nb_swap(r, y);
+            /* __unguarded_partition(first + 1, last, pivot = first) */
+            size_t lo = first + 1, hi = last;
+            for (;;) {
+                while (nb_cmp(b, &a[lo], &a[first])) ++lo;
+                --hi;
+                while (nb_cmp(b, &a[first], &a[hi])) --hi;
+                if (!(lo < hi)) break;
+                nb_swap(&a[lo], &a[hi]);
+                ++lo;
+            }
+            /* recurse on [cut, last), continue with [first, cut) */
+            if (sp < 127) { stack[sp].first = lo; stack[sp].last = last; stack[sp].depth = depth; ++sp; }
+            last = lo;
+        }
+    }
+    /* __final_insertion_sort */
+    if (n > 16) {
+        insertion_sort(b, a, 0, 16);
+        for (size_t i = 16; i != n; ++i) unguarded_linear_insert(b, a, i);
+    } else {
+        insertion_sort(b, a, 0, n);
     }
 }
 
@@ -463,9 +537,9 @@ static float index_distance(const svso_index* ix, const fixed_query* fq, uint32_
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* greedy_search  (index/vamana/greedy_search.h:124-203) with EntryPointInitializer (:62-94) */
-int svso_greedy_search(
+static int greedy_search_core(
     const svso_index* ix, const void* query, int q_dtype, svso_buffer* buf, svso_stats* stats,
-    uint32_t* history, float* history_dist, size_t history_cap, size_t* history_len
+    uint32_t* history, float* history_dist, size_t history_cap, size_t* history_len, int resume
 ) {
     fixed_query fq;
     int rc = fix_query(ix, query, q_dtype, &fq);
@@ -488,13 +562,15 @@ int svso_greedy_search(
     if (stats) memset(sim_filter, 0, sizeof(sim_filter));
     size_t hlen = 0;
 
-    svso_buffer_clear(buf);
-    for (size_t e = 0; e < ix->n_entry; ++e) {
-        uint32_t id = ix->entry_points[e];
-        float dd = index_distance(ix, &fq, id, scratch);
-        local.distance_evals++;
-        svso_buffer_push_back(buf, id, dd);
-    }
+    if (!resume) { /* EntryPointInitializer (:62-94) */
+        svso_buffer_clear(buf);
+        for (size_t e = 0; e < ix->n_entry; ++e) {
+            uint32_t id = ix->entry_points[e];
+            float dd = index_distance(ix, &fq, id, scratch);
+            local.distance_evals++;
+            svso_buffer_push_back(buf, id, dd);
+        }
+    } /* else RestartInitializer (index/vamana/iterator.h:36-63): keep the contents, only sort */
     svso_buffer_sort(buf);
 
     while (!svso_buffer_done(buf)) {
@@ -539,6 +615,102 @@ int svso_greedy_search(
     free(scratch);
     free(fq.owned);
     return 0;
+}
+
+int svso_greedy_search(
+    const svso_index* ix, const void* query, int q_dtype, svso_buffer* buf, svso_stats* stats,
+    uint32_t* history, float* history_dist, size_t history_cap, size_t* history_len
+) {
+    return greedy_search_core(ix, query, q_dtype, buf, stats, history, history_dist, history_cap, history_len, 0);
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* BatchIterator (index/vamana/iterator.h:81-339), static index (no id translation, no reranking).
+ * RestartInitializer re-sorts the already sorted buffer with std::sort (:61), which permutes entries of exactly equal
+ * distance: svso_buffer_sort restates libstdc++'s algorithm so that the tie order matches too. */
+int svso_buffer_change_maxsize(svso_buffer* b, size_t window, size_t capacity) { /* search_buffer.h:206-211 */
+    svso_neighbor* e = (svso_neighbor*)realloc(b->e, (capacity + 1) * sizeof(svso_neighbor));
+    if (!e) return -2;
+    b->e = e;
+    b->window = window;
+    b->capacity = capacity;
+    if (b->size > capacity) b->size = capacity;
+    return 0;
+}
+
+int svso_iterator_init(svso_iterator* it, const svso_index* ix, const void* query, int q_dtype, size_t extra_capacity) {
+    memset(it, 0, sizeof(*it));
+    it->ix = ix;
+    it->q_dtype = q_dtype;
+    size_t qb = svso_dtype_size(q_dtype) * ix->d;
+    it->query = malloc(qb ? qb : 1);
+    if (!it->query) return -2;
+    memcpy(it->query, query, qb);
+    it->extra = extra_capacity == (size_t)-1 ? 100 : extra_capacity; /* lib/preprocessor.h:177,187; iterator.h:166-170 */
+    it->restart = 1;
+    /* initialize_buffer (:127-131): SearchBufferConfig{0, extra}, clear */
+    int rc = svso_buffer_init(&it->buf, 0, it->extra, ix->metric != SVSO_L2, 0);
+    if (rc) { free(it->query); it->query = NULL; }
+    return rc;
+}
+
+void svso_iterator_free(svso_iterator* it) {
+    svso_buffer_free(&it->buf);
+    free(it->query);
+    free(it->yielded);
+    memset(it, 0, sizeof(*it));
+}
+
+int svso_iterator_done(const svso_iterator* it) { /* :230 */
+    return it->n_yielded == it->ix->n || it->exhausted;
+}
+
+void svso_iterator_restart_next_search(svso_iterator* it) { it->restart = 1; } /* :233 */
+
+int svso_iterator_update(svso_iterator* it, const void* query) { /* :177-190 */
+    memcpy(it->query, query, svso_dtype_size(it->q_dtype) * it->ix->d);
+    int rc = svso_buffer_change_maxsize(&it->buf, 0, it->extra);
+    if (rc) return rc;
+    svso_buffer_clear(&it->buf);
+    it->restart = 1;
+    it->iteration = 0;
+    it->n_yielded = 0;
+    it->exhausted = 0;
+    return 0;
+}
+
+/* next (:249-317) + copy_from_scratch (:104-124): returns the number of neighbours written (<= batch_size), < 0 on error */
+long svso_iterator_next(svso_iterator* it, size_t batch_size, uint32_t* ids, float* dists) {
+    if (svso_iterator_done(it)) return 0;
+    /* increment_buffer (:135-139) */
+    int rc = svso_buffer_change_maxsize(&it->buf, it->buf.window + batch_size, it->buf.capacity + batch_size);
+    if (rc) return rc;
+    int hard = it->restart;
+    it->restart = 1;
+    rc = greedy_search_core(it->ix, it->query, it->q_dtype, &it->buf, NULL, NULL, NULL, 0, NULL, !hard);
+    if (rc) return rc;
+    it->iteration++;
+    it->restart = 0;
+    size_t got = 0;
+    for (size_t i = 0; i < it->buf.size && got < batch_size; ++i) {
+        uint32_t id = it->buf.e[i].id;
+        int seen = 0;
+        for (size_t y = 0; y < it->n_yielded; ++y) if (it->yielded[y] == id) { seen = 1; break; }
+        if (seen) continue;
+        if (it->n_yielded == it->yielded_cap) {
+            size_t nc = it->yielded_cap ? it->yielded_cap * 2 : 256;
+            uint32_t* ny = (uint32_t*)realloc(it->yielded, nc * sizeof(uint32_t));
+            if (!ny) return -2;
+            it->yielded = ny;
+            it->yielded_cap = nc;
+        }
+        it->yielded[it->n_yielded++] = id;
+        ids[got] = id;
+        dists[got] = it->buf.e[i].dist;
+        got++;
+    }
+    if (got == 0 && batch_size > 0) it->exhausted = 1;
+    return (long)got;
 }
 
 /* VamanaIndex::search batch (index/vamana/index.h:564-611) + per_thread_batch_search (extensions.h:555-592) */

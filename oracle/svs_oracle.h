@@ -71,7 +71,8 @@ int svso_buffer_init(svso_buffer* b, size_t window, size_t capacity, int greater
 void svso_buffer_free(svso_buffer* b);
 void svso_buffer_clear(svso_buffer* b);
 void svso_buffer_push_back(svso_buffer* b, uint32_t id, float dist);
-void svso_buffer_sort(svso_buffer* b);
+void svso_buffer_sort(svso_buffer* b);   /* libstdc++ std::sort order, ties included */
+int svso_sort_depth_exhausted(void);
 size_t svso_buffer_insert(svso_buffer* b, uint32_t id, float dist);
 int svso_buffer_done(const svso_buffer* b);
 svso_neighbor svso_buffer_next(svso_buffer* b);
@@ -107,6 +108,28 @@ int svso_greedy_search(
     const svso_index* ix, const void* query, int q_dtype, svso_buffer* buf, svso_stats* stats,
     uint32_t* history, float* history_dist, size_t history_cap, size_t* history_len
 );
+
+/* ---- index/vamana/iterator.h:81-339 BatchIterator over one query (static index) ---- */
+typedef struct {
+    const svso_index* ix;
+    void* query;
+    int q_dtype;
+    size_t extra;           /* extra_search_buffer_capacity_ */
+    svso_buffer buf;        /* scratchspace_.buffer: persists between next() calls */
+    uint32_t* yielded;      /* yielded_ (ids in yield order) */
+    size_t n_yielded, yielded_cap;
+    size_t iteration;       /* batch_number() */
+    int restart;            /* restart_search_ */
+    int exhausted;          /* is_exhausted_ */
+} svso_iterator;
+
+int svso_buffer_change_maxsize(svso_buffer* b, size_t window, size_t capacity);
+int svso_iterator_init(svso_iterator* it, const svso_index* ix, const void* query, int q_dtype, size_t extra_capacity);
+void svso_iterator_free(svso_iterator* it);
+int svso_iterator_done(const svso_iterator* it);
+void svso_iterator_restart_next_search(svso_iterator* it);
+int svso_iterator_update(svso_iterator* it, const void* query);
+long svso_iterator_next(svso_iterator* it, size_t batch_size, uint32_t* ids, float* dists);
 
 /* index/vamana/index.h:564-611 + extensions.h:555-592 (single thread): ids32 nq x k, dists nq x k.
  * Rows with fewer than k results are padded with id 0xFFFFFFFF and dist +inf (runtime convention, api_defs.h:58-66). */

@@ -9,6 +9,7 @@ The compute lives in libsvsx.so (hand-written HIP for gfx950); there is no CPU f
 from ._lib import SvsxError, build, lib  # noqa: F401
 from .distance import DistanceCosineSimilarity, DistanceIP, DistanceL2, DistanceType, compute  # noqa: F401
 from .calibrate import CalibrationParameters, calibrate  # noqa: F401
+from .iterator import BatchIterator, filtered_search, range_search  # noqa: F401
 from .index import (  # noqa: F401
     FlatIndex, QueryResult, SearchBufferConfig, VamanaIndex, VamanaSearchParameters, k_recall_at_n,
 )
@@ -16,4 +17,5 @@ from .index import (  # noqa: F401
 __all__ = [
     "SvsxError", "build", "lib", "DistanceType", "DistanceL2", "DistanceIP", "DistanceCosineSimilarity", "compute",
     "VamanaIndex", "FlatIndex", "VamanaSearchParameters", "SearchBufferConfig", "QueryResult", "k_recall_at_n", "calibrate", "CalibrationParameters",
+    "BatchIterator", "filtered_search", "range_search",
 ]

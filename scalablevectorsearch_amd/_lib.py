@@ -60,6 +60,8 @@ class SearchAux(C.Structure):
 EXPORTS = [
     "svsx_index_create", "svsx_index_create_device_view", "svsx_index_destroy", "svsx_search", "svsx_search_device",
     "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
+    "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
+    "svsx_iterator_next_device", "svsx_iterator_state",
 ]
 
 _lib = None
@@ -107,6 +109,14 @@ def lib() -> C.CDLL:
         L.svsx_prune_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         L.svsx_flat_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.svsx_iterator_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.svsx_iterator_destroy.argtypes = [C.c_void_p]
+        L.svsx_iterator_destroy.restype = None
+        L.svsx_iterator_update.argtypes = [C.c_void_p, C.c_void_p]
+        L.svsx_iterator_restart_next_search.argtypes = [C.c_void_p]
+        L.svsx_iterator_next.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svsx_iterator_next_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svsx_iterator_state.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

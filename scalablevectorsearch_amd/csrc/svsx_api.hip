@@ -260,6 +260,36 @@ int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
     return SVSX_SUCCESS;
 }
 
+static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, int q_dtype, size_t q_row_bytes, size_t nq) {
+    SearchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.data = ix->d_data;
+    a.row_bytes = ix->row_bytes;
+    a.graph = ix->d_graph;
+    a.gstride = static_cast<uint32_t>(ix->gstride);
+    a.n = static_cast<uint32_t>(ix->n);
+    a.d = static_cast<uint32_t>(ix->d);
+    a.entry = ix->d_entry;
+    a.n_entry = static_cast<uint32_t>(ix->n_entry);
+    a.sq_scale = ix->sq_scale;
+    a.sq_bias = ix->sq_bias;
+    a.id_offset = ix->id_offset;
+    a.queries = d_queries;
+    a.q_dtype = q_dtype;
+    a.q_row_bytes = q_row_bytes;
+    a.nq = static_cast<uint32_t>(nq);
+    a.general = ix->n_entry > 16 ? 1u : 0u; // std::sort of > 16 entry points is not a stable insertion sort
+    return a;
+}
+
+// default LDS visited filter: 4 KB per wave (the measured optimum): 4096 entries with 8-bit tags when they identify
+// the id exactly ((n >> 12) < 255), else 2048 entries with 16-bit tags; grown until tags are exact, else off
+static void default_filter(const svsx_index* ix, SearchArgs& a, uint32_t fe) {
+    while (fe <= 16384 && (ix->n >> __builtin_ctz(fe)) >= 0xFFFFu) fe <<= 1;
+    a.filter_entries = fe <= 16384 ? fe : 0;
+    a.filter_tag8 = (a.filter_entries && (ix->n >> __builtin_ctz(a.filter_entries)) < 0xFFu) ? 1u : 0u;
+}
+
 static int search_common(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     uint64_t* d_ids64, uint32_t* d_ids32, float* d_dists, const svsx_search_aux* aux, hipStream_t stream
@@ -278,23 +308,7 @@ static int search_common(
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0)
         return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d%s) pair", q_dtype, ix->data_dtype, ix->sq_enabled ? ", SQ" : "");
-    SearchArgs a;
-    memset(&a, 0, sizeof(a));
-    a.data = ix->d_data;
-    a.row_bytes = ix->row_bytes;
-    a.graph = ix->d_graph;
-    a.gstride = static_cast<uint32_t>(ix->gstride);
-    a.n = static_cast<uint32_t>(ix->n);
-    a.d = static_cast<uint32_t>(ix->d);
-    a.entry = ix->d_entry;
-    a.n_entry = static_cast<uint32_t>(ix->n_entry);
-    a.sq_scale = ix->sq_scale;
-    a.sq_bias = ix->sq_bias;
-    a.id_offset = ix->id_offset;
-    a.queries = d_queries;
-    a.q_dtype = q_dtype;
-    a.q_row_bytes = (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype);
-    a.nq = static_cast<uint32_t>(nq);
+    SearchArgs a = base_search_args(ix, d_queries, q_dtype, (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype), nq);
     a.window = static_cast<uint32_t>(window);
     a.capacity = static_cast<uint32_t>(capacity);
     a.k = static_cast<uint32_t>(k);
@@ -313,9 +327,7 @@ static int search_common(
             while (fe & (fe - 1)) fe &= fe - 1;
         }
         // tags must identify the id exactly: grow the table until (n >> log2 entries) < 0xFFFF, else stay off
-        while (fe <= 16384 && (ix->n >> __builtin_ctz(fe)) >= 0xFFFFu) fe <<= 1;
-        a.filter_entries = fe <= 16384 ? fe : 0;
-        a.filter_tag8 = (a.filter_entries && (ix->n >> __builtin_ctz(a.filter_entries)) < 0xFFu) ? 1u : 0u;
+        default_filter(ix, a, fe);
     }
     a.ids64 = d_ids64;
     a.ids32 = d_ids32;
@@ -563,3 +575,206 @@ int svsx_merge_topk_device(
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched BatchIterator (index/vamana/iterator.h:81-339): see include/svsx.h
+struct svsx_batch_iterator {
+    const svsx_index* ix = nullptr;
+    int q_dtype = 0;
+    int qmode = 0;
+    size_t nq = 0;
+    size_t extra = 0;
+    size_t q_stride = 0;
+    void* d_queries = nullptr;
+    uint2* d_entries = nullptr;
+    size_t estride = 0;       // entries per query
+    uint32_t* d_meta = nullptr;
+    uint32_t* d_yielded = nullptr;
+    size_t ystride = 0;
+    size_t max_capacity = 0;  // upper bound of any query's capacity
+    size_t yield_bound = 0;   // upper bound of any query's yielded count
+};
+
+namespace {
+
+int iterator_reset_meta(svsx_batch_iterator* it, hipStream_t stream) {
+    std::vector<uint32_t> meta(it->nq * 8, 0u);
+    for (size_t i = 0; i < it->nq; ++i) {
+        meta[i * 8 + 3] = static_cast<uint32_t>(it->extra); // initialize_buffer: SearchBufferConfig{0, extra} (iterator.h:127-131)
+        meta[i * 8 + 6] = 1u;                               // restart_search_ = true
+    }
+    HIP_TRY(hipMemcpyAsync(it->d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    it->max_capacity = it->extra;
+    it->yield_bound = 0;
+    return SVSX_SUCCESS;
+}
+
+// grow a [nq][stride] device table, keeping the first `keep` elements of every row
+template <typename T> int grow_rows(T*& p, size_t& stride, size_t need, size_t nq, size_t keep) {
+    if (need <= stride) return SVSX_SUCCESS;
+    size_t ns = stride * 2 > need ? stride * 2 : need;
+    ns = (ns + 63) & ~size_t(63);
+    T* np = nullptr;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&np), ns * nq * sizeof(T)));
+    if (p && keep) {
+        hipError_t e = hipMemcpy2D(np, ns * sizeof(T), p, stride * sizeof(T), keep * sizeof(T), nq, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(np);
+            return fail(SVSX_RUNTIME_ERROR, "iterator state copy failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    stride = ns;
+    return SVSX_SUCCESS;
+}
+
+} // namespace
+
+int svsx_iterator_create(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t extra, svsx_batch_iterator** out
+) {
+    if (!out) return fail(SVSX_INVALID_ARGUMENT, "null output handle");
+    *out = nullptr;
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (!ix->d_graph) return fail(SVSX_INVALID_ARGUMENT, "this index was created without a graph (flat search only)");
+    if (dtype_size(q_dtype) == 0) return fail(SVSX_INVALID_ARGUMENT, "unknown query dtype %d", q_dtype);
+    if (nq == 0 || !queries) return fail(SVSX_INVALID_ARGUMENT, "null queries");
+    if (nq >= (size_t(1) << 31)) return fail(SVSX_INVALID_ARGUMENT, "too many queries in one batch");
+    const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
+    if (qmode < 0)
+        return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d%s) pair", q_dtype, ix->data_dtype, ix->sq_enabled ? ", SQ" : "");
+    if (extra == ~size_t(0)) extra = 100; // lib/preprocessor.h:177,187
+    if (extra > 16000) return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu exceeds the LDS budget of one wave", extra);
+    HIP_TRY(hipSetDevice(ix->device));
+    svsx_batch_iterator* it = new (std::nothrow) svsx_batch_iterator();
+    if (!it) return fail(SVSX_RUNTIME_ERROR, "out of memory");
+    it->ix = ix;
+    it->q_dtype = q_dtype;
+    it->qmode = qmode;
+    it->nq = nq;
+    it->extra = extra;
+    it->q_stride = ix->d * dtype_size(q_dtype);
+    int rc = SVSX_SUCCESS;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&it->d_queries, it->q_stride * nq));
+        HIP_TRY(hipMemcpy(it->d_queries, queries, it->q_stride * nq, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&it->d_meta), nq * 32));
+        return iterator_reset_meta(it, nullptr);
+    };
+    rc = body();
+    if (rc != SVSX_SUCCESS) {
+        svsx_iterator_destroy(it);
+        return rc;
+    }
+    *out = it;
+    return SVSX_SUCCESS;
+}
+
+void svsx_iterator_destroy(svsx_batch_iterator* it) {
+    if (!it) return;
+    (void)hipSetDevice(it->ix->device);
+    if (it->d_queries) (void)hipFree(it->d_queries);
+    if (it->d_entries) (void)hipFree(it->d_entries);
+    if (it->d_meta) (void)hipFree(it->d_meta);
+    if (it->d_yielded) (void)hipFree(it->d_yielded);
+    delete it;
+}
+
+int svsx_iterator_update(svsx_batch_iterator* it, const void* queries) {
+    if (!it) return fail(SVSX_NOT_INITIALIZED, "Iterator not initialized");
+    if (!queries) return fail(SVSX_INVALID_ARGUMENT, "null queries");
+    HIP_TRY(hipSetDevice(it->ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(it->d_queries, queries, it->q_stride * it->nq, hipMemcpyHostToDevice));
+    return iterator_reset_meta(it, nullptr);
+}
+
+int svsx_iterator_restart_next_search(svsx_batch_iterator* it) {
+    if (!it) return fail(SVSX_NOT_INITIALIZED, "Iterator not initialized");
+    HIP_TRY(hipSetDevice(it->ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> meta(it->nq * 8);
+    HIP_TRY(hipMemcpy(meta.data(), it->d_meta, meta.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < it->nq; ++i) meta[i * 8 + 6] |= 1u;
+    HIP_TRY(hipMemcpy(it->d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
+    return SVSX_SUCCESS;
+}
+
+int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta) {
+    if (!it) return fail(SVSX_NOT_INITIALIZED, "Iterator not initialized");
+    if (!meta) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(it->ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(meta, it->d_meta, it->nq * 32, hipMemcpyDeviceToHost));
+    return SVSX_SUCCESS;
+}
+
+int svsx_iterator_next_device(
+    svsx_batch_iterator* it, size_t batch_size, const uint32_t* d_batch_sizes, uint64_t* d_ids64, float* d_dists,
+    uint32_t* d_counts, void* hip_stream
+) {
+    if (!it) return fail(SVSX_NOT_INITIALIZED, "Iterator not initialized");
+    if (!d_ids64 || !d_dists || !d_counts) return fail(SVSX_INVALID_ARGUMENT, "null output");
+    if (batch_size >= 0xFFFFFFFFull) return fail(SVSX_INVALID_ARGUMENT, "batch size too large");
+    const svsx_index* ix = it->ix;
+    const size_t cap = it->max_capacity + batch_size;
+    if (cap > 16000)
+        return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu exceeds the LDS budget of one wave (restart with update())", cap);
+    HIP_TRY(hipSetDevice(ix->device));
+    size_t ybound = it->yield_bound + batch_size;
+    if (ybound > ix->n) ybound = ix->n;
+    if (int rc = grow_rows(it->d_entries, it->estride, cap + 1, it->nq, it->estride)) return rc;
+    if (int rc = grow_rows(it->d_yielded, it->ystride, ybound ? ybound : 1, it->nq, it->ystride)) return rc;
+    SearchArgs a = base_search_args(ix, it->d_queries, it->q_dtype, it->q_stride, it->nq);
+    a.general = 1;
+    a.window = static_cast<uint32_t>(cap); // per-query values come from the state table; this sizes the LDS buffer
+    a.capacity = static_cast<uint32_t>(cap);
+    default_filter(ix, a, (ix->n >> 12) < 0xFFu ? 4096u : kDefaultFilterEntries); // result-neutral within one call
+    a.it_entries = it->d_entries;
+    a.it_estride = static_cast<uint32_t>(it->estride);
+    a.it_meta = it->d_meta;
+    a.it_yielded = it->d_yielded;
+    a.it_ystride = static_cast<uint32_t>(it->ystride);
+    a.it_batch_sizes = d_batch_sizes;
+    a.it_batch = static_cast<uint32_t>(batch_size);
+    a.it_out_ids = d_ids64;
+    a.it_out_dists = d_dists;
+    a.it_counts = d_counts;
+    hipError_t e = launch_search(ix->data_dtype, ix->metric, it->qmode, a, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "iterator kernel launch failed: %s", hipGetErrorString(e));
+    it->max_capacity = cap;
+    it->yield_bound = ybound;
+    return SVSX_SUCCESS;
+}
+
+int svsx_iterator_next(
+    svsx_batch_iterator* it, size_t batch_size, const uint32_t* batch_sizes, uint64_t* ids64, float* dists, uint32_t* counts
+) {
+    if (!it) return fail(SVSX_NOT_INITIALIZED, "Iterator not initialized");
+    if (!ids64 || !dists || !counts) return fail(SVSX_INVALID_ARGUMENT, "null output");
+    HIP_TRY(hipSetDevice(it->ix->device));
+    CallStream cs;
+    HIP_TRY(cs.create());
+    StreamBuffer dbs, d64, dd, dc;
+    const size_t nq = it->nq;
+    if (batch_sizes) {
+        HIP_TRY(dbs.alloc(nq * 4, cs.s));
+        HIP_TRY(hipMemcpyAsync(dbs.p, batch_sizes, nq * 4, hipMemcpyHostToDevice, cs.s));
+    }
+    HIP_TRY(d64.alloc(nq * batch_size * 8, cs.s));
+    HIP_TRY(dd.alloc(nq * batch_size * 4, cs.s));
+    HIP_TRY(dc.alloc(nq * 4, cs.s));
+    if (int rc = svsx_iterator_next_device(it, batch_size, static_cast<const uint32_t*>(dbs.p), static_cast<uint64_t*>(d64.p),
+                                           static_cast<float*>(dd.p), static_cast<uint32_t*>(dc.p), cs.s))
+        return rc;
+    if (batch_size) {
+        HIP_TRY(hipMemcpyAsync(ids64, d64.p, nq * batch_size * 8, hipMemcpyDeviceToHost, cs.s));
+        HIP_TRY(hipMemcpyAsync(dists, dd.p, nq * batch_size * 4, hipMemcpyDeviceToHost, cs.s));
+    }
+    HIP_TRY(hipMemcpyAsync(counts, dc.p, nq * 4, hipMemcpyDeviceToHost, cs.s));
+    HIP_TRY(hipStreamSynchronize(cs.s));
+    return SVSX_SUCCESS;
+}

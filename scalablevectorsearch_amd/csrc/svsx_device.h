@@ -780,4 +780,101 @@ __device__ __forceinline__ bool wave_done(const WaveBuffer& b) {
     return b.best_unvisited == upper;
 }
 
+// SearchBuffer::sort (search_buffer.h:408) = std::sort(begin(), end(), compare_).  std::sort is not stable, and
+// BatchIterator re-sorts an already sorted buffer on every resumed search (iterator.h:61), so entries of exactly
+// equal distance come out in the order libstdc++'s algorithm leaves them.  To stay id-exact through ties this restates
+// that algorithm (introsort: median of {first+1, mid, last-1} swapped to first, unguarded partition, ranges of <= 16
+// left to a final insertion sort; the depth-limit heapsort cannot trigger on sorted input because ranges halve).
+// Sequential by nature: lane 0 runs it in LDS; `stack` = 64 uint2 of LDS.  `presorted` callers skip it when no two
+// adjacent distances are equal (a sorted range without ties is a fixed point).
+template <bool GREATER> __device__ __forceinline__ bool entry_less(const uint2 x, const uint2 y) {
+    return cmpf<GREATER>(__uint_as_float(x.x), __uint_as_float(y.x));
+}
+
+template <bool GREATER> __device__ inline void lane0_linear_insert(uint2* a, uint32_t last) {
+    const uint2 val = a[last];
+    uint32_t next = last - 1;
+    while (entry_less<GREATER>(val, a[next])) {
+        a[last] = a[next];
+        last = next;
+        --next;
+    }
+    a[last] = val;
+}
+
+template <bool GREATER> __device__ inline void lane0_insertion_sort(uint2* a, uint32_t first, uint32_t last) {
+    if (first == last) return;
+    for (uint32_t i = first + 1; i != last; ++i) {
+        if (entry_less<GREATER>(a[i], a[first])) {
+            const uint2 val = a[i];
+            for (uint32_t j = i; j > first; --j) a[j] = a[j - 1];
+            a[first] = val;
+        } else {
+            lane0_linear_insert<GREATER>(a, i);
+        }
+    }
+}
+
+template <bool GREATER>
+__device__ __noinline__ void wave_std_sort(WaveBuffer& b, uint2* stack, uint32_t lane, bool presorted) {
+    const uint32_t n = b.size;
+    if (n < 2) return;
+    if (presorted) {
+        bool tie = false;
+        for (uint32_t base = 0; base + 1 < n; base += 64) {
+            const uint32_t i = base + lane;
+            bool t = false;
+            if (i + 1 < n) t = b.e[i].x == b.e[i + 1].x || __uint_as_float(b.e[i].x) == __uint_as_float(b.e[i + 1].x);
+            tie = tie || (__ballot(t) != 0ull);
+        }
+        if (!tie) return;
+    }
+    lds_order();
+    if (lane == 0) {
+        uint2* a = b.e;
+        uint32_t sp = 0;
+        stack[sp++] = make_uint2(0u, n);
+        while (sp > 0) {
+            const uint2 r = stack[--sp];
+            const uint32_t first = r.x;
+            uint32_t last = r.y;
+            while (last - first > 16u) {
+                const uint32_t ix = first + 1, iy = first + (last - first) / 2, iz = last - 1;
+                const uint2 x = a[ix], y = a[iy], z = a[iz];
+                uint32_t pick; // __move_median_to_first
+                if (entry_less<GREATER>(x, y)) {
+                    if (entry_less<GREATER>(y, z)) pick = iy;
+                    else if (entry_less<GREATER>(x, z)) pick = iz;
+                    else pick = ix;
+                } else if (entry_less<GREATER>(x, z)) pick = ix;
+                else if (entry_less<GREATER>(y, z)) pick = iz;
+                else pick = iy;
+                const uint2 pivot = a[pick];
+                a[pick] = a[first];
+                a[first] = pivot;
+                uint32_t lo = first + 1, hi = last; // __unguarded_partition(first + 1, last, first)
+                for (;;) {
+                    while (entry_less<GREATER>(a[lo], pivot)) ++lo;
+                    --hi;
+                    while (entry_less<GREATER>(pivot, a[hi])) --hi;
+                    if (!(lo < hi)) break;
+                    const uint2 t = a[lo];
+                    a[lo] = a[hi];
+                    a[hi] = t;
+                    ++lo;
+                }
+                if (sp < 64u) stack[sp++] = make_uint2(lo, last);
+                last = lo;
+            }
+        }
+        if (n > 16u) { // __final_insertion_sort
+            lane0_insertion_sort<GREATER>(a, 0u, 16u);
+            for (uint32_t i = 16u; i != n; ++i) lane0_linear_insert<GREATER>(a, i);
+        } else {
+            lane0_insertion_sort<GREATER>(a, 0u, n);
+        }
+    }
+    lds_order();
+}
+
 } // namespace svsx

@@ -37,6 +37,20 @@ struct SearchArgs {
     float* history_dists;
     uint32_t* history_len;
     uint32_t history_cap;
+    // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
+    uint32_t general;
+    // BatchIterator (index/vamana/iterator.h): per-query state in HBM.  meta = 8 u32 per query:
+    //   [0] size  [1] best_unvisited  [2] window  [3] capacity  [4] yielded  [5] iteration  [6] flags (1 restart, 2 exhausted)
+    uint2* it_entries;       // [nq][it_estride] buffer entries {dist bits, id | visited << 31}
+    uint32_t it_estride;
+    uint32_t* it_meta;       // nullptr = plain search
+    uint32_t* it_yielded;    // [nq][it_ystride] ids already handed out, in yield order
+    uint32_t it_ystride;
+    const uint32_t* it_batch_sizes; // optional per-query batch size (0xFFFFFFFF = leave this query untouched)
+    uint32_t it_batch;       // uniform batch size and row stride of the outputs
+    uint64_t* it_out_ids;    // [nq][it_batch]
+    float* it_out_dists;     // [nq][it_batch]
+    uint32_t* it_counts;     // [nq]
 };
 
 hipError_t launch_search(int data_dtype, int metric, int qmode, const SearchArgs& a, hipStream_t stream);

@@ -21,7 +21,7 @@
 
 namespace svsx {
 
-template <int DT, int METRIC, int QMODE, int DS>
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false>
 __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
@@ -56,6 +56,32 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     const bool tag8 = a.filter_tag8 != 0u;
     const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + (a.filter_entries ? 256u : 0u)); // GENERAL only
+
+    // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
+    uint32_t* it_meta = nullptr;
+    uint32_t it_bs = 0;
+    bool resume = false;
+    if constexpr (GENERAL) {
+        if (a.it_meta != nullptr) {
+            it_meta = a.it_meta + static_cast<size_t>(qi) * 8;
+            it_bs = a.it_batch_sizes != nullptr ? a.it_batch_sizes[qi] : a.it_batch;
+            const bool skip = it_bs == 0xFFFFFFFFu;
+            const bool done = it_meta[4] == a.n || (it_meta[6] & 2u) != 0u;
+            if (skip || done) { // results_.clear() (:253-256); an untouched query reports nothing either
+                for (uint32_t j = lane; j < a.it_batch; j += 64) {
+                    a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + j] = ~0ull;
+                    a.it_out_dists[static_cast<size_t>(qi) * a.it_batch + j] = __builtin_inff();
+                }
+                if (lane == 0) a.it_counts[qi] = 0;
+                return;
+            }
+            if (it_bs > a.it_batch) it_bs = a.it_batch;
+            buf.window = it_meta[2] + it_bs;      // SearchBufferConfig::increment (search_buffer.h:70-73)
+            buf.capacity = it_meta[3] + it_bs;
+            resume = (it_meta[6] & 1u) == 0u;
+        }
+    }
     const uint32_t fmask = a.filter_entries - 1u;
     const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));
     for (uint32_t i = lane; i < filt_bytes / 4u; i += 64) reinterpret_cast<uint32_t*>(filt)[i] = 0xFFFFFFFFu;
@@ -102,7 +128,10 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     uint32_t n_exp = 0, n_slots = 0, n_eval = 0, n_ins = 0;
 
     // ---- EntryPointInitializer: distances to the entry points, push_back, sort --------------------------------
-    {
+    // (push_back + sort == ordered insert for <= 16 entry points, where std::sort is a stable insertion sort; the
+    //  GENERAL variant appends and runs the std::sort restatement, exact for any number of entry points)
+    const bool append_then_sort = GENERAL && a.n_entry > 16u;
+    if (!resume) {
         for (uint32_t base = 0; base < a.n_entry; base += RPP) {
             const uint32_t ci = base + grp;
             const bool act = ci < a.n_entry;
@@ -121,8 +150,8 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 }
                 if (buf.size < buf.capacity) {
                     // push_back + (stable) sort == ordered insert without the duplicate check
-                    uint32_t pos = 0;
-                    for (uint32_t i0 = 0; i0 < buf.size; i0 += 64) {
+                    uint32_t pos = append_then_sort ? buf.size : 0u;
+                    for (uint32_t i0 = 0; !append_then_sort && i0 < buf.size; i0 += 64) {
                         const uint32_t i = i0 + lane;
                         bool before = false;
                         if (i < buf.size) before = !cmpf<GREATER>(dd, __uint_as_float(buf.e[i].x));
@@ -140,8 +169,21 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         }
     }
 
+    if constexpr (GENERAL) {
+        if (resume) { // RestartInitializer (iterator.h:36-63): keep the previous contents, sort()
+            buf.size = it_meta[0];
+            buf.best_unvisited = it_meta[1];
+            const uint2* src = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
+            for (uint32_t i = lane; i < buf.size; i += 64) buf.e[i] = src[i];
+            lds_order();
+            wave_std_sort<GREATER>(buf, sort_stack, lane, true);
+        } else if (append_then_sort) {
+            wave_std_sort<GREATER>(buf, sort_stack, lane, false);
+        }
+    }
+
     bool full = buf.size == buf.capacity;
-    float worst = full ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
+    float worst = (full && buf.capacity > 0u) ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
 
     // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
     while (!wave_done(buf)) {
@@ -207,6 +249,58 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         }
     }
 
+    if constexpr (GENERAL) {
+        if (it_meta != nullptr) {
+            // ---- save the buffer for the next call; copy_from_scratch (iterator.h:104-124): the best entries not yet
+            // handed out, in buffer order, at most batch_size of them -------------------------------------------------------
+            uint2* dst = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
+            for (uint32_t i = lane; i < buf.size; i += 64) dst[i] = buf.e[i];
+            const uint32_t n_old = it_meta[4];
+            uint32_t* yl = a.it_yielded + static_cast<size_t>(qi) * a.it_ystride;
+            uint32_t got = 0;
+            for (uint32_t base = 0; base < buf.size && got < it_bs; base += 64) {
+                const uint32_t i = base + lane;
+                const bool valid = i < buf.size;
+                uint2 en = make_uint2(0u, kInvalidId);
+                if (valid) en = buf.e[i];
+                const uint32_t id = valid ? (en.y & kIdMask) : kInvalidId;
+                bool fresh = valid;
+                for (uint32_t y0 = 0; y0 < n_old; y0 += 64) {
+                    if (__ballot(fresh) == 0ull) break;
+                    uint32_t yv = kInvalidId;
+                    if (y0 + lane < n_old) yv = yl[y0 + lane];
+                    for (int t = 0; t < 64; ++t) {
+                        const uint32_t v = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(yv), t));
+                        fresh = fresh && (v != id);
+                    }
+                }
+                const unsigned long long fm = __ballot(fresh);
+                const uint32_t rank = got + __popcll(fm & ((1ull << lane) - 1ull));
+                if (fresh && rank < it_bs) {
+                    a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + rank] = static_cast<uint64_t>(id) + a.id_offset;
+                    a.it_out_dists[static_cast<size_t>(qi) * a.it_batch + rank] = __uint_as_float(en.x);
+                    yl[n_old + rank] = id;
+                }
+                const uint32_t add = __popcll(fm);
+                got = (got + add < it_bs) ? got + add : it_bs;
+            }
+            for (uint32_t j = got + lane; j < a.it_batch; j += 64) {
+                a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + j] = ~0ull;
+                a.it_out_dists[static_cast<size_t>(qi) * a.it_batch + j] = __builtin_inff();
+            }
+            if (lane == 0) {
+                a.it_counts[qi] = got;
+                it_meta[0] = buf.size;
+                it_meta[1] = buf.best_unvisited;
+                it_meta[2] = buf.window;
+                it_meta[3] = buf.capacity;
+                it_meta[4] = n_old + got;
+                it_meta[5] = it_meta[5] + 1u;
+                it_meta[6] = (got == 0u && it_bs > 0u) ? 2u : 0u; // restart_search_ = false; is_exhausted_ (:311-316)
+            }
+        }
+    }
+
     // ---- copy-back (extensions.h:588-590), padded like vamana_index_impl.h:205-209 -----------------------------
     for (uint32_t j = lane; j < a.k; j += 64) {
         uint32_t id = kInvalidId;
@@ -237,15 +331,16 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, int METRIC, int QMODE, int DS> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
     const int d = static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
-                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) + 64 * 4 : 0);
+                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) + 64 * 4 : 0) +
+                       (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = search_kernel<DT, METRIC, QMODE, DS>;
+    auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
@@ -255,6 +350,7 @@ template <int DT, int METRIC, int QMODE, int DS> static hipError_t launch_one(co
 }
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
+    if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         if (a.d == 96) return launch_one<DT, METRIC, QMODE, 96>(a, stream);
         if (a.d == 128) return launch_one<DT, METRIC, QMODE, 128>(a, stream);

@@ -200,6 +200,12 @@ class VamanaIndex:
         res = QueryResult(ids, dists)
         return (res, st) if stats else res
 
+    def batch_iterator(self, queries, extra_search_buffer_capacity: int | None = None):
+        """VamanaIndex::make_batch_iterator (index/vamana/index.h:936), one iterator per query of the batch."""
+        from .iterator import BatchIterator
+
+        return BatchIterator(self, queries, extra_search_buffer_capacity)
+
     def flat_search_device(self, d_queries, num_neighbors: int, d_ids64=None, d_dists=None, q_dtype=None, stream=None):
         """Exhaustive search (FlatIndex::search, index/flat/flat.h:322-460) on torch CUDA tensors: MFMA f16 shortlist +
         exact re-rank.  Returns (ids int64 [nq,k], dists f32 [nq,k])."""

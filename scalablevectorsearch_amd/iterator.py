@@ -1,0 +1,205 @@
+"""Batched BatchIterator and the two searches the reference's runtime builds on it.
+
+Mirrors (host side, over the C ABI `svsx_iterator_*` of include/svsx.h):
+  svs::index::vamana::BatchIterator                index/vamana/iterator.h:81-339
+  VamanaIndex::make_batch_iterator                 index/vamana/index.h:936
+  runtime filtered search (IDFilter)               bindings/cpp/src/vamana_index_impl.h:140-218
+  runtime range_search                             bindings/cpp/src/vamana_index_impl.h:220-326
+One iterator object drives one independent reference-style iterator PER QUERY of the batch; every next() is one
+kernel launch that resumes all live queries from the search buffers kept in HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .index import QueryResult, VamanaSearchParameters, dtype_code
+
+SKIP = 0xFFFFFFFF  # per-query batch size meaning "leave this query untouched"
+UNSIGNED_INTEGER_PLACEHOLDER = (1 << 64) - 1  # lib/preprocessor.h:177
+
+
+class BatchIterator:
+    """`index.batch_iterator(queries)`; `next(batch_size)` yields, per query, the next best neighbours not yet yielded."""
+
+    def __init__(self, index, queries, extra_search_buffer_capacity: int | None = None):
+        queries = np.ascontiguousarray(np.atleast_2d(queries))
+        if queries.shape[1] != index.d:  # detail::checkdims (iterator.h:66-74)
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Incompatible dimensions. Query has {queries.shape[1]} while the index expects {index.d}.")
+        self.index = index
+        self.nq = queries.shape[0]
+        self._qdtype = queries.dtype
+        self._h = C.c_void_p()
+        extra = UNSIGNED_INTEGER_PLACEHOLDER if extra_search_buffer_capacity is None else int(extra_search_buffer_capacity)
+        _lib.check(_lib.lib().svsx_iterator_create(index._h, queries.ctypes.data, dtype_code(queries), self.nq, extra, C.byref(self._h)))
+        self._ids = np.zeros((self.nq, 0), np.uint64)
+        self._dists = np.zeros((self.nq, 0), np.float32)
+        self._counts = np.zeros(self.nq, np.uint32)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().svsx_iterator_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    def next(self, batch_size: int, batch_sizes=None):
+        """BatchIterator::next for every query.  Returns (ids uint64 [nq, batch_size], dists [nq, batch_size], counts [nq]);
+        row i holds counts[i] results (best first), the rest is padded with all-ones / +inf."""
+        batch_size = int(batch_size)
+        ids = np.empty((self.nq, batch_size), np.uint64)
+        dists = np.empty((self.nq, batch_size), np.float32)
+        counts = np.empty(self.nq, np.uint32)
+        bs = None
+        if batch_sizes is not None:
+            bs = np.ascontiguousarray(batch_sizes, dtype=np.uint32)
+            if bs.shape != (self.nq,):
+                raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "batch_sizes must have one entry per query")
+            if np.any((bs != SKIP) & (bs > batch_size)):
+                raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "per-query batch sizes must not exceed batch_size")
+        _lib.check(_lib.lib().svsx_iterator_next(self._h, batch_size, None if bs is None else bs.ctypes.data, ids.ctypes.data,
+                                                 dists.ctypes.data, counts.ctypes.data))
+        self._ids, self._dists, self._counts = ids, dists, counts
+        return ids, dists, counts
+
+    def next_device(self, batch_size: int, d_ids64, d_dists, d_counts, d_batch_sizes=None, stream=None):
+        """Same with torch CUDA tensors (ids int64/uint64 [nq, batch_size], dists f32, counts int32/uint32 [nq])."""
+        _lib.check(_lib.lib().svsx_iterator_next_device(
+            self._h, int(batch_size), None if d_batch_sizes is None else d_batch_sizes.data_ptr(), d_ids64.data_ptr(),
+            d_dists.data_ptr(), d_counts.data_ptr(), None if stream is None else stream.cuda_stream))
+
+    def contents(self, i: int):
+        """Current batch of query i (BatchIterator::contents, iterator.h:221)."""
+        c = int(self._counts[i])
+        return self._ids[i, :c], self._dists[i, :c]
+
+    def size(self) -> np.ndarray:
+        return self._counts.copy()
+
+    def state(self) -> np.ndarray:
+        meta = np.empty((self.nq, 8), np.uint32)
+        _lib.check(_lib.lib().svsx_iterator_state(self._h, meta.ctypes.data))
+        return meta
+
+    def done(self) -> np.ndarray:  # iterator.h:230
+        m = self.state()
+        return (m[:, 4] == self.index.n) | ((m[:, 6] & 2) != 0)
+
+    def batch_number(self) -> np.ndarray:  # iterator.h:227
+        return self.state()[:, 5].copy()
+
+    def parameters_for_current_iteration(self):  # iterator.h:236-245: (search window, capacity) per query
+        m = self.state()
+        return m[:, 2].copy(), m[:, 3].copy()
+
+    def restart_next_search(self) -> None:
+        _lib.check(_lib.lib().svsx_iterator_restart_next_search(self._h))
+
+    def update(self, queries) -> None:
+        queries = np.ascontiguousarray(np.atleast_2d(queries))
+        if queries.shape != (self.nq, self.index.d) or queries.dtype != self._qdtype:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Incompatible dimensions. Query has {queries.shape[1]} while the index expects {self.index.d}.")
+        _lib.check(_lib.lib().svsx_iterator_update(self._h, queries.ctypes.data))
+        self._counts[:] = 0
+
+
+def predict_further_processing(processed, hits, goal, hint, max_value):
+    """bindings/cpp/src/svs_runtime_utils.h:411-419 (float arithmetic as there)."""
+    if hits == 0 or hits >= goal:
+        return min(int(hint), int(max_value))
+    batch = np.float32(goal - hits) * np.float32(processed) / np.float32(hits)
+    return min(max(int(batch), 1), int(max_value))
+
+
+def should_stop_filtered_search(total_checked, found, filter_stop):
+    """svs_runtime_utils.h:424-434"""
+    if filter_stop <= 0 or total_checked == 0:
+        return False
+    if found == 0:
+        return True
+    return np.float32(found) / np.float32(total_checked) < np.float32(filter_stop)
+
+
+def filtered_search(index, queries, k: int, is_member, search_parameters: VamanaSearchParameters | None = None,
+                    filter_stop: float = 0.0, extra_search_buffer_capacity: int | None = None, make_iterator=None) -> QueryResult:
+    """Runtime VamanaIndex::search with an IDFilter (vamana_index_impl.h:140-218) with filter_estimate_batch = false:
+    per query, pull adaptive batches from the iterator until k members of the filter are found.
+    `is_member`: boolean array over ids.  Unfilled slots: id all-ones, distance +inf."""
+    queries = np.ascontiguousarray(np.atleast_2d(queries))
+    nq = queries.shape[0]
+    member = np.asarray(is_member, dtype=bool)
+    sp = search_parameters or index.get_search_parameters()
+    sws = sp.buffer_config.get_search_window_size()
+    max_batch = index.size()
+    it = (make_iterator or BatchIterator)(index, queries, extra_search_buffer_capacity)
+    ids = np.full((nq, k), np.iinfo(np.uint64).max, np.uint64)
+    dists = np.full((nq, k), np.inf, np.float32)
+    found = np.zeros(nq, np.int64)
+    checked = np.zeros(nq, np.int64)
+    batch = np.full(nq, max(k, sws), np.int64)
+    active = np.ones(nq, bool)
+    while active.any():
+        for i in np.flatnonzero(active):
+            batch[i] = predict_further_processing(checked[i], found[i], k, batch[i], max_batch)
+        per_query = np.where(active, batch, SKIP).astype(np.uint32)
+        b_ids, b_dists, counts = it.next(int(batch[active].max()), per_query)
+        done = it.done()
+        for i in np.flatnonzero(active):
+            c = int(counts[i])
+            checked[i] += c
+            for j in range(c):
+                if member[int(b_ids[i, j])]:
+                    ids[i, found[i]] = b_ids[i, j]
+                    dists[i, found[i]] = b_dists[i, j]
+                    found[i] += 1
+                    if found[i] == k:
+                        break
+            if should_stop_filtered_search(checked[i], found[i], filter_stop):
+                found[i] = 0
+                ids[i, :] = np.iinfo(np.uint64).max
+                dists[i, :] = np.inf
+                active[i] = False
+            elif found[i] >= k or done[i]:
+                active[i] = False
+    return QueryResult(ids, dists)
+
+
+def range_search(index, queries, radius: float, search_parameters: VamanaSearchParameters | None = None, is_member=None,
+                 extra_search_buffer_capacity: int | None = None, make_iterator=None):
+    """Runtime VamanaIndex::range_search (vamana_index_impl.h:220-326): everything closer than `radius` the iterator
+    reaches before its first out-of-range neighbour.  Returns FAISS-style (lims [nq+1], labels, distances)."""
+    if radius <= 0:
+        raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "radius must be greater than 0")
+    queries = np.ascontiguousarray(np.atleast_2d(queries))
+    nq = queries.shape[0]
+    sp = search_parameters or index.get_search_parameters()
+    batch = max(sp.buffer_config.get_search_window_size(), 10)
+    greater = int(index.distance.metric) != 0
+    it = (make_iterator or BatchIterator)(index, queries, extra_search_buffer_capacity)
+    member = None if is_member is None else np.asarray(is_member, dtype=bool)
+    res = [[] for _ in range(nq)]
+    active = np.ones(nq, bool)
+    while active.any():
+        per_query = np.where(active, batch, SKIP).astype(np.uint32)
+        b_ids, b_dists, counts = it.next(batch, per_query)
+        done = it.done()
+        for i in np.flatnonzero(active):
+            in_range = True
+            for j in range(int(counts[i])):
+                dd = b_dists[i, j]
+                in_range = bool(dd > radius) if greater else bool(dd < radius)
+                if not in_range:
+                    break
+                if member is None or member[int(b_ids[i, j])]:
+                    res[i].append((int(b_ids[i, j]), dd))
+            if not in_range or done[i]:
+                active[i] = False
+    lims = np.zeros(nq + 1, np.int64)
+    lims[1:] = np.cumsum([len(r) for r in res])
+    labels = np.array([p[0] for r in res for p in r], np.uint64)
+    distances = np.array([p[1] for r in res for p in r], np.float32)
+    return lims, labels, distances

@@ -3,6 +3,7 @@
 SearchBuffer, VisitedFilter and simd::generic_simd_op compiled from /root/reference/include).
 
 Run in the build container (needs /root/reference and an AVX-512 host):  python tests/golden/make_golden.py
+(`python tests/golden/make_golden.py iterator` regenerates only iterator.npz.)
 The .npz files hold only inputs and expected outputs (data), no reference source.
 """
 import os
@@ -28,7 +29,57 @@ def gen(rng, dt, n, d):
     return rng.integers(0, 256, (n, d)).astype(np.uint8)
 
 
+SCHEDULES = [[10] * 10, [20, 5, 50, 1, 0, 7, 100], [64, 64, 64], [400, 400]]
+
+
+def make_iterator_golden():
+    """BatchIterator known answers: the reference's SearchBuffer / greedy_search / EntryPointInitializer / std::sort driven
+    with iterator.h's control flow (oracle/ref_driver.cpp svsref_iterate), on a set with duplicated vectors so that
+    exactly tied distances occur in every buffer."""
+    ref, orc = Ref(), Oracle()
+    rng = np.random.default_rng(20260927)
+    n, d, nq = 600, 40, 6
+    a = np.random.default_rng(7).standard_normal((12, d)).astype(np.float32)
+    base = (rng.standard_normal((n // 2, 12)).astype(np.float32) @ a + 0.1 * rng.standard_normal((n // 2, d)).astype(np.float32)).astype(np.float32)
+    x = np.concatenate([base, base[rng.permutation(n // 2)]])[rng.permutation(n)]  # every vector appears twice
+    q = (rng.standard_normal((nq, 12)).astype(np.float32) @ a + 0.1 * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+    graph, entry = orc.build_vamana(L2, x, R=16, L=32)
+    out = dict(x=x, q=q, graph=graph, entry=entry, n_schedules=np.array(len(SCHEDULES)))
+    for m, xv, tag in ((L2, x, "l2_f32"), (IP, x.astype(np.float16), "ip_f16")):
+        for si, sched in enumerate(SCHEDULES):
+            out[f"sched_{si}"] = np.array(sched, np.int64)
+            for qi in range(nq):
+                res, done = ref.iterate(m, xv, graph, entry, q[qi], sched)
+                out[f"{tag}_{si}_{qi}_counts"] = np.array([len(r[0]) for r in res], np.int64)
+                out[f"{tag}_{si}_{qi}_ids"] = np.concatenate([r[0] for r in res]) if res else np.zeros(0, np.uint32)
+                out[f"{tag}_{si}_{qi}_dists"] = np.concatenate([r[1] for r in res]) if res else np.zeros(0, np.float32)
+                out[f"{tag}_{si}_{qi}_done"] = np.array(done, np.uint8)
+        # restart_next_search before calls 2 and 4
+        rb = [0, 0, 1, 0, 1, 0]
+        res, done = ref.iterate(m, xv, graph, entry, q[0], [15] * 6, restart_before=rb)
+        out[f"{tag}_restart_ids"] = np.concatenate([r[0] for r in res])
+        out[f"{tag}_restart_dists"] = np.concatenate([r[1] for r in res])
+    # std::sort on sorted-with-ties and unsorted buffers (SearchBuffer::sort, search_buffer.h:408)
+    for t in range(12):
+        m_ = int(rng.integers(17, 400))
+        vals = rng.integers(0, max(2, m_ // int(rng.integers(2, 8))), m_).astype(np.float32)
+        greater = bool(t & 1)
+        if t % 3:
+            vals = np.sort(vals)[::-1 if greater else 1].copy()
+        b = ref.buffer(m_, m_, greater)
+        for i, v in enumerate(vals):
+            b.push_back(i, float(v))
+        b.sort()
+        out[f"sort_{t}_in"] = vals
+        out[f"sort_{t}_greater"] = np.array(int(greater))
+        out[f"sort_{t}_ids"] = np.array([e[0] for e in b.state()], np.uint32)
+    np.savez_compressed(os.path.join(HERE, "iterator.npz"), **out)
+    print("iterator.npz", os.path.getsize(os.path.join(HERE, "iterator.npz")))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "iterator":
+        return make_iterator_golden()
     ref, orc = Ref(), Oracle()
     rng = np.random.default_rng(20260926)
 
@@ -102,6 +153,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "buffer_trace.npz"), **t)
     for f in ("distances.npz", "search.npz", "buffer_trace.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
+    make_iterator_golden()
 
 
 if __name__ == "__main__":
