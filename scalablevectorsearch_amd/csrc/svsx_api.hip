@@ -717,7 +717,7 @@ int svsx_iterator_next_device(
     uint32_t* d_counts, void* hip_stream
 ) {
     if (!it) return fail(SVSX_NOT_INITIALIZED, "Iterator not initialized");
-    if (!d_ids64 || !d_dists || !d_counts) return fail(SVSX_INVALID_ARGUMENT, "null output");
+    if ((batch_size && (!d_ids64 || !d_dists)) || !d_counts) return fail(SVSX_INVALID_ARGUMENT, "null output");
     if (batch_size >= 0xFFFFFFFFull) return fail(SVSX_INVALID_ARGUMENT, "batch size too large");
     const svsx_index* ix = it->ix;
     const size_t cap = it->max_capacity + batch_size;
@@ -754,7 +754,7 @@ int svsx_iterator_next(
     svsx_batch_iterator* it, size_t batch_size, const uint32_t* batch_sizes, uint64_t* ids64, float* dists, uint32_t* counts
 ) {
     if (!it) return fail(SVSX_NOT_INITIALIZED, "Iterator not initialized");
-    if (!ids64 || !dists || !counts) return fail(SVSX_INVALID_ARGUMENT, "null output");
+    if ((batch_size && (!ids64 || !dists)) || !counts) return fail(SVSX_INVALID_ARGUMENT, "null output");
     HIP_TRY(hipSetDevice(it->ix->device));
     CallStream cs;
     HIP_TRY(cs.create());
