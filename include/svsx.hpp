@@ -7,6 +7,7 @@
 //   svs::QueryResult<size_t>                                               core/query_result.h:53-172
 //   svs::distance::DistanceL2 / DistanceIP / DistanceCosineSimilarity      core/distance/*.h (compare, implicit_broadcast)
 //   svs::ANNException                                                      lib/exception.h
+//   svs::index::vamana::BatchIterator (one per query of a batch)           index/vamana/iterator.h:81-339
 // so that a caller written against the reference reads the same:  index.search(result.view(), queries, params).
 #pragma once
 
@@ -125,6 +126,65 @@ template <typename T, typename Dist> class VamanaIndex {
         QueryResult<size_t> r(nq, k);
         search(r.view(), queries, defaults_);
         return r;
+    }
+    const svsx_index* handle() const { return h_; }
+    size_t size() const { uint64_t info[6]; check(svsx_index_info(h_, info)); return info[0]; }
+};
+
+// svs::Neighbor<size_t> as yielded by the iterator (core/query_result.h / lib/neighbor.h)
+struct Neighbor {
+    size_t id_;
+    float distance_;
+    size_t id() const { return id_; }
+    float distance() const { return distance_; }
+};
+
+// index/vamana/iterator.h:81-339 for a BATCH of queries: query q behaves exactly like the reference's
+// BatchIterator{index, queries[q], extra_search_buffer_capacity}; next() advances all of them with one kernel launch.
+template <typename Q> class BatchIterator {
+    svsx_batch_iterator* h_ = nullptr;
+    size_t nq_ = 0, n_ = 0, stride_ = 0;
+    std::vector<uint64_t> ids_;
+    std::vector<float> dists_;
+    std::vector<uint32_t> counts_;
+    std::vector<Neighbor> results_;
+    mutable std::vector<uint32_t> meta_;
+    void refresh() const { meta_.resize(nq_ * 8); check(svsx_iterator_state(h_, meta_.data())); }
+  public:
+    static constexpr uint32_t skip = 0xFFFFFFFFu;
+    template <typename T, typename Dist>
+    BatchIterator(const VamanaIndex<T, Dist>& parent, const Q* queries, size_t nq,
+                  size_t extra_search_buffer_capacity = std::numeric_limits<size_t>::max())
+        : nq_(nq), n_(parent.size()), counts_(nq, 0) {
+        check(svsx_iterator_create(parent.handle(), queries, dtype_of<Q>(), nq, extra_search_buffer_capacity, &h_));
+    }
+    BatchIterator(const BatchIterator&) = delete;
+    BatchIterator& operator=(const BatchIterator&) = delete;
+    ~BatchIterator() { svsx_iterator_destroy(h_); }
+
+    // BatchIterator::next (:249-317); per_query (optional): batch size of each query, `skip` leaves a query untouched
+    void next(size_t batch_size, const uint32_t* per_query = nullptr) {
+        stride_ = batch_size;
+        ids_.resize(nq_ * batch_size);
+        dists_.resize(nq_ * batch_size);
+        check(svsx_iterator_next(h_, batch_size, per_query, ids_.data(), dists_.data(), counts_.data()));
+    }
+    void update(const Q* queries) { check(svsx_iterator_update(h_, queries)); std::fill(counts_.begin(), counts_.end(), 0u); }
+    void restart_next_search() { check(svsx_iterator_restart_next_search(h_)); }
+
+    size_t size(size_t q) const { return counts_[q]; }                                       // :224
+    std::span<const Neighbor> contents(size_t q) {                                           // :221
+        results_.resize(counts_[q]);
+        for (size_t j = 0; j < counts_[q]; ++j) results_[j] = Neighbor{static_cast<size_t>(ids_[q * stride_ + j]), dists_[q * stride_ + j]};
+        return {results_.data(), results_.size()};
+    }
+    size_t batch_number(size_t q) const { refresh(); return meta_[q * 8 + 5]; }             // :227
+    bool done(size_t q) const { refresh(); return meta_[q * 8 + 4] == n_ || (meta_[q * 8 + 6] & 2u); } // :230
+    VamanaSearchParameters parameters_for_current_iteration(size_t q) const {               // :236-245
+        refresh();
+        VamanaSearchParameters p{};
+        p.buffer_config_ = SearchBufferConfig(meta_[q * 8 + 2], meta_[q * 8 + 3]);
+        return p;
     }
 };
 

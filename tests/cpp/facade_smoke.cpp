@@ -23,7 +23,22 @@ int main(int argc, char**) {
         svsx::QueryResult<size_t> result(1, 3);
         index.search(result.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}));
         std::printf("%zu %zu %zu\n", result.index(0, 0), result.index(0, 1), result.index(0, 2));
-        return (result.index(0, 0) == 5 && result.index(0, 1) == 6 && result.index(0, 2) == 4) ? 0 : 1;
+        if (!(result.index(0, 0) == 5 && result.index(0, 1) == 6 && result.index(0, 2) == 4)) return 1;
+        // BatchIterator: 8 points on a ring, batches of 3 -> 5 6 4 | 7 3 2 | 1 0 | (done)
+        svsx::BatchIterator<float> it(index, q.data(), 1);
+        const size_t want[8] = {5, 6, 4, 7, 3, 2, 1, 0};
+        size_t seen = 0;
+        for (size_t batch = 1; !it.done(0); ++batch) {
+            it.next(3);
+            if (it.batch_number(0) != batch) return 3;
+            for (const auto& nb : it.contents(0)) {
+                std::printf("batch %zu: %zu %g\n", batch, nb.id(), nb.distance());
+                if (seen >= 8 || nb.id() != want[seen++]) return 4;
+            }
+        }
+        if (seen != 8) return 5;
+        it.next(3);
+        return it.size(0) == 0 ? 0 : 6;
     } catch (const svsx::ANNException& e) {
         std::printf("ANNException(%d): %s\n", e.code, e.what());
         return 2;
