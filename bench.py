@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the multi-GPU code path (RCCL all-gather + merge) even at world size 1")
     ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
+    ap.add_argument("--bound-codes", type=int, default=0, help="1: build the 128-B bound-code rows (result-neutral lower-bound rejection)")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph here (lets a profiler run skip the build)")
     args = ap.parse_args()
 
@@ -148,6 +149,8 @@ def main():
 
     d_entry = torch.tensor([entry], dtype=torch.int32, device=device)
     index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n, d, np.float32, device=local_rank, id_offset=rank * n)
+    if args.bound_codes:
+        index.build_bound_codes()
     sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window), search_buffer_visited_set=args.visited)
 
     ids = torch.empty((nq, k), dtype=torch.int64, device=device)  # written as uint64
@@ -253,7 +256,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     shard_queries_per_s = world * nq * args.steps / elapsed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(n, nq, args.window, R, args.visited) if not multi else (None, None)
+    traffic, traffic_src = measured_traffic(n, nq, args.window, R, args.visited, args.bound_codes) if not multi else (None, None)
     result = {
         "metric": "QPS at recall@10>=0.9 (batch=10k); achieved HBM GB/s vs roofline",
         "value": shard_queries_per_s,
@@ -280,6 +283,8 @@ def main():
             "visited_filter": args.visited,
             "distance_evals_per_query": int(st[:, 2].sum()) / nq,
             "partial_distance_rejects_per_query": int(st[:, 4].sum()) / nq,
+            "bound_codes": args.bound_codes,
+            "bound_code_rejects_per_query": int(st[:, 5].sum()) / nq,
         },
         "roofline": {
             "bound": "hbm",
@@ -338,7 +343,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(n, nq, window, degree, visited):
+def measured_traffic(n, nq, window, degree, visited, bound_codes=0):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_pmc.json, produced by tools/collect_pmc.sh: separate --pmc passes, gfx950 FETCH_SIZE x2 correction
     calibrated on a known stream).  bench.py cannot host the profiler itself; returns (None, None) if no pass matches."""
@@ -347,7 +352,10 @@ def measured_traffic(n, nq, window, degree, visited):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
             j = json.load(open(f))
-            if j["workload"] == {"n": n, "d": 96, "nq": nq, "window": window, "degree": degree, "visited": visited}:
+            want = {"n": n, "d": 96, "nq": nq, "window": window, "degree": degree, "visited": visited}
+            if bound_codes:
+                want["bound_codes"] = bound_codes
+            if j["workload"] == want:
                 return float(j["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             continue

@@ -100,7 +100,7 @@ typedef struct {
 
 /* Optional side outputs of a search (device pointers for svsx_search_device, host for svsx_search).
  *   stats        nq x 6 u32: {expansions, neighbour slots, distance evaluations started, accepted inserts,
- *                candidates rejected after a partial (lower-bound) distance, reserved}; the first two are
+ *                candidates rejected after a partial (lower-bound) distance, candidates rejected by their bound codes}; the first two are
  *                the GreedySearchTracker counts of greedy_search.h:165 / search_tracker.h:29-62
  *   history_*    per query, the expanded nodes in order (id, distance) -- the builder's
  *                use_full_search_history pool (vamana_build.h:54-91); history_len may exceed history_cap. */
@@ -210,6 +210,14 @@ int svsx_iterator_next_device(
  * (parameters_for_current_iteration, iterator.h:236-245), [4] ids yielded so far, [5] batch_number() (:227),
  * [6] flags: 1 = next search restarts from the entry points, 2 = exhausted; done() (:230) = [4] == n || flags & 2. */
 int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
+
+/* Bound codes (no reference counterpart; result-neutral): builds, next to the vectors, one 128-byte row per vector with
+ * 8-bit codes of its first min(d, 120) components and the exact coding error.  The search kernel turns them into a
+ * rigorous LOWER BOUND of the L2 distance and drops candidates that can_skip (search_buffer.h:338-340) would drop anyway
+ * before their full row is fetched -- ids and distances returned are unchanged, HBM traffic per candidate falls from 3
+ * lines to about 1.  float32 data, L2, d = 96 or 128 (SVSX_NOT_IMPLEMENTED otherwise); +128 B of HBM per vector.
+ * enable = 0 frees them.  Call while no search is in flight on this index. */
+int svsx_index_build_bound_codes(svsx_index* index, int enable);
 
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),
  * [5]=data row stride (bytes). */

@@ -61,7 +61,7 @@ EXPORTS = [
     "svsx_index_create", "svsx_index_create_device_view", "svsx_index_destroy", "svsx_search", "svsx_search_device",
     "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
     "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
-    "svsx_iterator_next_device", "svsx_iterator_state",
+    "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes",
 ]
 
 _lib = None
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         L.svsx_iterator_next.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_iterator_next_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_iterator_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.svsx_index_build_bound_codes.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 

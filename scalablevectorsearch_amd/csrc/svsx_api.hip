@@ -37,6 +37,9 @@ struct svsx_index {
     mutable std::mutex shadow_mutex;
     mutable void* d_half = nullptr;
     mutable float* d_norm2 = nullptr;
+    // bound codes (svsx_index_build_bound_codes): 128 B per vector
+    void* d_codes = nullptr;
+    float code_scale = 1.0f, code_bias = 0.0f;
 };
 
 namespace {
@@ -246,6 +249,7 @@ void svsx_index_destroy(svsx_index* ix) {
     }
     if (ix->d_half) (void)hipFree(ix->d_half);
     if (ix->d_norm2) (void)hipFree(ix->d_norm2);
+    if (ix->d_codes) (void)hipFree(ix->d_codes);
     delete ix;
 }
 
@@ -257,6 +261,43 @@ int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
     info[3] = ix->gstride * ix->n * sizeof(uint32_t);
     info[4] = ix->gstride;
     info[5] = ix->row_bytes;
+    return SVSX_SUCCESS;
+}
+
+int svsx_index_build_bound_codes(svsx_index* ix, int enable) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    HIP_TRY(hipSetDevice(ix->device));
+    std::lock_guard<std::mutex> lock(ix->shadow_mutex);
+    if (!enable) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ix->d_codes) (void)hipFree(ix->d_codes);
+        ix->d_codes = nullptr;
+        return SVSX_SUCCESS;
+    }
+    if (ix->d_codes) return SVSX_SUCCESS;
+    if (ix->metric != M_L2 || ix->data_dtype != DT_F32 || ix->sq_enabled || (ix->d != 96 && ix->d != 128))
+        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 L2 indexes of dimension 96 or 128");
+    const uint32_t dc = static_cast<uint32_t>(ix->d < 120 ? ix->d : 120);
+    DeviceBuffer mm;
+    HIP_TRY(mm.alloc(12));
+    HIP_TRY(launch_codes_minmax(ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, static_cast<uint32_t*>(mm.p), nullptr));
+    uint32_t h[3];
+    HIP_TRY(hipMemcpy(h, mm.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[2] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
+    const float lo = codes_key_to_float(h[0]), hi = codes_key_to_float(h[1]);
+    float scale = (hi - lo) / 255.0f;
+    if (!(scale > 0.0f) || !(scale < 3.0e38f)) scale = 1.0f;
+    void* codes = nullptr;
+    HIP_TRY(hipMalloc(&codes, ix->n * 128 + 128));
+    hipError_t e = launch_codes_build(ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, scale, lo, codes, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(codes);
+        return fail(SVSX_RUNTIME_ERROR, "bound code kernel failed: %s", hipGetErrorString(e));
+    }
+    ix->code_scale = scale;
+    ix->code_bias = lo;
+    ix->d_codes = codes;
     return SVSX_SUCCESS;
 }
 
@@ -279,6 +320,11 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     a.q_row_bytes = q_row_bytes;
     a.nq = static_cast<uint32_t>(nq);
     a.general = ix->n_entry > 16 ? 1u : 0u; // std::sort of > 16 entry points is not a stable insertion sort
+    if (ix->d_codes && !a.general) { // result-neutral lower-bound rejection (float queries on float32 L2 rows)
+        a.codes = static_cast<const unsigned char*>(ix->d_codes);
+        a.code_scale = ix->code_scale;
+        a.code_bias = ix->code_bias;
+    }
     return a;
 }
 
@@ -730,6 +776,7 @@ int svsx_iterator_next_device(
     if (int rc = grow_rows(it->d_yielded, it->ystride, ybound ? ybound : 1, it->nq, it->ystride)) return rc;
     SearchArgs a = base_search_args(ix, it->d_queries, it->q_dtype, it->q_stride, it->nq);
     a.general = 1;
+    a.codes = nullptr;
     a.window = static_cast<uint32_t>(cap); // per-query values come from the state table; this sizes the LDS buffer
     a.capacity = static_cast<uint32_t>(cap);
     default_filter(ix, a, (ix->n >> 12) < 0xFFu ? 4096u : kDefaultFilterEntries); // result-neutral within one call

@@ -136,6 +136,92 @@ __global__ void pack_graph_kernel(const uint32_t* __restrict__ in, uint32_t in_s
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Bound codes (svsx_index_build_bound_codes): one 128-B row per vector = u8 codes of its first min(d, 120) components
+// under one global (scale, bias), zero padding, then at byte 120 ||x_C - xhat||_2 rounded UP (f32) and at byte 124
+// sum(code^2) (i32).  The search kernel derives a rigorous lower bound of the L2 distance from them (svsx_search.hip).
+__device__ __forceinline__ uint32_t order_key(float f) { // monotone float -> u32
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void codes_minmax_kernel(const float* __restrict__ data, size_t row_floats, uint32_t n, uint32_t dc, uint32_t* __restrict__ mm) {
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    bool bad = false;
+    for (size_t r = blockIdx.x; r < n; r += gridDim.x) {
+        for (uint32_t j = threadIdx.x; j < dc; j += blockDim.x) {
+            const float v = data[r * row_floats + j];
+            bad = bad || !(__builtin_fabsf(v) <= 3.0e38f);
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(mm + 2, 1u);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicMin(mm, order_key(lo));
+        atomicMax(mm + 1, order_key(hi));
+    }
+}
+
+__global__ void codes_build_kernel(const float* __restrict__ data, size_t row_floats, uint32_t n, uint32_t dc, float scale, float bias,
+                                   unsigned char* __restrict__ codes) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* x = data + static_cast<size_t>(r) * row_floats;
+    uint32_t* out = reinterpret_cast<uint32_t*>(codes + static_cast<size_t>(r) * 128);
+    const float inv = 1.0f / scale;
+    double err2 = 0.0;
+    int xx = 0;
+    for (uint32_t w = 0; w < 30; ++w) {
+        uint32_t packed = 0;
+        for (uint32_t t = 0; t < 4; ++t) {
+            const uint32_t j = w * 4 + t;
+            if (j < dc) {
+                const float v = x[j];
+                float c = __builtin_rintf((v - bias) * inv);
+                c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
+                const int ci = static_cast<int>(c);
+                const double e = static_cast<double>(v) - (static_cast<double>(bias) + static_cast<double>(scale) * static_cast<double>(ci));
+                err2 += e * e;
+                xx += ci * ci;
+                packed |= static_cast<uint32_t>(ci) << (8 * t);
+            }
+        }
+        out[w] = packed;
+    }
+    float ex = static_cast<float>(__builtin_sqrt(err2) * (1.0 + 1e-9));
+    ex = __uint_as_float(__float_as_uint(ex) + 2u); // round up (ex >= 0): the stored value bounds the true error from above
+    out[30] = __float_as_uint(ex);
+    out[31] = static_cast<uint32_t>(xx);
+}
+
+hipError_t launch_codes_minmax(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, uint32_t* d_mm3, hipStream_t stream) {
+    const uint32_t init[3] = {0xFFFFFFFFu, 0u, 0u};
+    hipError_t e = hipMemcpyAsync(d_mm3, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t blocks = n < 4096u ? n : 4096u;
+    hipLaunchKernelGGL(codes_minmax_kernel, dim3(blocks), dim3(64), 0, stream, static_cast<const float*>(d_data), row_bytes / 4, n, dc, d_mm3);
+    return hipGetLastError();
+}
+
+float codes_key_to_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+hipError_t launch_codes_build(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, float scale, float bias, void* d_codes, hipStream_t stream) {
+    hipLaunchKernelGGL(codes_build_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, static_cast<const float*>(d_data), row_bytes / 4, n, dc, scale, bias,
+                       static_cast<unsigned char*>(d_codes));
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_graph(const uint32_t* d_in, uint32_t in_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, uint32_t* d_bad, hipStream_t stream) {
     hipLaunchKernelGGL(pack_graph_kernel, dim3(n), dim3(64), 0, stream, d_in, in_stride, n, d_out, out_stride, d_bad);
     return hipGetLastError();

@@ -37,6 +37,9 @@ struct SearchArgs {
     float* history_dists;
     uint32_t* history_len;
     uint32_t history_cap;
+    // optional 128-B bound-code rows (f32 L2, d = 96 or 128): rigorous lower-bound rejection before a row is fetched
+    const unsigned char* codes;
+    float code_scale, code_bias;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
     uint32_t general;
     // BatchIterator (index/vamana/iterator.h): per-query state in HBM.  meta = 8 u32 per query:
@@ -121,6 +124,10 @@ struct RerankArgs {
 hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
 
 // layout conversion kernels (index creation)
+// bound codes (svsx_index_build_bound_codes): d_mm3 = {min key, max key, non-finite count}
+hipError_t launch_codes_minmax(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, uint32_t* d_mm3, hipStream_t stream);
+float codes_key_to_float(uint32_t key);
+hipError_t launch_codes_build(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, float scale, float bias, void* d_codes, hipStream_t stream);
 hipError_t launch_pack_graph(const uint32_t* d_svs_graph, uint32_t svs_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, uint32_t* d_bad2,
                              hipStream_t stream);
 

@@ -21,7 +21,7 @@
 
 namespace svsx {
 
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false>
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODES = false>
 __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     const bool tag8 = a.filter_tag8 != 0u;
     const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + (a.filter_entries ? 256u : 0u)); // GENERAL only
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES) ? 256u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -93,6 +93,51 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     const unsigned char* data = static_cast<const unsigned char*>(a.data);
     const int sub = static_cast<int>(lane) & (G - 1);
     const uint32_t grp = lane / G;
+
+    // ---- bound codes (svsx_index_build_bound_codes): the query's own codes, kept in registers -----------------------
+    // Row r has codes cx (u8) of its first DC components under the global (scale, bias): xhat_j = bias + scale * cx_j, and
+    // the stored ex >= ||x_C - xhat||.  With the query coded the same way (error eq, computed here),
+    //     sqrt(distance_L2) >= ||q_C - x_C|| >= ||qhat - xhat|| - eq - ex = scale * sqrt(sum (cq - cx)^2) - eq - ex,
+    // and the integer sum is exact (v_dot4).  A candidate whose bound already exceeds the worst buffer entry would be
+    // skipped by can_skip (search_buffer.h:338-340) whatever its exact distance -> its 384-B row is never fetched.
+    // Margins (0.99998 on the code distance, 1.001 on eq, 1.0001 on the threshold) cover every float rounding involved.
+    uint32_t qc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int code_qq = 0;
+    float code_eq = 0.0f;
+    uint32_t n_code_rej = 0;
+    if constexpr (CODES) {
+        static_assert(G == 4 && DS > 0, "bound codes: f32 rows of static dimension");
+        constexpr int DC = DS < 120 ? DS : 120;
+        const float inv = 1.0f / a.code_scale;
+        float e2 = 0.0f;
+        int qq = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = sub * 32 + w * 4 + t;
+                if (j < DC) {
+                    const float v = qf[j];
+                    float c = __builtin_rintf((v - a.code_bias) * inv);
+                    c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
+                    const int ci = static_cast<int>(c);
+                    const float r = v - (a.code_bias + a.code_scale * c);
+                    e2 += r * r;
+                    qq += ci * ci;
+                    packed |= static_cast<uint32_t>(ci) << (8 * t);
+                }
+            }
+            qc[w] = packed;
+        }
+        e2 += xor1f(e2);
+        e2 += xor2f(e2);
+        qq += xor1i(qq);
+        qq += xor2i(qq);
+        code_qq = qq;
+        code_eq = __builtin_sqrtf(e2) * 1.001f + 1.0e-7f;
+        if (!(code_eq < 3.0e38f)) code_eq = __builtin_inff(); // non-finite query: the bound never fires
+    }
 
     // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
     // candidate out (l2_row_distance_two_phase); result-neutral, removes the third line of most rows at d = 96
@@ -224,6 +269,53 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 nid = lane < cnt ? compact[lane] : kInvalidId;
                 lds_order();
             }
+            if constexpr (CODES) {
+                if (full && cnt > 0u) {
+                    // bound pass over all candidates of this expansion; survivors keep their adjacency order.  `worst` can
+                    // only improve while they are inserted, so a bound taken against the current worst stays valid.
+                    const float thr2 = worst * 1.0001f;
+                    uint32_t nsurv = 0;
+                    for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
+                        const uint32_t ci = p0 + grp;
+                        const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
+                        const bool act = ci < cnt;
+                        const uint4* crow = reinterpret_cast<const uint4*>(a.codes + static_cast<size_t>(act ? cid : 0u) * 128u) + sub * 2;
+                        const uint4 c0 = crow[0], c1 = crow[1];
+                        uint32_t dot = 0;
+                        dot = __builtin_amdgcn_udot4(c0.x, qc[0], dot, false);
+                        dot = __builtin_amdgcn_udot4(c0.y, qc[1], dot, false);
+                        dot = __builtin_amdgcn_udot4(c0.z, qc[2], dot, false);
+                        dot = __builtin_amdgcn_udot4(c0.w, qc[3], dot, false);
+                        dot = __builtin_amdgcn_udot4(c1.x, qc[4], dot, false);
+                        dot = __builtin_amdgcn_udot4(c1.y, qc[5], dot, false);
+                        dot = __builtin_amdgcn_udot4(c1.z, qc[6], dot, false); // qc[6], qc[7] are 0 in the lane that holds the row tail
+                        dot = __builtin_amdgcn_udot4(c1.w, qc[7], dot, false);
+                        int part = -2 * static_cast<int>(dot);
+                        float ex = 0.0f;
+                        if (sub == 3) {
+                            ex = __uint_as_float(c1.z);
+                            part += static_cast<int>(c1.w);
+                        }
+                        part += xor1i(part);
+                        part += xor2i(part);
+                        ex += xor1f(ex);
+                        ex += xor2f(ex);
+                        const float isum = static_cast<float>(code_qq + part); // sum (cq - cx)^2 < 2^24: exact
+                        const float lb = a.code_scale * __builtin_sqrtf(isum) * 0.99998f - code_eq - ex;
+                        const bool rej = lb > 0.0f && lb * lb > thr2;
+                        const bool surv = act && !rej && sub == 0;
+                        const unsigned long long sm = __ballot(surv);
+                        if (surv) compact[nsurv + __popcll(sm & ((1ull << lane) - 1ull))] = cid;
+                        nsurv += __popcll(sm);
+                    }
+                    lds_order();
+                    nid = lane < nsurv ? compact[lane] : kInvalidId;
+                    lds_order();
+                    n_code_rej += cnt - nsurv;
+                    n_eval += cnt - nsurv;
+                    cnt = nsurv;
+                }
+            }
             for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
                 const uint32_t ci = p0 + grp;
                 const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
@@ -324,23 +416,23 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
             st[2] = n_eval;
             st[3] = n_ins;
             st[4] = n_early;
-            st[5] = 0;
+            st[5] = n_code_rej;
         }
         if (a.history_len != nullptr) a.history_len[qi] = n_exp;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODES = false> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
     const int d = static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
-                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) + 64 * 4 : 0) +
-                       (GENERAL ? 64 * 8 : 0);
+                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
+                       ((a.filter_entries || CODES) ? 64 * 4 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL>;
+    auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
@@ -351,6 +443,10 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false> static hi
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
     if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
+    if constexpr (QMODE == QM_FLOAT && DT == DT_F32 && METRIC == M_L2) {
+        if (a.codes != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, true>(a, stream);
+        if (a.codes != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, true>(a, stream);
+    }
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         if (a.d == 96) return launch_one<DT, METRIC, QMODE, 96>(a, stream);
         if (a.d == 128) return launch_one<DT, METRIC, QMODE, 128>(a, stream);

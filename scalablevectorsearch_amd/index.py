@@ -200,6 +200,10 @@ class VamanaIndex:
         res = QueryResult(ids, dists)
         return (res, st) if stats else res
 
+    def build_bound_codes(self, enable: bool = True) -> None:
+        """svsx_index_build_bound_codes: result-neutral lower-bound rejection (float32 L2, d = 96 / 128)."""
+        _lib.check(_lib.lib().svsx_index_build_bound_codes(self._h, int(enable)))
+
     def batch_iterator(self, queries, extra_search_buffer_capacity: int | None = None):
         """VamanaIndex::make_batch_iterator (index/vamana/index.h:936), one iterator per query of the batch."""
         from .iterator import BatchIterator
