@@ -283,6 +283,7 @@ def main():
             "visited_filter": args.visited,
             "distance_evals_per_query": int(st[:, 2].sum()) / nq,
             "partial_distance_rejects_per_query": int(st[:, 4].sum()) / nq,
+            "accepted_inserts_per_query": int(st[:, 3].sum()) / nq,
             "bound_codes": args.bound_codes,
             "bound_code_rejects_per_query": int(st[:, 5].sum()) / nq,
         },

@@ -711,6 +711,30 @@ __device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ
 // SearchBuffer::insert_inner (search_buffer.h:353-403).  d / id are wave-uniform.  Returns true if inserted.
 template <bool GREATER>
 __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id, uint32_t lane) {
+    if (b.size <= 128u) {
+        // at most two entries per lane: one LDS read serves the position search, the duplicate scan AND the shift
+        // (old[i] -> e[i + 1] straight from the registers: every read precedes every write, no chunk ordering needed)
+        const uint32_t i0 = lane, i1 = lane + 64u;
+        const bool v0 = i0 < b.size, v1 = i1 < b.size;
+        uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
+        if (v0) e0 = b.e[i0];
+        if (v1) e1 = b.e[i1];
+        const float d0 = __uint_as_float(e0.x), d1 = __uint_as_float(e1.x);
+        const bool bf0 = v0 && !cmpf<GREATER>(d, d0);
+        const bool bf1 = v1 && !cmpf<GREATER>(d, d1);
+        const bool same = (v0 && d0 == d && (e0.y & kIdMask) == id) || (v1 && d1 == d && (e1.y & kIdMask) == id);
+        const unsigned long long m0 = __ballot(bf0), m1 = __ballot(bf1);
+        if (__ballot(same) != 0ull) return false;
+        const uint32_t pos = static_cast<uint32_t>(__popcll(m0) + __popcll(m1)); // sorted: the "before" entries are a prefix
+        lds_order();
+        if (v0 && i0 >= pos) b.e[i0 + 1u] = e0;
+        if (v1 && i1 >= pos) b.e[i1 + 1u] = e1;
+        if (lane == 0) b.e[pos] = make_uint2(__float_as_uint(d), id);
+        lds_order();
+        b.size = (b.size + 1 < b.capacity) ? b.size + 1 : b.capacity;
+        b.best_unvisited = pos < b.best_unvisited ? pos : b.best_unvisited;
+        return true;
+    }
     // position after all elements that do not compare greater (lower_bound with !cmp(d, other)) + duplicate scan
     uint32_t pos = 0;
     bool dup = false;

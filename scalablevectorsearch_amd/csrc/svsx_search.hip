@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         const unsigned char* row = data + static_cast<size_t>(active ? cid : 0u) * a.row_bytes;
         float fmain = 0.0f, fnrm = 0.0f;
         int ab = 0, bb = 0;
-        if constexpr (TWO_PHASE) {
+        if constexpr (TWO_PHASE && !CODES) { // survivors of the bound codes are close to the worst entry: fetch whole rows
             bool rejected = false;
             const float dd = l2_row_distance_two_phase<DT, (DS > 64 && DS <= 128) ? DS : 96>(row, active, qf, sub, thr, rejected);
             n_early += __popcll(__ballot(active && rejected && sub == 0));
@@ -273,7 +273,11 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 if (full && cnt > 0u) {
                     // bound pass over all candidates of this expansion; survivors keep their adjacency order.  `worst` can
                     // only improve while they are inserted, so a bound taken against the current worst stays valid.
-                    const float thr2 = worst * 1.0001f;
+                    // reject iff  scale * sqrt(I) * 0.99998 - eq - ex > sqrt(worst * 1.0001),  I = sum (cq - cx)^2; with
+                    // T = (sqrt(worst * 1.0001) * 1.00001 + eq + ex) / (0.99998 * scale) this is implied by I > T^2 * 1.00001
+                    // (one square root per expansion instead of one per candidate)
+                    const float sthr = __builtin_sqrtf(worst * 1.0001f) * 1.00001f + code_eq;
+                    const float tscale = 1.00002f / a.code_scale * 1.000001f;
                     uint32_t nsurv = 0;
                     for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
                         const uint32_t ci = p0 + grp;
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                         ex += xor1f(ex);
                         ex += xor2f(ex);
                         const float isum = static_cast<float>(code_qq + part); // sum (cq - cx)^2 < 2^24: exact
-                        const float lb = a.code_scale * __builtin_sqrtf(isum) * 0.99998f - code_eq - ex;
-                        const bool rej = lb > 0.0f && lb * lb > thr2;
+                        const float t = (sthr + ex) * tscale;
+                        const bool rej = isum > t * t * 1.00001f; // false for NaN / inf thresholds
                         const bool surv = act && !rej && sub == 0;
                         const unsigned long long sm = __ballot(surv);
                         if (surv) compact[nsurv + __popcll(sm & ((1ull << lane) - 1ull))] = cid;

@@ -121,4 +121,6 @@ def test_cxx_facade_search_on_gpu(lib, tmp_path):
     exe = _build_facade(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.split() == ["5", "6", "4"]
+    lines = out.stdout.splitlines()
+    assert lines[0].split() == ["5", "6", "4"]
+    assert [ln.split()[2] for ln in lines[1:]] == ["5", "6", "4", "7", "3", "2", "1", "0"]  # BatchIterator, batches of 3
