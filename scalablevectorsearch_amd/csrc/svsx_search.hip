@@ -19,6 +19,12 @@
 #include "svsx_device.h"
 #include "svsx_kernels.h"
 
+#ifndef SVSX_CODE_BATCH
+// bound-code passes (16 candidates each) whose loads are issued together.  Measured on the bench workload: 1 -> 4.90,
+// 2 -> 5.17, 3 -> 5.13, 4 -> 4.55 M QPS (4 needs 105 VGPRs = 4 waves/SIMD); profiles/r01_notes.md
+#define SVSX_CODE_BATCH 2
+#endif
+
 namespace svsx {
 
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODES = false>
@@ -279,26 +285,44 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                     const float sthr = __builtin_sqrtf(worst * 1.0001f) * 1.00001f + code_eq;
                     const float tscale = 1.00002f / a.code_scale * 1.000001f;
                     uint32_t nsurv = 0;
-                    for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
-                        const uint32_t ci = p0 + grp;
-                        const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
+                    // the code rows of CB passes (16 candidates each) are requested together before the first is used:
+                    // fewer dependent memory round trips per expansion
+                    constexpr int CB = SVSX_CODE_BATCH;
+                    for (int pg = 0; pg < 4 && static_cast<uint32_t>(pg) * RPP < cnt; pg += CB) {
+                    uint4 c0[CB], c1[CB];
+                    uint32_t pcid[CB];
+#pragma unroll
+                    for (int pp = 0; pp < CB; ++pp) {
+                        const int p = pp;
+                        const uint32_t ci = static_cast<uint32_t>(pg + pp) * RPP + grp;
+                        pcid[p] = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
+                        if (static_cast<uint32_t>(pg + pp) * RPP < cnt) {
+                            const uint4* crow = reinterpret_cast<const uint4*>(a.codes + static_cast<size_t>(ci < cnt ? pcid[p] : 0u) * 128u) + sub * 2;
+                            c0[p] = crow[0];
+                            c1[p] = crow[1];
+                        }
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < CB; ++pp) {
+                        const int p = pp;
+                        if (static_cast<uint32_t>(pg + pp) * RPP >= cnt) break;
+                        const uint32_t ci = static_cast<uint32_t>(pg + pp) * RPP + grp;
+                        const uint32_t cid = pcid[p];
                         const bool act = ci < cnt;
-                        const uint4* crow = reinterpret_cast<const uint4*>(a.codes + static_cast<size_t>(act ? cid : 0u) * 128u) + sub * 2;
-                        const uint4 c0 = crow[0], c1 = crow[1];
                         uint32_t dot = 0;
-                        dot = __builtin_amdgcn_udot4(c0.x, qc[0], dot, false);
-                        dot = __builtin_amdgcn_udot4(c0.y, qc[1], dot, false);
-                        dot = __builtin_amdgcn_udot4(c0.z, qc[2], dot, false);
-                        dot = __builtin_amdgcn_udot4(c0.w, qc[3], dot, false);
-                        dot = __builtin_amdgcn_udot4(c1.x, qc[4], dot, false);
-                        dot = __builtin_amdgcn_udot4(c1.y, qc[5], dot, false);
-                        dot = __builtin_amdgcn_udot4(c1.z, qc[6], dot, false); // qc[6], qc[7] are 0 in the lane that holds the row tail
-                        dot = __builtin_amdgcn_udot4(c1.w, qc[7], dot, false);
+                        dot = __builtin_amdgcn_udot4(c0[p].x, qc[0], dot, false);
+                        dot = __builtin_amdgcn_udot4(c0[p].y, qc[1], dot, false);
+                        dot = __builtin_amdgcn_udot4(c0[p].z, qc[2], dot, false);
+                        dot = __builtin_amdgcn_udot4(c0[p].w, qc[3], dot, false);
+                        dot = __builtin_amdgcn_udot4(c1[p].x, qc[4], dot, false);
+                        dot = __builtin_amdgcn_udot4(c1[p].y, qc[5], dot, false);
+                        dot = __builtin_amdgcn_udot4(c1[p].z, qc[6], dot, false); // qc[6], qc[7] are 0 in the lane that holds the row tail
+                        dot = __builtin_amdgcn_udot4(c1[p].w, qc[7], dot, false);
                         int part = -2 * static_cast<int>(dot);
                         float ex = 0.0f;
                         if (sub == 3) {
-                            ex = __uint_as_float(c1.z);
-                            part += static_cast<int>(c1.w);
+                            ex = __uint_as_float(c1[p].z);
+                            part += static_cast<int>(c1[p].w);
                         }
                         part += xor1i(part);
                         part += xor2i(part);
@@ -311,6 +335,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                         const unsigned long long sm = __ballot(surv);
                         if (surv) compact[nsurv + __popcll(sm & ((1ull << lane) - 1ull))] = cid;
                         nsurv += __popcll(sm);
+                    }
                     }
                     lds_order();
                     nid = lane < nsurv ? compact[lane] : kInvalidId;

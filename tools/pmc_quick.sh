@@ -3,7 +3,7 @@
 R=$PWD; BA=${1:-}
 python bench.py $BA --graph-cache /tmp/g1m.pt --no-cpu-baseline > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
+for C in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
   rm -rf /tmp/pq; rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pq -o p -- python $R/bench.py $BA --graph-cache /tmp/g1m.pt --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
   python - <<'PY'
 import csv, glob, collections
