@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the multi-GPU code path (RCCL all-gather + merge) even at world size 1")
     ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
-    ap.add_argument("--bound-codes", type=int, default=0, help="1: build the 128-B bound-code rows (result-neutral lower-bound rejection)")
+    ap.add_argument("--bound-codes", type=int, default=1, help="1: build the 128-B bound-code rows (result-neutral lower-bound rejection); 0: off")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph here (lets a profiler run skip the build)")
     args = ap.parse_args()
 
@@ -299,9 +299,9 @@ def main():
             "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "measured_copy_GBs": copy_gbs,
             "note": "achieved = ALGORITHMIC bytes (reference traversal: visited set off, whole rows; SURVEY 8d) / kernel time; "
-                    "the kernel skips result-neutral work (visited filter, partial-distance rejection), so measured traffic "
+                    "the kernel skips result-neutral work (visited filter, bound-code / partial-distance rejection), so measured traffic "
                     "is below the algorithmic bytes and frac can exceed 1; traffic_rate = measured fabric bytes / kernel time",
-            "kernel": "svsx::search_kernel<f32,L2,float,96>",
+            "kernel": "svsx::search_kernel<f32,L2,float,96%s>" % (",bound-codes" if args.bound_codes else ""),
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
         },

@@ -4,6 +4,7 @@ import collections, csv, glob, json, os, statistics, sys
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 visited = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+bound_codes = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 base = f"gpurun_out/{rnd}"
 
 
@@ -38,8 +39,8 @@ known = 3_000_000 * 96 * 4
 factor = known / (cal * 1024)
 s = {
     "command": "rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --graph-cache /tmp/g1m.pt --no-cpu-baseline --steps 3 --warmup 1 (one pass per counter group; means over the search_kernel launches at window 128 of each pass)",
-    "workload": {"n": 1000000, "d": 96, "nq": 10000, "window": 128, "degree": 64, "visited": visited},
-    "kernel": "svsx::search_kernel<0,0,0,96>",
+    "workload": dict({"n": 1000000, "d": 96, "nq": 10000, "window": 128, "degree": 64, "visited": visited}, **({"bound_codes": bound_codes} if bound_codes else {})),
+    "kernel": "svsx::search_kernel<0,0,0,96,false,%s>" % ("true" if bound_codes else "false"),
     "counters_per_launch": out,
     "fetch_size_calibration": {"known_bytes": known, "FETCH_SIZE_KB": cal, "factor": factor,
                                "pattern": "distance_kernel streaming 3e6 x 384-B rows once with the search kernel's row-group loads (4 lanes x 16 B)"},
