@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000); ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--dtype", default="f16", choices=["f32", "f16", "sq8", "i8"]); ap.add_argument("--metric", default="ip", choices=["l2", "ip", "cos"])
     ap.add_argument("--nq", type=int, default=10_000); ap.add_argument("--window", type=int, default=128); ap.add_argument("--degree", type=int, default=64)
-    ap.add_argument("--latent", type=int, default=32); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--cpu", type=int, default=1); ap.add_argument("--visited", type=int, default=1)
+    ap.add_argument("--latent", type=int, default=32); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--cpu", type=int, default=1); ap.add_argument("--visited", type=int, default=1); ap.add_argument("--bound-codes", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     fn = {"l2": svs.DistanceL2(), "ip": svs.DistanceIP(), "cos": svs.DistanceCosineSimilarity()}[a.metric]
@@ -76,6 +76,8 @@ def main():
                                        data_dtype=np_dt, sq=sq)
     t_build = time.time() - t0
     idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), a.n, a.d, np_dt, sq=sq)
+    if a.bound_codes:
+        idx.build_bound_codes()
     k = 10
     ids = torch.empty((a.nq, k), dtype=torch.int64, device=dev); dists = torch.empty((a.nq, k), device=dev)
     stats = torch.zeros((a.nq, 6), dtype=torch.int32, device=dev)
