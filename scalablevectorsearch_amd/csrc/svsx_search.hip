@@ -140,9 +140,10 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         e2 += xor2f(e2);
         qq += xor1i(qq);
         qq += xor2i(qq);
-        code_qq = qq;
+        code_qq = __builtin_amdgcn_readfirstlane(qq); // wave-uniform values live in SGPRs
         code_eq = __builtin_sqrtf(e2) * 1.001f + 1.0e-7f;
         if (!(code_eq < 3.0e38f)) code_eq = __builtin_inff(); // non-finite query: the bound never fires
+        code_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, code_eq)));
     }
 
     // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     }
 
     bool full = buf.size == buf.capacity;
-    float worst = (full && buf.capacity > 0u) ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
+    float worst = (full && buf.capacity > 0u) ? __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(buf.e[buf.capacity - 1].x)))) : 0.0f;
 
     // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
     while (!wave_done(buf)) {
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                     if (wave_insert<GREATER>(buf, dd, id, lane)) {
                         ++n_ins;
                         full = buf.size == buf.capacity;
-                        if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
+                        if (full) worst = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(buf.e[buf.capacity - 1].x))));
                     }
                 }
             }
