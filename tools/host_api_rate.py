@@ -13,7 +13,9 @@ t0 = time.perf_counter()
 idx = svs.VamanaIndex(device_graph_to_svs(b["graph"], 64), x.cpu().numpy(), svs.DistanceL2(), [b["entry"]])
 t_create = time.perf_counter() - t0
 qh = q.cpu().numpy()
-sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(128))
+sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(128), True)
+if len(sys.argv) > 1 and sys.argv[1] == "codes":
+    idx.build_bound_codes()
 idx.search(qh, 10, sp)
 ts = []
 for _ in range(5):
