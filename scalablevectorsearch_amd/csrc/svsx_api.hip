@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -546,25 +547,92 @@ int svsx_flat_search_device(
     void *qh = bqh.p, *sk = bsk.p, *si = bsi.p, *mk = bmk.p, *mi = bmi.p;
     hipError_t e = launch_to_half(q_dtype, d_queries, q_stride, static_cast<uint32_t>(nq), static_cast<uint32_t>(ix->d), dpad, 0, 1.0f, 0.0f, qh, nullptr, stream);
     FlatArgs fa;
+    memset(&fa, 0, sizeof(fa));
     fa.xh = ix->d_half; fa.xnorm2 = ix->d_norm2; fa.n = static_cast<uint32_t>(ix->n); fa.dpad = dpad; fa.qh = qh;
     fa.nq = static_cast<uint32_t>(nq); fa.kk = static_cast<uint32_t>(kk); fa.n_slices = static_cast<uint32_t>(slices);
     fa.out_keys = static_cast<float*>(sk); fa.out_ids = static_cast<uint64_t*>(si);
+    fa.tile_step = 1;
     StreamBuffer bgt;
     HIP_TRY(bgt.alloc(nq * 4, stream));
     fa.gtau = static_cast<uint32_t*>(bgt.p);
-    if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream); // +inf, order-encoded
-    if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
     MergeArgs ma;
+    memset(&ma, 0, sizeof(ma));
     ma.dists = static_cast<const float*>(sk); ma.ids = static_cast<const uint64_t*>(si);
     ma.out_dists = static_cast<float*>(mk); ma.out_ids = static_cast<uint64_t*>(mi);
     ma.n_shards = static_cast<uint32_t>(slices); ma.nq = static_cast<uint32_t>(nq); ma.k = static_cast<uint32_t>(kk);
-    if (e == hipSuccess) e = launch_merge(M_L2, ma, stream); // keys: smaller is better for every metric
     RerankArgs ra;
+    memset(&ra, 0, sizeof(ra));
     ra.data = ix->d_data; ra.row_bytes = ix->row_bytes; ra.d = static_cast<uint32_t>(ix->d); ra.sq_scale = ix->sq_scale; ra.sq_bias = ix->sq_bias;
     ra.id_offset = ix->id_offset; ra.queries = d_queries; ra.q_row_bytes = q_stride; ra.q_dtype = q_dtype;
     ra.nq = static_cast<uint32_t>(nq); ra.kk = static_cast<uint32_t>(kk); ra.k = static_cast<uint32_t>(k);
     ra.cand_ids = static_cast<const uint64_t*>(mi); ra.ids64 = d_ids64; ra.dists = d_dists;
-    if (e == hipSuccess) e = launch_rerank(ix->data_dtype, ix->metric, qmode, ra, stream);
+    // Large sets with d <= 128 take the threshold pipeline (svsx_flat.hip stage 1b): nested strided samples of the 32-row
+    // tiles, every 16^j-th tile for j = L .. 1, each ~16x larger than the one before.  The smallest (>= 256 rows) is
+    // taken whole (threshold +inf); at every level the threshold kernel appends the rows at or below the current
+    // threshold (about 16 kk per query) and the select kernel takes the kk-th best key of that list as the next, tighter
+    // threshold -- which at least kk rows of the next level satisfy, because the samples are nested.  The last level is
+    // the full set; its lists (>= kk rows, ~16 kk expected) are re-ranked exactly.  Queries whose lists overflow
+    // (unrepresentative samples) are recomputed by the full shortlist kernel, gated per 64-query block.
+    const bool thresh_path = dpad <= 128 && ix->n >= 65536 && nq <= 65536 && !getenv("SVSX_FLAT_SHORTLIST_ONLY");
+    StreamBuffer bcand, bkeys, bcnt, bgate, btau_a, btau_b;
+    if (thresh_path) {
+        const size_t tiles = (ix->n + 31) / 32;
+        uint32_t step = 1;
+        while (tiles / (static_cast<size_t>(step) * 16) >= 4) step *= 16; // coarsest level keeps >= 4 tiles = 128 rows >= kk
+        size_t s2 = (2 * 1024) / nqb; // two waves per SIMD, one generation
+        if (s2 > ix->n / 4096) s2 = ix->n / 4096;
+        if (s2 < 1) s2 = 1;
+        if (s2 > 1024) s2 = 1024;
+        // rows per (query, slice) list: ~16 kk / s2 expected at every level, at most 16 x 32 at the coarsest; 4x head room
+        size_t cap = 512;
+        while (cap < 4 * (16 * kk / s2 + 1)) cap *= 2;
+        const size_t coarse_rows = (tiles / step + 1) * 32; // all of them are appended at the first level
+        while (cap < 2 * coarse_rows / s2 && cap < 8192) cap *= 2;
+        HIP_TRY(bcand.alloc(nq * s2 * cap * 4, stream));
+        HIP_TRY(bkeys.alloc(nq * s2 * cap * 4, stream));
+        HIP_TRY(bcnt.alloc(nq * s2 * 4, stream));
+        HIP_TRY(bgate.alloc(nqb * 4, stream));
+        HIP_TRY(btau_a.alloc(nq * 4, stream));
+        HIP_TRY(btau_b.alloc(nq * 4, stream));
+        float* tau_cur = static_cast<float*>(btau_a.p);
+        float* tau_nxt = static_cast<float*>(btau_b.p);
+        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tau_cur), 0x7F800000, nq, stream); // +inf
+        FlatThreshArgs ta;
+        memset(&ta, 0, sizeof(ta));
+        ta.xh = ix->d_half; ta.xnorm2 = ix->d_norm2; ta.n = static_cast<uint32_t>(ix->n); ta.dpad = dpad; ta.qh = qh;
+        ta.nq = static_cast<uint32_t>(nq);
+        ta.n_slices = static_cast<uint32_t>(s2);
+        ta.tau_stride = 1;
+        ta.cand = static_cast<uint32_t*>(bcand.p);
+        ta.cnt = static_cast<uint32_t*>(bcnt.p); ta.cap = static_cast<uint32_t>(cap);
+        for (; step > 1; step /= 16) {
+            ta.tile_step = step;
+            ta.tau = tau_cur;
+            ta.cand_keys = static_cast<float*>(bkeys.p);
+            if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
+            if (e == hipSuccess) e = launch_flat_select(ta.cand_keys, ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t>(kk), tau_cur, 1, tau_nxt, stream);
+            float* t = tau_cur; tau_cur = tau_nxt; tau_nxt = t;
+        }
+        ta.tile_step = 1;
+        ta.tau = tau_cur;
+        ta.cand_keys = nullptr;
+        if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
+        if (e == hipSuccess) e = launch_flat_gate(ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t*>(bgate.p), stream);
+        // gated fallback: full shortlist pass and merge only for the query blocks that overflowed
+        fa.tile_step = 1;
+        fa.block_gate = static_cast<const uint32_t*>(bgate.p);
+        ma.gate64 = fa.block_gate;
+        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream);
+        if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
+        if (e == hipSuccess) e = launch_merge(M_L2, ma, stream);
+        ra.cand32 = ta.cand; ra.cnt = ta.cnt; ra.cap = ta.cap; ra.n_lists = ta.n_slices;
+        if (e == hipSuccess) e = launch_rerank2(ix->data_dtype, ix->metric, qmode, ra, stream);
+    } else {
+        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream); // +inf, order-encoded
+        if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
+        if (e == hipSuccess) e = launch_merge(M_L2, ma, stream); // keys: smaller is better for every metric
+        if (e == hipSuccess) e = launch_rerank(ix->data_dtype, ix->metric, qmode, ra, stream);
+    }
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "flat search launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
 }
@@ -608,6 +676,7 @@ int svsx_merge_topk_device(
     if (nq == 0) return SVSX_SUCCESS;
     if (!d_dists || !d_ids || !d_out_dists || !d_out_ids) return fail(SVSX_INVALID_ARGUMENT, "null argument");
     MergeArgs a;
+    memset(&a, 0, sizeof(a));
     a.dists = d_dists;
     a.ids = d_ids;
     a.out_dists = d_out_dists;

@@ -80,6 +80,7 @@ hipError_t launch_distance(int b_dtype, int metric, int qmode, const DistanceArg
 template <bool GREATER> __global__ void merge_kernel(const MergeArgs a) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= a.nq) return;
+    if (a.gate64 != nullptr && a.gate64[q >> 6] == 0u) return;
     constexpr int MAXS = 64;
     uint16_t cur[MAXS];
     for (uint32_t s = 0; s < a.n_shards; ++s) cur[s] = 0;

@@ -76,11 +76,13 @@ hipError_t launch_to_half(int dtype, const void* src, size_t src_row_bytes, uint
 template <int METRIC, int KS>
 __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (a.block_gate != nullptr && a.block_gate[blockIdx.x] == 0u) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t q0 = blockIdx.x * 64u;
     const uint32_t slice = blockIdx.y;
     const uint32_t dpad = a.dpad;
     const uint32_t ks = dpad >> 4;
+    const uint32_t xstep = 32u * (a.tile_step ? a.tile_step : 1u);
     const uint32_t astride = dpad * 2u + 16u; // bytes; +16 shifts consecutive rows by 4 banks
     unsigned char* A = smem;                                         // runtime-k path only
     const uint32_t a_bytes = KS > 0 ? 0u : 64u * astride;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
     const uint32_t rows_per_slice = ((a.n + a.n_slices - 1) / a.n_slices + 31u) & ~31u;
     const uint32_t x_lo = slice * rows_per_slice;
     const uint32_t x_hi = (x_lo + rows_per_slice) < a.n ? (x_lo + rows_per_slice) : a.n;
+    const uint32_t x_first = ((x_lo + xstep - 1u) / xstep) * xstep; // sampled tiles are absolute: tile index % tile_step == 0
     const uint32_t half = lane >> 5, col = lane & 31u;
     const _Float16* xh = static_cast<const _Float16*>(a.xh);
 
@@ -142,10 +145,10 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
             afr0[s2] = r0 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r0) * dpad + 16 * s2 + 8u * half) : z;
             afr1[s2] = r1 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r1) * dpad + 16 * s2 + 8u * half) : z;
         }
-        if (x_lo < x_hi) load_tile(x_lo, bcur, xn_cur);
+        if (x_first < x_hi) load_tile(x_first, bcur, xn_cur);
     }
     uint32_t tile_no = 0;
-    for (uint32_t x0 = x_lo; x0 < x_hi; x0 += 32, ++tile_no) {
+    for (uint32_t x0 = x_first; x0 < x_hi; x0 += xstep, ++tile_no) {
         if (a.gtau != nullptr && (tile_no & 7u) == 0u) {
             // every slice of the same query block publishes its kk-th best key; the minimum over slices is a valid
             // pruning threshold for all of them (that slice alone holds kk better candidates)
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(64) void flat_mfma_kernel(const FlatArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
         if constexpr (KS > 0) {
-            if (x0 + 32 < x_hi) load_tile(x0 + 32, bnext, xn_next); // in flight during this tile's MFMAs
+            if (x0 + xstep < x_hi) load_tile(x0 + xstep, bnext, xn_next); // in flight during this tile's MFMAs
 #pragma unroll
             for (int s2 = 0; s2 < KS; ++s2) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[s2], bcur[s2], acc0, 0, 0, 0);
@@ -332,6 +335,269 @@ hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
+// ---- stage 1b: threshold pass ------------------------------------------------------------------------------------------------
+// With a per-query threshold tau known in advance selection needs no ordered shortlist: every (query, row) with
+// key <= tau is appended to the (query, slice) candidate list (LDS counter + store, straight from the lane that owns the
+// cell).  No shortlists in LDS, three B tiles in flight per wave; the epilogue is one fma + one compare per cell.
+// The thresholds come from two cheap refinement steps (svsx_api.hip): the shortlist kernel on a ~4096-row sample, then
+// this kernel on every 16th tile with that threshold, then flat_select_kernel -> the kk-th best key of the 1/16 sample,
+// which at least kk rows satisfy by construction.
+constexpr uint32_t kFlatRerankCap = 2048; // candidates per query the exact re-rank accepts (LDS)
+constexpr uint32_t kFlatSelectCap = 8192; // keys per query the threshold selection accepts (LDS)
+
+__device__ __forceinline__ bool flat_overflow(const uint32_t* cnt, uint32_t q, uint32_t n_slices, uint32_t cap, uint32_t& total,
+                                              uint32_t total_cap = kFlatRerankCap) {
+    bool over = false;
+    total = 0;
+    for (uint32_t s2 = 0; s2 < n_slices; ++s2) {
+        const uint32_t c = cnt[static_cast<size_t>(q) * n_slices + s2];
+        over = over || c > cap;
+        total += c;
+    }
+    return over || total > total_cap;
+}
+
+template <int METRIC, int KS>
+__global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs a) {
+    __shared__ uint32_t lcnt[64];
+    __shared__ __align__(16) float ltau[64];
+    // B tiles go global -> registers (KS fully coalesced 1-KB loads: a 32-row tile of the f16 shadow is contiguous) -> LDS
+    // (row pitch + 16 B: conflict-free ds_read_b128 in the MFMA fragment layout) -> fragments.  Reading the fragments
+    // straight from global memory touches 32 cache lines per load instruction and is bound by the vector-memory path.
+    __shared__ __align__(16) unsigned char btile[2][32 * (KS * 32 + 16)];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q0 = blockIdx.x * 64u;
+    const uint32_t slice = blockIdx.y;
+    const uint32_t dpad = a.dpad;
+    const uint32_t rows_per_slice = ((a.n + a.n_slices - 1) / a.n_slices + 31u) & ~31u;
+    const uint32_t x_lo = slice * rows_per_slice;
+    const uint32_t x_hi = (x_lo + rows_per_slice) < a.n ? (x_lo + rows_per_slice) : a.n;
+    const uint32_t xs = 32u * (a.tile_step ? a.tile_step : 1u);
+    const uint32_t x_first = ((x_lo + xs - 1u) / xs) * xs;
+    lcnt[lane] = 0u;
+    lds_order();
+    const uint32_t half = lane >> 5, col = lane & 31u;
+    const _Float16* xh = static_cast<const _Float16*>(a.xh);
+    const _Float16* qh = static_cast<const _Float16*>(a.qh);
+
+    if (x_lo < x_hi && x_first < x_hi) {
+        half8_t afr0[KS], afr1[KS];
+        {
+            const uint32_t r0 = q0 + col, r1 = q0 + 32u + col;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                half8_t z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = static_cast<_Float16>(0.0f);
+                afr0[s2] = r0 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r0) * dpad + 16 * s2 + 8u * half) : z;
+                afr1[s2] = r1 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r1) * dpad + 16 * s2 + 8u * half) : z;
+            }
+        }
+        // thresholds of the 64 queries in LDS (-inf for padding queries); a lane's 32 cells read them as 8 float4
+        ltau[lane] = q0 + lane < a.nq ? a.tau[static_cast<size_t>(q0 + lane) * a.tau_stride] : -__builtin_inff();
+        lds_order();
+        constexpr uint32_t ROWB = KS * 32u;       // bytes of one f16 row (dpad * 2)
+        constexpr uint32_t PITCH = ROWB + 16u;
+        uint32_t lds_off[KS];                      // where this lane's 16-B piece of 1-KB chunk i lands
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const uint32_t g = static_cast<uint32_t>(i) * 1024u + lane * 16u;
+            lds_off[i] = (g / ROWB) * PITCH + (g % ROWB);
+        }
+        const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(xh);
+        auto load_tile = [&](uint32_t xt, half8_t (&dst)[KS], float& xnv) { // native 16-B vectors stay in registers
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const uint32_t g = static_cast<uint32_t>(i) * 1024u + lane * 16u;
+                const uint32_t r = xt + g / ROWB;                      // row this piece belongs to
+                const size_t src = r < a.n ? static_cast<size_t>(xt) * ROWB + g : static_cast<size_t>(g % ROWB); // past the end: row 0
+                dst[i] = *reinterpret_cast<const half8_t*>(xbytes + src);
+            }
+            if constexpr (METRIC != M_IP) {
+                const uint32_t r = xt + col;
+                xnv = a.xnorm2[r < a.n ? r : 0u];
+            }
+        };
+        auto stage = [&](uint32_t buf, const half8_t (&src)[KS]) {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) *reinterpret_cast<half8_t*>(&btile[buf][lds_off[i]]) = src[i];
+        };
+        auto fragments = [&](uint32_t buf, half8_t (&dst)[KS]) {
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) dst[s2] = *reinterpret_cast<const half8_t*>(&btile[buf][col * PITCH + 32u * s2 + 16u * half]);
+        };
+        const size_t stride_q = static_cast<size_t>(a.n_slices) * a.cap;                       // list stride between queries
+        const size_t lane_base = (static_cast<size_t>(q0 + 4u * half) * a.n_slices + slice) * a.cap; // this lane's query group
+        auto consume = [&](uint32_t x0, const half8_t (&b)[KS], float xn) {
+            float16v_t acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[s2], b[s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr1[s2], b[s2], acc1, 0, 0, 0);
+            }
+            float rinv = 1.0f;
+            if constexpr (METRIC == M_COS) rinv = 1.0f / sqrtf(xn > 0.0f ? xn : 1.0f);
+            auto keyof = [&](float sc) -> float {
+                if constexpr (METRIC == M_L2) return xn - 2.0f * sc;
+                else if constexpr (METRIC == M_IP) return -sc;
+                else return -sc * rinv;
+            };
+            // accept test: one compare per cell, folded into 8 wave-level masks (4 cells each); the append path only
+            // revisits the groups in which some lane hit
+            unsigned long long gm[2][4];
+            unsigned long long anym = 0ull;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&ltau[qt * 32 + 8 * g4 + 4 * static_cast<int>(half)]);
+                    const float t[4] = {t4.x, t4.y, t4.z, t4.w};
+                    bool anyg = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) anyg = anyg || (keyof(qt == 0 ? acc0[4 * g4 + j] : acc1[4 * g4 + j]) <= t[j]);
+                    gm[qt][g4] = __ballot(anyg);
+                    anym |= gm[qt][g4];
+                }
+            }
+            if (anym == 0ull) return;
+            const uint32_t row = x0 + col;
+            const bool valid = row < x_hi; // lanes of a partial last tile hold a duplicate of another row
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (gm[qt][g4] == 0ull) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g4 + j;
+                        const float kv = keyof(qt == 0 ? acc0[r] : acc1[r]);
+                        const uint32_t cell = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>(j + 8 * g4);
+                        const bool hit = valid && kv <= ltau[cell + 4u * half];
+                        if (hit) {
+                            const uint32_t pos = atomicAdd(&lcnt[cell + 4u * half], 1u);
+                            if (pos < a.cap) {
+                                const size_t o = lane_base + static_cast<size_t>(cell) * stride_q + pos; // cell * stride_q is wave-uniform
+                                a.cand[o] = row;
+                                if (a.cand_keys != nullptr) a.cand_keys[o] = kv;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        half8_t gnext[KS];
+        half8_t bcur[KS];
+        float xn_cur = 0.0f, xn_next = 0.0f;
+        load_tile(x_first, gnext, xn_next);
+        stage(0u, gnext);
+        uint32_t buf = 0;
+        for (uint32_t x0 = x_first; x0 < x_hi; x0 += xs, buf ^= 1u) {
+            xn_cur = xn_next;
+            // next tile in flight during this tile's MFMAs and epilogue (past the end: a harmless re-read of the first)
+            load_tile(x0 + xs < x_hi ? x0 + xs : x_first, gnext, xn_next);
+            lds_order();
+            fragments(buf, bcur);
+            consume(x0, bcur, xn_cur);
+            stage(buf ^ 1u, gnext);
+            lds_order();
+        }
+    }
+    lds_order();
+    if (q0 + lane < a.nq) a.cnt[static_cast<size_t>(q0 + lane) * a.n_slices + slice] = lcnt[lane];
+}
+
+hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t stream) {
+    const uint32_t ks = a.dpad >> 4;
+    if (ks < 1 || ks > 8) return hipErrorInvalidValue;
+    const dim3 grid((a.nq + 63) / 64, a.n_slices);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(64), 0, stream, a);
+        return hipGetLastError();
+    };
+#define SVSX_THRESH_CASE(M)                                   \
+    switch (ks) {                                             \
+        case 1: return go(flat_thresh_kernel<M, 1>);          \
+        case 2: return go(flat_thresh_kernel<M, 2>);          \
+        case 3: return go(flat_thresh_kernel<M, 3>);          \
+        case 4: return go(flat_thresh_kernel<M, 4>);          \
+        case 5: return go(flat_thresh_kernel<M, 5>);          \
+        case 6: return go(flat_thresh_kernel<M, 6>);          \
+        case 7: return go(flat_thresh_kernel<M, 7>);          \
+        default: return go(flat_thresh_kernel<M, 8>);         \
+    }
+    switch (metric) {
+        case M_L2: SVSX_THRESH_CASE(M_L2)
+        case M_IP: SVSX_THRESH_CASE(M_IP)
+        case M_COS: SVSX_THRESH_CASE(M_COS)
+    }
+#undef SVSX_THRESH_CASE
+    return hipErrorInvalidValue;
+}
+
+// kk-th smallest key of one query's candidate lists (one wave per query): radix descent over the order-encoded keys held in
+// LDS.  Falls back to the coarser threshold when a list overflowed or holds fewer than kk rows.
+__global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict__ keys, const uint32_t* __restrict__ cnt, uint32_t nq,
+                                                         uint32_t n_slices, uint32_t cap, uint32_t kk, const float* __restrict__ fb,
+                                                         uint32_t fb_stride, float* __restrict__ out) {
+    __shared__ uint32_t buf[kFlatSelectCap];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    uint32_t total = 0;
+    const bool over = flat_overflow(cnt, q, n_slices, cap, total, kFlatSelectCap);
+    if (over || total < kk) {
+        if (lane == 0) out[q] = fb[static_cast<size_t>(q) * fb_stride];
+        return;
+    }
+    uint32_t off = 0;
+    for (uint32_t s2 = 0; s2 < n_slices; ++s2) {
+        const uint32_t c = cnt[static_cast<size_t>(q) * n_slices + s2];
+        const float* src = keys + (static_cast<size_t>(q) * n_slices + s2) * cap;
+        for (uint32_t i = lane; i < c; i += 64) buf[off + i] = enc_key(src[i]);
+        off += c;
+    }
+    lds_order();
+    uint32_t prefix = 0, remaining = kk;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t himask = bit == 31 ? 0u : ~((2u << bit) - 1u);
+        uint32_t zeros = 0;
+        for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool z = false;
+            if (i < total) {
+                const uint32_t v = buf[i];
+                z = (v & himask) == prefix && ((v >> bit) & 1u) == 0u;
+            }
+            zeros += static_cast<uint32_t>(__popcll(__ballot(z)));
+        }
+        if (remaining > zeros) {
+            remaining -= zeros;
+            prefix |= 1u << bit;
+        }
+    }
+    if (lane == 0) out[q] = dec_key(prefix);
+}
+
+hipError_t launch_flat_select(const float* cand_keys, const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t kk,
+                              const float* tau_fallback, uint32_t fallback_stride, float* tau_out, hipStream_t stream) {
+    hipLaunchKernelGGL(flat_select_kernel, dim3(nq), dim3(64), 0, stream, cand_keys, cnt, nq, n_slices, cap, kk, tau_fallback, fallback_stride, tau_out);
+    return hipGetLastError();
+}
+
+// one word per 64-query block: non-zero if any of its queries overflowed (that block re-runs the shortlist kernel)
+__global__ void flat_gate_kernel(const uint32_t* __restrict__ cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t* __restrict__ gate) {
+    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+    uint32_t total = 0;
+    const bool over = q < nq && flat_overflow(cnt, q, n_slices, cap, total);
+    const unsigned long long m = __ballot(over);
+    if (threadIdx.x == 0) gate[blockIdx.x] = m != 0ull ? 1u : 0u;
+}
+
+hipError_t launch_flat_gate(const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t* block_gate, hipStream_t stream) {
+    hipLaunchKernelGGL(flat_gate_kernel, dim3((nq + 63) / 64), dim3(64), 0, stream, cnt, nq, n_slices, cap, block_gate);
+    return hipGetLastError();
+}
+
 // ---- stage 3: exact re-rank of the shortlist --------------------------------------------------------------------------------
 template <int DT, int METRIC, int QMODE>
 __global__ __launch_bounds__(64) void rerank_kernel(const RerankArgs a) {
@@ -398,6 +664,108 @@ __global__ __launch_bounds__(64) void rerank_kernel(const RerankArgs a) {
     }
 }
 
+// ---- stage 3b: exact re-rank of a variable-length candidate list (threshold pass) ----------------------------------------------
+// Same exact-order distance routines as rerank_kernel; the k best by (distance, then id) are then extracted by k
+// rounds of a wave-wide arg-min over the list held in LDS.  A query whose list overflowed uses the gated shortlist path's
+// merged list instead.
+template <int DT, int METRIC, int QMODE>
+__global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool GREATER = METRIC != M_L2;
+    constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    constexpr bool BC = !INTPATH && use_block_cyclic<DT>();
+    constexpr int G = (INTPATH || BC) ? 4 : 16 / Elem<DT>::E;
+    constexpr int RPP = 64 / G;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const int d = static_cast<int>(a.d);
+    const int dpad = (d + 15) & ~15;
+    float* qf = reinterpret_cast<float*>(smem);
+    uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t q_bytes = INTPATH ? static_cast<uint32_t>(dpad) : static_cast<uint32_t>(dpad) * 4u;
+    const uint32_t cm = kFlatRerankCap > a.kk ? kFlatRerankCap : a.kk;
+    float* cd = reinterpret_cast<float*>(smem + q_bytes);
+    uint32_t* ci = reinterpret_cast<uint32_t*>(cd + cm);
+    const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
+    const QueryFix fx = prepare_query<DT, METRIC, QMODE>(qptr, a.q_dtype, d, dpad, qf, qw, a.sq_scale, a.sq_bias, lane);
+    const int sub = static_cast<int>(lane) & (G - 1);
+    const uint32_t grp = lane / G;
+    const unsigned char* data = static_cast<const unsigned char*>(a.data);
+    const float worst = GREATER ? -__builtin_inff() : __builtin_inff();
+    uint32_t total = 0;
+    const bool overflow = flat_overflow(a.cnt, qi, a.n_lists, a.cap, total);
+    const uint32_t c_n = overflow ? a.kk : total;
+    // gather the candidate ids into LDS
+    if (overflow) {
+        for (uint32_t c = lane; c < c_n; c += 64) {
+            const uint64_t id64 = a.cand_ids[static_cast<size_t>(qi) * a.kk + c];
+            ci[c] = id64 == ~0ull ? kInvalidId : static_cast<uint32_t>(id64);
+        }
+    } else {
+        uint32_t off = 0;
+        for (uint32_t l = 0; l < a.n_lists; ++l) {
+            const uint32_t c = a.cnt[static_cast<size_t>(qi) * a.n_lists + l];
+            const uint32_t* src = a.cand32 + (static_cast<size_t>(qi) * a.n_lists + l) * a.cap;
+            for (uint32_t i = lane; i < c; i += 64) ci[off + i] = src[i];
+            off += c;
+        }
+    }
+    lds_order();
+    for (uint32_t c0 = 0; c0 < c_n; c0 += RPP) {
+        const uint32_t c = c0 + grp;
+        uint32_t id = kInvalidId;
+        if (c < c_n) id = ci[c];
+        const bool act = id != kInvalidId;
+        const unsigned char* row = data + static_cast<size_t>(act ? id : 0u) * a.row_bytes;
+        float fmain = 0.0f, fnrm = 0.0f;
+        int ab = 0, bb = 0;
+        if constexpr (INTPATH) int_row_sums<DT>(row, act, qw, d, sub, ab, bb);
+        else if constexpr (BC) float_row_distance_bc<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+        else float_row_distance<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+        const float dist = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
+        if (c < c_n && sub == 0) cd[c] = act ? dist : worst;
+    }
+    lds_order();
+    for (uint32_t j = 0; j < a.k; ++j) {
+        float bd = worst;
+        uint32_t bi = kInvalidId, bp = 0;
+        for (uint32_t i = lane; i < c_n; i += 64) {
+            const uint32_t id = ci[i];
+            if (id == kInvalidId) continue;
+            const float dd = cd[i];
+            const bool better = bi == kInvalidId || cmpf<GREATER>(dd, bd) || (!cmpf<GREATER>(bd, dd) && id < bi);
+            if (better) { bd = dd; bi = id; bp = i; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(bd, off);
+            const uint32_t oi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(bi), off));
+            const uint32_t op = static_cast<uint32_t>(__shfl_xor(static_cast<int>(bp), off));
+            const bool take = oi != kInvalidId && (bi == kInvalidId || cmpf<GREATER>(od, bd) || (!cmpf<GREATER>(bd, od) && oi < bi));
+            if (take) { bd = od; bi = oi; bp = op; }
+        }
+        const bool have = bi != kInvalidId;
+        if (lane == 0) {
+            const size_t o = static_cast<size_t>(qi) * a.k + j;
+            if (a.ids64 != nullptr) a.ids64[o] = have ? static_cast<uint64_t>(bi) + a.id_offset : ~0ull;
+            if (a.dists != nullptr) a.dists[o] = have ? bd : __builtin_inff();
+            if (have) ci[bp] = kInvalidId;
+        }
+        lds_order();
+    }
+}
+
+template <int DT, int METRIC, int QMODE> static hipError_t launch_rerank2_one(const RerankArgs& a, hipStream_t stream) {
+    const int dpad = (static_cast<int>(a.d) + 15) & ~15;
+    const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    const size_t cm = kFlatRerankCap > a.kk ? kFlatRerankCap : a.kk;
+    const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + cm * 8;
+    auto kern = rerank2_kernel<DT, METRIC, QMODE>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
 template <int DT, int METRIC, int QMODE> static hipError_t launch_rerank_one(const RerankArgs& a, hipStream_t stream) {
     const int dpad = (static_cast<int>(a.d) + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
@@ -446,6 +814,51 @@ hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs
         case QM_SQ_L2:
             if (data_dtype == DT_I8) return launch_rerank_metric<DT_I8, QM_SQ_L2>(metric, a, stream);
             if (data_dtype == DT_U8) return launch_rerank_metric<DT_U8, QM_SQ_L2>(metric, a, stream);
+            break;
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int DT, int QMODE> static hipError_t launch_rerank2_metric(int metric, const RerankArgs& a, hipStream_t stream) {
+    switch (metric) {
+        case M_L2:
+            if constexpr (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_rerank2_one<DT, M_L2, QMODE>(a, stream);
+        case M_IP:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_rerank2_one<DT, M_IP, QMODE>(a, stream);
+        case M_COS:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_IP) return hipErrorInvalidValue;
+            else return launch_rerank2_one<DT, M_COS, QMODE>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_rerank2(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream) {
+    switch (qmode) {
+        case QM_FLOAT:
+            switch (data_dtype) {
+                case DT_F32: return launch_rerank2_metric<DT_F32, QM_FLOAT>(metric, a, stream);
+                case DT_F16: return launch_rerank2_metric<DT_F16, QM_FLOAT>(metric, a, stream);
+                case DT_I8: return launch_rerank2_metric<DT_I8, QM_FLOAT>(metric, a, stream);
+                case DT_U8: return launch_rerank2_metric<DT_U8, QM_FLOAT>(metric, a, stream);
+            }
+            break;
+        case QM_INT:
+            if (data_dtype == DT_I8) return launch_rerank2_metric<DT_I8, QM_INT>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank2_metric<DT_U8, QM_INT>(metric, a, stream);
+            break;
+        case QM_SQ_IP:
+            if (data_dtype == DT_I8) return launch_rerank2_metric<DT_I8, QM_SQ_IP>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank2_metric<DT_U8, QM_SQ_IP>(metric, a, stream);
+            break;
+        case QM_SQ_COS:
+            if (data_dtype == DT_I8) return launch_rerank2_metric<DT_I8, QM_SQ_COS>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank2_metric<DT_U8, QM_SQ_COS>(metric, a, stream);
+            break;
+        case QM_SQ_L2:
+            if (data_dtype == DT_I8) return launch_rerank2_metric<DT_I8, QM_SQ_L2>(metric, a, stream);
+            if (data_dtype == DT_U8) return launch_rerank2_metric<DT_U8, QM_SQ_L2>(metric, a, stream);
             break;
     }
     return hipErrorInvalidValue;

@@ -74,6 +74,7 @@ struct MergeArgs {
     float* out_dists;       // [nq][k]
     uint64_t* out_ids;      // [nq][k]
     uint32_t n_shards, nq, k;
+    const uint32_t* gate64;  // optional: one word per 64 queries; a query is merged only if its word is non-zero
 };
 hipError_t launch_merge(int metric, const MergeArgs& a, hipStream_t stream);
 
@@ -105,8 +106,30 @@ struct FlatArgs {
     uint32_t* gtau;         // nq order-encoded thresholds shared by the slices of a query block (init 0xFF800000 = +inf), or NULL
     float* out_keys;        // [n_slices][nq][kk]
     uint64_t* out_ids;      // [n_slices][nq][kk]
+    uint32_t tile_step;     // visit every tile_step-th 32-row tile of the slice (1 = all; > 1 = strided sample)
+    const uint32_t* block_gate; // optional, one word per 64-query block: the block only runs if its word is non-zero
 };
 hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream);
+// threshold pass: every (query, row) whose f16 key is <= tau[query] is appended to the (query, slice) candidate list
+struct FlatThreshArgs {
+    const void* xh;
+    const float* xnorm2;
+    uint32_t n, dpad;
+    const void* qh;
+    uint32_t nq, n_slices;
+    uint32_t tile_step;     // only 32-row tiles whose global index is a multiple of tile_step (1 = all)
+    const float* tau;       // tau[q * tau_stride]
+    uint32_t tau_stride;
+    uint32_t* cand;         // [nq][n_slices][cap] row ids, unordered
+    float* cand_keys;       // optional, same shape: the f16-pass key of each appended row
+    uint32_t* cnt;          // [nq][n_slices] rows below the threshold (may exceed cap: overflow)
+    uint32_t cap;           // per (query, slice)
+};
+hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t stream);   // dpad <= 128 only
+// tau_out[q] = kk-th smallest key of query q's lists; tau_fallback[q * stride] if a list overflowed or fewer than kk rows
+hipError_t launch_flat_select(const float* cand_keys, const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t kk,
+                              const float* tau_fallback, uint32_t fallback_stride, float* tau_out, hipStream_t stream);
+hipError_t launch_flat_gate(const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t* block_gate, hipStream_t stream);
 struct RerankArgs {
     const void* data;
     size_t row_bytes;
@@ -118,10 +141,16 @@ struct RerankArgs {
     int q_dtype;
     uint32_t nq, kk, k;
     const uint64_t* cand_ids;   // [nq][kk], ~0 = empty
+    // candidate lists of the threshold pass (rerank2): cand32 [nq][n_lists][cap] with cnt[q][list] entries; a query with
+    // an overflowed list (cnt > cap) falls back to cand_ids
+    const uint32_t* cand32;
+    const uint32_t* cnt;
+    uint32_t cap, n_lists;
     uint64_t* ids64;            // [nq][k]
     float* dists;               // [nq][k]
 };
 hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
+hipError_t launch_rerank2(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
 
 // layout conversion kernels (index creation)
 // bound codes (svsx_index_build_bound_codes): d_mm3 = {min key, max key, non-finite count}

@@ -518,3 +518,41 @@ def test_malformed_graph_is_rejected(svs):
     g[2, 0] = 7  # degree larger than the row
     with pytest.raises(svs.SvsxError):
         svs.VamanaIndex(g, x, svs.DistanceL2(), [0])
+
+
+@pytest.mark.parametrize("metric,d", [(L2, 96), (IP, 100), (COS, 32), (L2, 128)])
+def test_flat_search_threshold_pipeline(svs, oracle, metric, d):
+    """n >= 65536 and d <= 128 take the sample-threshold-append pipeline (svsx_flat.hip stage 1b / 3b): same answers as the
+    oracle's exhaustive search, ties by lower id."""
+    fn = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}[metric]
+    n, nq = 70_000, 100
+    x = deep_like(n, d, 12, seed=31, normalize=metric == L2)
+    q = deep_like(nq, d, 12, seed=32, normalize=metric == L2)
+    idx = svs.FlatIndex(x, fn)
+    for k in (10, 32):
+        res = idx.search(q, k)
+        ids, dists = oracle.flat_search(metric, x, q, k)
+        same = res.indices == ids.astype(np.uint64)
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all(), (metric, d, k)
+        assert same.mean() > 0.999 or (same | (res.distances == dists)).all()
+
+
+def test_flat_search_threshold_overflow_falls_back(svs, oracle):
+    """three distinct vectors repeated 70 000 times: every key ties with the threshold, every candidate list overflows, the
+    gated shortlist pass takes over; the answer is still the exhaustive one (equal distances -> lowest ids)."""
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((3, 96)).astype(np.float32)
+    x = base[np.arange(70_000) % 3].copy()
+    q = base + np.float32(0.01) * rng.standard_normal((3, 96)).astype(np.float32)
+    idx = svs.FlatIndex(x, svs.DistanceL2())
+    res = idx.search(q, 10)
+    ids, dists = oracle.flat_search(L2, x, q, 10)
+    assert (res.indices == ids.astype(np.uint64)).all() and (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+    # unrepresentative sample: the sampled tiles (every 16th tile of 32 rows in a slice) hold far rows, the rest near ones
+    x2 = deep_like(80_000, 96, 12, seed=41)
+    q2 = deep_like(40, 96, 12, seed=42)
+    x2[(np.arange(80_000) // 32) % 4 == 0] *= np.float32(25.0)  # a superset of every possible sample tile pattern
+    idx2 = svs.FlatIndex(x2, svs.DistanceL2())
+    res2 = idx2.search(q2, 10)
+    ids2, dists2 = oracle.flat_search(L2, x2, q2, 10)
+    assert (res2.indices == ids2.astype(np.uint64)).all() and (res2.distances.view(np.uint32) == dists2.view(np.uint32)).all()
