@@ -343,7 +343,7 @@ hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
 // this kernel on every 16th tile with that threshold, then flat_select_kernel -> the kk-th best key of the 1/16 sample,
 // which at least kk rows satisfy by construction.
 constexpr uint32_t kFlatRerankCap = 2048; // candidates per query the exact re-rank accepts (LDS)
-constexpr uint32_t kFlatSelectCap = 8192; // keys per query the threshold selection accepts (LDS)
+constexpr uint32_t kFlatSelectCap = 4096; // keys per query the threshold selection accepts (LDS)
 
 __device__ __forceinline__ bool flat_overflow(const uint32_t* cnt, uint32_t q, uint32_t n_slices, uint32_t cap, uint32_t& total,
                                               uint32_t total_cap = kFlatRerankCap) {
@@ -355,6 +355,36 @@ __device__ __forceinline__ bool flat_overflow(const uint32_t* cnt, uint32_t q, u
         total += c;
     }
     return over || total > total_cap;
+}
+
+// Offsets of one query's (query, slice) lists in the flattened candidate order: loff[s] = sum of the counts of slices < s
+// (loff[n_slices] = total).  n_slices <= 1024.  All lanes then walk the flattened index space in parallel (independent
+// loads) and find an element's slice by binary search in LDS.
+constexpr uint32_t kFlatMaxSlices = 1024;
+__device__ __forceinline__ void flat_list_offsets(const uint32_t* cnt, uint32_t q, uint32_t n_slices, uint32_t* loff, uint32_t lane) {
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0; s0 < n_slices; s0 += 64) {
+        const uint32_t s2 = s0 + lane;
+        const uint32_t c = s2 < n_slices ? cnt[static_cast<size_t>(q) * n_slices + s2] : 0u;
+        uint32_t incl = c; // inclusive scan across the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), off));
+            if (lane >= static_cast<uint32_t>(off)) incl += v;
+        }
+        if (s2 < n_slices) loff[s2] = carry + incl - c;
+        carry += static_cast<uint32_t>(__shfl(static_cast<int>(incl), 63));
+    }
+    if (lane == 0) loff[n_slices] = carry;
+    lds_order();
+}
+__device__ __forceinline__ uint32_t flat_find_slice(const uint32_t* loff, uint32_t n_slices, uint32_t e) {
+    uint32_t lo = 0, hi = n_slices; // largest s with loff[s] <= e
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (loff[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
 template <int METRIC, int KS>
@@ -549,12 +579,11 @@ __global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict
         if (lane == 0) out[q] = fb[static_cast<size_t>(q) * fb_stride];
         return;
     }
-    uint32_t off = 0;
-    for (uint32_t s2 = 0; s2 < n_slices; ++s2) {
-        const uint32_t c = cnt[static_cast<size_t>(q) * n_slices + s2];
-        const float* src = keys + (static_cast<size_t>(q) * n_slices + s2) * cap;
-        for (uint32_t i = lane; i < c; i += 64) buf[off + i] = enc_key(src[i]);
-        off += c;
+    __shared__ uint32_t loff[kFlatMaxSlices + 1];
+    flat_list_offsets(cnt, q, n_slices, loff, lane);
+    for (uint32_t e = lane; e < total; e += 64) {
+        const uint32_t s2 = flat_find_slice(loff, n_slices, e);
+        buf[e] = enc_key(keys[(static_cast<size_t>(q) * n_slices + s2) * cap + (e - loff[s2])]);
     }
     lds_order();
     uint32_t prefix = 0, remaining = kk;
@@ -702,12 +731,11 @@ __global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
             ci[c] = id64 == ~0ull ? kInvalidId : static_cast<uint32_t>(id64);
         }
     } else {
-        uint32_t off = 0;
-        for (uint32_t l = 0; l < a.n_lists; ++l) {
-            const uint32_t c = a.cnt[static_cast<size_t>(qi) * a.n_lists + l];
-            const uint32_t* src = a.cand32 + (static_cast<size_t>(qi) * a.n_lists + l) * a.cap;
-            for (uint32_t i = lane; i < c; i += 64) ci[off + i] = src[i];
-            off += c;
+        uint32_t* loff = ci + cm; // n_lists + 1 words behind the id array
+        flat_list_offsets(a.cnt, qi, a.n_lists, loff, lane);
+        for (uint32_t e = lane; e < total; e += 64) {
+            const uint32_t l = flat_find_slice(loff, a.n_lists, e);
+            ci[e] = a.cand32[(static_cast<size_t>(qi) * a.n_lists + l) * a.cap + (e - loff[l])];
         }
     }
     lds_order();
@@ -759,7 +787,7 @@ template <int DT, int METRIC, int QMODE> static hipError_t launch_rerank2_one(co
     const int dpad = (static_cast<int>(a.d) + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     const size_t cm = kFlatRerankCap > a.kk ? kFlatRerankCap : a.kk;
-    const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + cm * 8;
+    const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + cm * 8 + (static_cast<size_t>(a.n_lists) + 1) * 4;
     auto kern = rerank2_kernel<DT, METRIC, QMODE>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), lds, stream, a);
