@@ -127,6 +127,8 @@ template <typename T, typename Dist> class VamanaIndex {
         search(r.view(), queries, defaults_);
         return r;
     }
+    // optional, result-neutral: 128 B of lower-bound codes per vector (float32 L2, d = 96 / 128); see svsx.h
+    void build_bound_codes(bool enable = true) { check(svsx_index_build_bound_codes(h_, enable ? 1 : 0)); }
     const svsx_index* handle() const { return h_; }
     size_t size() const { uint64_t info[6]; check(svsx_index_info(h_, info)); return info[0]; }
 };
