@@ -116,3 +116,65 @@ def test_bound_codes_scope(svs, oracle, small_world):
     got = it.next(10)[0]
     for i in range(4):
         assert (got[i] == oracle.iterate(L2, sw["x"], sw["graph"], sw["entry"], sw["q"][i], [10])[0][0][0].astype(np.uint64)).all()
+
+
+# ---- scalar-quantized indexes (IP / cosine): integer similarity bound --------------------------------------------------
+IP, COS = 1, 2
+I8, U8 = 2, 3
+
+
+def _u64(ids):
+    out = ids.astype(np.uint64)
+    out[ids == np.uint32(0xFFFFFFFF)] = np.iinfo(np.uint64).max  # padding of rows with fewer than k results
+    return out
+
+
+def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24):
+    codes, sc, bias = oracle.sq_compress(x, code_dtype)
+    g, e = oracle.build_vamana(metric, x, R=R, L=40)
+    fn = svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
+    idx = svs.VamanaIndex(g, codes, fn, e, sq=(sc, bias))
+    idx.build_bound_codes()
+    rej = 0
+    for w, c, k, vis in configs:
+        res, st = idx.search(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
+        ids, dists, ost = oracle.search(metric, codes, g, e, q, k, w, c, visited_set=bool(vis), sq=(sc, bias), stats=True)
+        assert (res.indices == _u64(ids)).all(), (metric, code_dtype, w, c, k, vis)
+        assert (_bits(res.distances) == _bits(dists)).all(), (metric, code_dtype, w, c, k, vis)
+        assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
+        rej += int(st[:, 5].sum())
+    idx.build_bound_codes(False)
+    res, st = idx.search(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), stats=True)
+    ids, _ = oracle.search(metric, codes, g, e, q, 10, 20, sq=(sc, bias))
+    assert (res.indices == _u64(ids)).all() and st[:, 5].sum() == 0
+    return rej
+
+
+@pytest.mark.parametrize("metric", [IP, COS])
+@pytest.mark.parametrize("code_dtype", [I8, U8])
+def test_sq_similarity_bound(svs, oracle, metric, code_dtype):
+    x = deep_like(1500, 768, 32, seed=61, normalize=False)
+    q = deep_like(24, 768, 32, seed=62, normalize=False)
+    rej = _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS)
+    assert rej > 500
+    x = deep_like(1200, 100, 16, seed=63, normalize=False)  # runtime dimension, ragged tail
+    q = deep_like(24, 100, 16, seed=64, normalize=False)
+    _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sq_similarity_bound_fuzz(svs, oracle, seed):
+    """offsets that make the bias term dominate, tiny and huge scales, queries (nearly) orthogonal to everything, zero query"""
+    rng = np.random.default_rng(200 + seed)
+    d = int(rng.choice([64, 96, 200, 768]))
+    n = int(rng.integers(300, 1200))
+    x = deep_like(n, d, int(rng.integers(4, 40)), seed=seed + 70, normalize=bool(seed & 1))
+    x = (x * np.float32(10.0 ** rng.uniform(-3, 3)) + np.float32(rng.uniform(-1, 1) * (10.0 ** rng.uniform(-2, 2)))).astype(np.float32)
+    q = x[rng.integers(0, n, 20)] + rng.standard_normal((20, d)).astype(np.float32) * np.float32(np.abs(x).mean() * 0.3)
+    q[0] = 0.0
+    q[1] = rng.standard_normal(d).astype(np.float32) * np.float32(1e-6)
+    q[2] = -x[5]
+    q[3:6] -= q[3:6].mean(axis=1, keepdims=True)  # sum(q) = 0: the bias term vanishes, q.c is all there is
+    metric = IP if seed % 2 == 0 else COS
+    code_dtype = I8 if seed % 3 else U8
+    _check_sq(svs, oracle, metric, x, q, code_dtype, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)])
