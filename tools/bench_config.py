@@ -94,8 +94,20 @@ def main():
     for _ in range(a.steps): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.steps
+    ms_plain = None
+    if a.bound_codes:  # same index without the bound, for the A/B in one process
+        ids_b = ids.clone()
+        stats_b = stats.clone()
+        idx.build_bound_codes(False)
+        for _ in range(2): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
+        e0.record()
+        for _ in range(a.steps): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
+        e1.record(); torch.cuda.synchronize()
+        ms_plain = e0.elapsed_time(e1) / a.steps
+        assert bool((ids == ids_b).all()), "bound codes changed the result"
+        idx.build_bound_codes()
     out = dict(config=vars(a), build_s=t_build, mean_degree=float((graph[:, :a.degree] >= 0).sum(1).float().mean()), recall_at_10=rec, ms_per_batch=ms,
-               qps=a.nq / ms * 1e3, expansions=exp / a.nq, slots=slots / a.nq, alg_GB=alg / 1e9, achieved_GBs=alg / ms / 1e6, frac_of_8TBs=alg / ms / 1e6 / 8000)
+               qps=a.nq / ms * 1e3, ms_per_batch_without_bound=ms_plain, bound_rejects_per_query=float(stats[:, 5].sum()) / a.nq, evals_per_query=float(stats[:, 2].sum()) / a.nq, expansions=exp / a.nq, slots=slots / a.nq, alg_GB=alg / 1e9, achieved_GBs=alg / ms / 1e6, frac_of_8TBs=alg / ms / 1e6 / 8000)
     if a.cpu:
         from oracle.oracle import COS, IP, L2, Oracle, Ref
         m = {"l2": L2, "ip": IP, "cos": COS}[a.metric]
