@@ -215,10 +215,8 @@ int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
  * 8-bit codes of its first min(d, 120) components and the exact coding error.  The search kernel turns them into a
  * rigorous LOWER BOUND of the L2 distance and drops candidates that can_skip (search_buffer.h:338-340) would drop anyway
  * before their full row is fetched -- ids and distances returned are unchanged, HBM traffic per candidate falls from 3
- * lines to about 1.  float32 data, L2, d = 96 or 128; +128 B of HBM per vector.
- * Scalar-quantized indexes (sq_enabled, IP / cosine) get the integer-arithmetic analogue instead: per-row code sums
- * (8 B per vector) from which an upper bound of the similarity is computed with v_dot4 before the float kernel runs.
- * Anything else: SVSX_NOT_IMPLEMENTED.  enable = 0 frees them.  Call while no search is in flight on this index. */
+ * lines to about 1.  float32 data, L2, d = 96 or 128 (SVSX_NOT_IMPLEMENTED otherwise); +128 B of HBM per vector.
+ * enable = 0 frees them.  Call while no search is in flight on this index. */
 int svsx_index_build_bound_codes(svsx_index* index, int enable);
 
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),

@@ -41,7 +41,6 @@ struct svsx_index {
     // bound codes (svsx_index_build_bound_codes): 128 B per vector
     void* d_codes = nullptr;
     float code_scale = 1.0f, code_bias = 0.0f;
-    int32_t* d_sq_sums = nullptr; // SQ index, IP / cosine: per-row {sum(code), sum(code^2)}
 };
 
 namespace {
@@ -252,7 +251,6 @@ void svsx_index_destroy(svsx_index* ix) {
     if (ix->d_half) (void)hipFree(ix->d_half);
     if (ix->d_norm2) (void)hipFree(ix->d_norm2);
     if (ix->d_codes) (void)hipFree(ix->d_codes);
-    if (ix->d_sq_sums) (void)hipFree(ix->d_sq_sums);
     delete ix;
 }
 
@@ -274,28 +272,12 @@ int svsx_index_build_bound_codes(svsx_index* ix, int enable) {
     if (!enable) {
         HIP_TRY(hipDeviceSynchronize());
         if (ix->d_codes) (void)hipFree(ix->d_codes);
-        if (ix->d_sq_sums) (void)hipFree(ix->d_sq_sums);
         ix->d_codes = nullptr;
-        ix->d_sq_sums = nullptr;
         return SVSX_SUCCESS;
     }
-    if (ix->d_codes || ix->d_sq_sums) return SVSX_SUCCESS;
-    if (ix->sq_enabled && (ix->metric == M_IP || ix->metric == M_COS) && (ix->data_dtype == DT_I8 || ix->data_dtype == DT_U8)) {
-        // scalar-quantized rows already are 8-bit codes: only their integer sums are needed for the similarity bound
-        int32_t* sums = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sums), ix->n * 8));
-        hipError_t e2 = launch_sq_sums(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n),
-                                       static_cast<uint32_t>((ix->d + 15) & ~size_t(15)), sums, nullptr);
-        if (e2 == hipSuccess) e2 = hipDeviceSynchronize();
-        if (e2 != hipSuccess) {
-            (void)hipFree(sums);
-            return fail(SVSX_RUNTIME_ERROR, "code sum kernel failed: %s", hipGetErrorString(e2));
-        }
-        ix->d_sq_sums = sums;
-        return SVSX_SUCCESS;
-    }
+    if (ix->d_codes) return SVSX_SUCCESS;
     if (ix->metric != M_L2 || ix->data_dtype != DT_F32 || ix->sq_enabled || (ix->d != 96 && ix->d != 128))
-        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 L2 indexes of dimension 96 or 128 and scalar-quantized IP / cosine indexes");
+        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 L2 indexes of dimension 96 or 128");
     const uint32_t dc = static_cast<uint32_t>(ix->d < 120 ? ix->d : 120);
     DeviceBuffer mm;
     HIP_TRY(mm.alloc(12));
@@ -339,7 +321,6 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     a.q_row_bytes = q_row_bytes;
     a.nq = static_cast<uint32_t>(nq);
     a.general = ix->n_entry > 16 ? 1u : 0u; // std::sort of > 16 entry points is not a stable insertion sort
-    if (ix->d_sq_sums && !a.general) a.sq_sums = ix->d_sq_sums;
     if (ix->d_codes && !a.general) { // result-neutral lower-bound rejection (float queries on float32 L2 rows)
         a.codes = static_cast<const unsigned char*>(ix->d_codes);
         a.code_scale = ix->code_scale;
@@ -865,7 +846,6 @@ int svsx_iterator_next_device(
     SearchArgs a = base_search_args(ix, it->d_queries, it->q_dtype, it->q_stride, it->nq);
     a.general = 1;
     a.codes = nullptr;
-    a.sq_sums = nullptr;
     a.window = static_cast<uint32_t>(cap); // per-query values come from the state table; this sizes the LDS buffer
     a.capacity = static_cast<uint32_t>(cap);
     default_filter(ix, a, (ix->n >> 12) < 0xFFu ? 4096u : kDefaultFilterEntries); // result-neutral within one call

@@ -223,48 +223,6 @@ hipError_t launch_codes_build(const void* d_data, size_t row_bytes, uint32_t n, 
     return hipGetLastError();
 }
 
-// per-row {sum(c), sum(c^2)} of 8-bit code rows (zero padded to 16): exact v_dot4 sums, 4 rows per wave
-template <int DT> __global__ __launch_bounds__(64) void sq_sums_kernel(const unsigned char* __restrict__ codes, size_t row_bytes, uint32_t n, uint32_t dpad,
-                                                                      int32_t* __restrict__ sums) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t row = blockIdx.x * 4u + (lane >> 4);
-    const uint32_t sub = lane & 15u;
-    int s1 = 0, s2 = 0;
-    if (row < n) {
-        const unsigned char* r = codes + static_cast<size_t>(row) * row_bytes;
-        for (uint32_t b = sub * 16u; b < dpad; b += 256u) {
-            const uint4 v = *reinterpret_cast<const uint4*>(r + b);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if constexpr (DT == DT_I8) {
-                    s1 = __builtin_amdgcn_sdot4(w[t], 0x01010101u, s1, false);
-                    s2 = __builtin_amdgcn_sdot4(w[t], w[t], s2, false);
-                } else {
-                    s1 = static_cast<int>(__builtin_amdgcn_udot4(w[t], 0x01010101u, static_cast<unsigned>(s1), false));
-                    s2 = static_cast<int>(__builtin_amdgcn_udot4(w[t], w[t], static_cast<unsigned>(s2), false));
-                }
-            }
-        }
-    }
-    for (int off = 8; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off);
-        s2 += __shfl_xor(s2, off);
-    }
-    if (row < n && sub == 0) {
-        sums[2 * static_cast<size_t>(row)] = s1;
-        sums[2 * static_cast<size_t>(row) + 1] = s2;
-    }
-}
-
-hipError_t launch_sq_sums(int dtype, const void* d_codes, size_t row_bytes, uint32_t n, uint32_t dpad, int32_t* d_sums, hipStream_t stream) {
-    const dim3 grid((n + 3) / 4);
-    if (dtype == DT_I8) hipLaunchKernelGGL(sq_sums_kernel<DT_I8>, grid, dim3(64), 0, stream, static_cast<const unsigned char*>(d_codes), row_bytes, n, dpad, d_sums);
-    else if (dtype == DT_U8) hipLaunchKernelGGL(sq_sums_kernel<DT_U8>, grid, dim3(64), 0, stream, static_cast<const unsigned char*>(d_codes), row_bytes, n, dpad, d_sums);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
 hipError_t launch_pack_graph(const uint32_t* d_in, uint32_t in_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, uint32_t* d_bad, hipStream_t stream) {
     hipLaunchKernelGGL(pack_graph_kernel, dim3(n), dim3(64), 0, stream, d_in, in_stride, n, d_out, out_stride, d_bad);
     return hipGetLastError();

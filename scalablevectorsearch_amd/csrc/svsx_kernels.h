@@ -40,9 +40,6 @@ struct SearchArgs {
     // optional 128-B bound-code rows (f32 L2, d = 96 or 128): rigorous lower-bound rejection before a row is fetched
     const unsigned char* codes;
     float code_scale, code_bias;
-    // optional per-row {sum(code), sum(code^2)} of a scalar-quantized index (IP / cosine): integer upper bound of the
-    // similarity before the float kernel runs (svsx_index_build_bound_codes on an SQ index)
-    const int32_t* sq_sums;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
     uint32_t general;
     // BatchIterator (index/vamana/iterator.h): per-query state in HBM.  meta = 8 u32 per query:
@@ -156,7 +153,6 @@ hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs
 hipError_t launch_rerank2(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
 
 // layout conversion kernels (index creation)
-hipError_t launch_sq_sums(int dtype, const void* d_codes, size_t row_bytes, uint32_t n, uint32_t dpad, int32_t* d_sums, hipStream_t stream);
 // bound codes (svsx_index_build_bound_codes): d_mm3 = {min key, max key, non-finite count}
 hipError_t launch_codes_minmax(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, uint32_t* d_mm3, hipStream_t stream);
 float codes_key_to_float(uint32_t key);

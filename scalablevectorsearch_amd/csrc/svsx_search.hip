@@ -62,10 +62,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     const bool tag8 = a.filter_tag8 != 0u;
     const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
-    constexpr bool SQB = QMODE == QM_SQ_IP || QMODE == QM_SQ_COS; // scalar-quantized rows: integer similarity bound available
-    const bool has_compact = a.filter_entries != 0u || CODES || (SQB && a.sq_sums != nullptr);
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + (has_compact ? 256u : 0u)); // GENERAL only
-    unsigned char* qcode = smem + buf_bytes + q_bytes + filt_bytes + (has_compact ? 256u : 0u) + (GENERAL ? 512u : 0u); // SQB only: dpad bytes
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES) ? 256u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -147,60 +144,6 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         code_eq = __builtin_sqrtf(e2) * 1.001f + 1.0e-7f;
         if (!(code_eq < 3.0e38f)) code_eq = __builtin_inff(); // non-finite query: the bound never fires
         code_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, code_eq)));
-    }
-
-    // ---- scalar-quantized rows, IP / cosine: integer upper bound of the similarity --------------------------------------
-    // The rows already are 8-bit codes c (x_j = scale c_j + bias).  With the query coded to 8 bits once per wave,
-    // q = sq cq + rq, the dot product q.c = sq (cq.c) + rq.c lies within |rq| |c| of an exact integer dot product
-    // (v_dot4), and |x|^2 = scale^2 S2 + 2 scale bias S1 + d bias^2 follows from the per-row sums S1, S2.  A candidate
-    // whose upper bound is already below the worst buffer entry is skipped by can_skip whatever its exact value, and the
-    // float kernel (decompress + 2 fma per element, the cost of this path) never runs for it.
-    float sqb_sq = 0.0f, sqb_rq = 0.0f, sqb_sumq = 0.0f, sqb_sabs = 0.0f, sqb_qn = 0.0f;
-    bool sqb_on = false;
-    if constexpr (SQB) {
-        if (a.sq_sums != nullptr) {
-            float amax = 0.0f, sm = 0.0f, sa = 0.0f, q2 = 0.0f;
-            for (int i = static_cast<int>(lane); i < d; i += 64) {
-                const float v = qf[i];
-                const float av = __builtin_fabsf(v);
-                amax = av > amax ? av : amax;
-                sm += v;
-                sa += av;
-                q2 += v * v;
-            }
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float o = __shfl_xor(amax, off);
-                amax = o > amax ? o : amax;
-                sm += __shfl_xor(sm, off);
-                sa += __shfl_xor(sa, off);
-                q2 += __shfl_xor(q2, off);
-            }
-            sqb_qn = __builtin_sqrtf(q2) * 1.0001f;
-            if (amax > 0.0f && amax < 3.0e38f) {
-                const float sqn = amax / 127.0f;
-                const float inv = 1.0f / sqn;
-                float r2 = 0.0f;
-                for (int i = static_cast<int>(lane); i < dpad; i += 64) {
-                    int c = 0;
-                    if (i < d) {
-                        const float v = qf[i];
-                        float cf = __builtin_rintf(v * inv);
-                        cf = cf < -127.0f ? -127.0f : (cf > 127.0f ? 127.0f : cf);
-                        const float r = v - sqn * cf;
-                        r2 += r * r;
-                        c = static_cast<int>(cf);
-                    }
-                    qcode[i] = static_cast<unsigned char>(DT == DT_U8 ? c + 128 : c); // unsigned rows: shifted query codes
-                }
-                for (int off = 32; off >= 1; off >>= 1) r2 += __shfl_xor(r2, off);
-                sqb_sq = sqn;
-                sqb_rq = __builtin_sqrtf(r2) * 1.001f + 1.0e-30f;
-                sqb_sumq = sm;
-                sqb_sabs = sa;
-                sqb_on = sqb_rq < 3.0e38f;
-                lds_order();
-            }
-        }
     }
 
     // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
@@ -403,91 +346,6 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                     cnt = nsurv;
                 }
             }
-            if constexpr (SQB) {
-                if (sqb_on && full && cnt > 0u) {
-                    static_assert(!SQB || G == 4, "scalar-quantized rows use four lanes per row");
-                    const uint32_t nch = static_cast<uint32_t>(dpad) >> 4; // 16-B chunks per row
-                    uint32_t nsurv = 0;
-                    for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
-                        const uint32_t ci = p0 + grp;
-                        const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
-                        const bool act = ci < cnt;
-                        const unsigned char* row = data + static_cast<size_t>(act ? cid : 0u) * a.row_bytes;
-                        int dot = 0;
-#pragma unroll 1
-                        for (uint32_t ch0 = 0; ch0 < nch; ch0 += 16u) { // four 16-B loads per lane in flight
-                            uint4 xv[4], qv[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const uint32_t ch = ch0 + 4u * static_cast<uint32_t>(u) + static_cast<uint32_t>(sub);
-                                const bool in = ch < nch;
-                                xv[u] = *reinterpret_cast<const uint4*>(row + 16u * (in ? ch : 0u));
-                                qv[u] = *reinterpret_cast<const uint4*>(qcode + 16u * (in ? ch : 0u));
-                                if (!in) qv[u] = make_uint4(0u, 0u, 0u, 0u);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if constexpr (DT == DT_I8) {
-                                    dot = __builtin_amdgcn_sdot4(xv[u].x, qv[u].x, dot, false);
-                                    dot = __builtin_amdgcn_sdot4(xv[u].y, qv[u].y, dot, false);
-                                    dot = __builtin_amdgcn_sdot4(xv[u].z, qv[u].z, dot, false);
-                                    dot = __builtin_amdgcn_sdot4(xv[u].w, qv[u].w, dot, false);
-                                } else {
-                                    dot = static_cast<int>(__builtin_amdgcn_udot4(xv[u].x, qv[u].x, static_cast<unsigned>(dot), false));
-                                    dot = static_cast<int>(__builtin_amdgcn_udot4(xv[u].y, qv[u].y, static_cast<unsigned>(dot), false));
-                                    dot = static_cast<int>(__builtin_amdgcn_udot4(xv[u].z, qv[u].z, static_cast<unsigned>(dot), false));
-                                    dot = static_cast<int>(__builtin_amdgcn_udot4(xv[u].w, qv[u].w, static_cast<unsigned>(dot), false));
-                                }
-                            }
-                        }
-                        dot += xor1i(dot);
-                        dot += xor2i(dot);
-                        int s1 = 0, s2 = 0;
-                        if (act && sub == 0) {
-                            const int2 ss = *reinterpret_cast<const int2*>(a.sq_sums + 2 * static_cast<size_t>(cid));
-                            s1 = ss.x;
-                            s2 = ss.y;
-                        }
-                        s1 += xor1i(s1); s1 += xor2i(s1);
-                        s2 += xor1i(s2); s2 += xor2i(s2);
-                        const int itrue = DT == DT_U8 ? dot - 128 * s1 : dot; // cq . c
-                        const float sqrt_s2 = __builtin_sqrtf(static_cast<float>(s2)) * 1.000001f;
-                        const float qc_mid = sqb_sq * static_cast<float>(itrue);
-                        const float qc_err = sqb_rq * sqrt_s2;
-                        const float ascale = __builtin_fabsf(a.sq_scale), abias = __builtin_fabsf(a.sq_bias);
-                        // Upper bound of the reference's numerator scale (q.c) + bias sum(q):  the real-arithmetic bound,
-                        // + the rounding of this very expression, + the reference's own f32 accumulation error, which is at
-                        // most d 2^-23 sum |q_j x_j| <= acc_eps (|scale| |q| |c| + |bias| sum |q|).
-                        const float acc_eps = static_cast<float>(d) * 1.2e-7f + 1.0e-6f;
-                        const float bterm = a.sq_bias * sqb_sumq;
-                        const float num_ub = a.sq_scale * qc_mid + ascale * qc_err + bterm +
-                                             1.0e-6f * (ascale * (__builtin_fabsf(qc_mid) + qc_err) + __builtin_fabsf(bterm)) +
-                                             acc_eps * (ascale * sqb_qn * sqrt_s2 + abias * sqb_sabs) + 1.0e-30f;
-                        bool rej;
-                        if constexpr (QMODE == QM_SQ_IP) {
-                            rej = num_ub < worst;
-                        } else {
-                            const double x2 = static_cast<double>(a.sq_scale) * a.sq_scale * s2 + 2.0 * a.sq_scale * a.sq_bias * s1 +
-                                              static_cast<double>(d) * a.sq_bias * a.sq_bias;
-                            const float xn = static_cast<float>(__builtin_sqrt(x2 > 0.0 ? x2 : 0.0));
-                            // the reference's |x| carries the same kind of accumulation error: widen by acc_eps
-                            const float xn_lo = xn * (1.0f - acc_eps), xn_hi = xn * (1.0f + acc_eps);
-                            const float sim_ub = num_ub / (fx.norm * (num_ub >= 0.0f ? xn_lo : xn_hi)) * (num_ub >= 0.0f ? 1.000001f : 0.999999f) + 1.0e-6f;
-                            rej = x2 > 0.0 && fx.norm > 0.0f && xn_lo > 0.0f && (sim_ub < worst);
-                        }
-                        const bool surv = act && !rej && sub == 0;
-                        const unsigned long long smask = __ballot(surv);
-                        if (surv) compact[nsurv + __popcll(smask & ((1ull << lane) - 1ull))] = cid;
-                        nsurv += __popcll(smask);
-                    }
-                    lds_order();
-                    nid = lane < nsurv ? compact[lane] : kInvalidId;
-                    lds_order();
-                    n_code_rej += cnt - nsurv;
-                    n_eval += cnt - nsurv;
-                    cnt = nsurv;
-                }
-            }
             for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
                 const uint32_t ci = p0 + grp;
                 const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
@@ -599,11 +457,10 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODE
     const int d = static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
-    const bool sqb = (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && a.sq_sums != nullptr;
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       ((a.filter_entries || CODES || sqb) ? 64 * 4 : 0) + (GENERAL ? 64 * 8 : 0) + (sqb ? static_cast<size_t>(dpad) : 0);
+                       ((a.filter_entries || CODES) ? 64 * 4 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES>;
     if (lds > 48 * 1024) {

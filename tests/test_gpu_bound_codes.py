@@ -118,7 +118,7 @@ def test_bound_codes_scope(svs, oracle, small_world):
         assert (got[i] == oracle.iterate(L2, sw["x"], sw["graph"], sw["entry"], sw["q"][i], [10])[0][0][0].astype(np.uint64)).all()
 
 
-# ---- scalar-quantized indexes (IP / cosine): integer similarity bound --------------------------------------------------
+# ---- scalar-quantized indexes (IP / cosine): adversarial parity (a bound is not offered for them, see profiles/r01_notes.md) ------
 IP, COS = 1, 2
 I8, U8 = 2, 3
 
@@ -134,7 +134,8 @@ def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24):
     g, e = oracle.build_vamana(metric, x, R=R, L=40)
     fn = svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
     idx = svs.VamanaIndex(g, codes, fn, e, sq=(sc, bias))
-    idx.build_bound_codes()
+    with pytest.raises(svs.SvsxError):
+        idx.build_bound_codes()  # NOT_IMPLEMENTED: measured to buy nothing on these rows
     rej = 0
     for w, c, k, vis in configs:
         res, st = idx.search(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
@@ -143,28 +144,25 @@ def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24):
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, code_dtype, w, c, k, vis)
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
         rej += int(st[:, 5].sum())
-    idx.build_bound_codes(False)
-    res, st = idx.search(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), stats=True)
-    ids, _ = oracle.search(metric, codes, g, e, q, 10, 20, sq=(sc, bias))
-    assert (res.indices == _u64(ids)).all() and st[:, 5].sum() == 0
     return rej
 
 
 @pytest.mark.parametrize("metric", [IP, COS])
 @pytest.mark.parametrize("code_dtype", [I8, U8])
-def test_sq_similarity_bound(svs, oracle, metric, code_dtype):
+def test_sq_parity_d768_and_ragged(svs, oracle, metric, code_dtype):
     x = deep_like(1500, 768, 32, seed=61, normalize=False)
     q = deep_like(24, 768, 32, seed=62, normalize=False)
-    rej = _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS)
-    assert rej > 500
+    _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS)
     x = deep_like(1200, 100, 16, seed=63, normalize=False)  # runtime dimension, ragged tail
     q = deep_like(24, 100, 16, seed=64, normalize=False)
     _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS)
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_sq_similarity_bound_fuzz(svs, oracle, seed):
-    """offsets that make the bias term dominate, tiny and huge scales, queries (nearly) orthogonal to everything, zero query"""
+def test_sq_parity_fuzz(svs, oracle, seed):
+    """offsets that make the bias term dominate, tiny and huge scales, queries (nearly) orthogonal to everything, and a zero
+    query: cosine then is NaN for every row, which exercises the NaN behaviour of SearchBuffer::insert_inner (ids-only
+    duplicate scan, search_buffer.h:377-389)"""
     rng = np.random.default_rng(200 + seed)
     d = int(rng.choice([64, 96, 200, 768]))
     n = int(rng.integers(300, 1200))
