@@ -157,8 +157,15 @@ def main():
     dists = torch.empty((nq, k), dtype=torch.float32, device=device)
     stats = torch.zeros((nq, 6), dtype=torch.int32, device=device)
     if multi:
-        all_d = torch.empty((world, nq, k), dtype=torch.float32, device=device)
-        all_i = torch.empty((world, nq, k), dtype=torch.int64, device=device)
+        # every rank ships ONE packed buffer [nq*k f32 distances | nq*k i64 ids]; the search writes straight into it
+        from scalablevectorsearch_amd.sharded import packed_views
+
+        loc_buf = torch.empty(3 * nq * k, dtype=torch.int32, device=device)
+        dists = loc_buf[:nq * k].view(torch.float32).view(nq, k)
+        ids = loc_buf[nq * k:].view(torch.int64).view(nq, k)
+        all_buf = torch.empty(world * 3 * nq * k, dtype=torch.int32, device=device)
+        all_d, all_i = packed_views(all_buf, world, nq, k)
+        shard_stride_d, shard_stride_i = (all_d.stride(0), all_i.stride(0)) if world > 1 else (0, 0)
         out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=device)
 
@@ -169,10 +176,12 @@ def main():
     def step(with_stats=False):
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists, d_stats=stats if with_stats else None)
         if multi:
-            dist.all_gather_into_tensor(all_d.view(-1), dists.view(-1))
-            dist.all_gather_into_tensor(all_i.view(-1), ids.view(-1))
-            _lib.check(_lib.lib().svsx_merge_topk_device(0, world, nq, k, all_d.data_ptr(), all_i.data_ptr(), out_d.data_ptr(), out_i.data_ptr(),
-                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            gather_and_merge()
+
+    def gather_and_merge():
+        dist.all_gather_into_tensor(all_buf, loc_buf)
+        _lib.check(_lib.lib().svsx_merge_topk_strided_device(0, world, nq, k, all_d.data_ptr(), shard_stride_d, all_i.data_ptr(), shard_stride_i,
+                                                             out_d.data_ptr(), out_i.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     # ---- correctness of what is being timed: recall against exact ground truth ---------------------------------
     step(with_stats=True)
@@ -219,10 +228,7 @@ def main():
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
         ev[i][1].record()
         if multi:
-            dist.all_gather_into_tensor(all_d.view(-1), dists.view(-1))
-            dist.all_gather_into_tensor(all_i.view(-1), ids.view(-1))
-            _lib.check(_lib.lib().svsx_merge_topk_device(0, world, nq, k, all_d.data_ptr(), all_i.data_ptr(), out_d.data_ptr(), out_i.data_ptr(),
-                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            gather_and_merge()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()

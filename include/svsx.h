@@ -157,6 +157,13 @@ int svsx_merge_topk_device(
     uint64_t* d_out_ids, void* hip_stream
 );
 
+/* Same with explicit shard strides (in elements; 0 = dense nq*k): lets every rank ship its (distances | ids) as ONE
+ * packed buffer through ONE all-gather and merge straight out of the gathered buffer. */
+int svsx_merge_topk_strided_device(
+    int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, size_t dist_shard_stride, const uint64_t* d_ids,
+    size_t id_shard_stride, float* d_out_dists, uint64_t* d_out_ids, void* hip_stream
+);
+
 /* Exhaustive search: svs::index::flat::FlatIndex::search (index/flat/flat.h:322-460) -- every query
  * against every vector, k <= 128 best by (distance, then id).  A float16 MFMA pass shortlists max(4k, k+32) candidates
  * per query, which are re-ranked with the exact reference-order distance kernels.  Works on any index, including one

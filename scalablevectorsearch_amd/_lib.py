@@ -61,7 +61,7 @@ EXPORTS = [
     "svsx_index_create", "svsx_index_create_device_view", "svsx_index_destroy", "svsx_search", "svsx_search_device",
     "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
     "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
-    "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes",
+    "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
 ]
 
 _lib = None
@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SearchAux), C.c_void_p]
         L.svsx_distance_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.svsx_merge_topk_device.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svsx_merge_topk_strided_device.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_prune_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         L.svsx_flat_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]

@@ -666,9 +666,9 @@ int svsx_prune_device(
     return SVSX_SUCCESS;
 }
 
-int svsx_merge_topk_device(
-    int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, const uint64_t* d_ids, float* d_out_dists,
-    uint64_t* d_out_ids, void* hip_stream
+int svsx_merge_topk_strided_device(
+    int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, size_t dist_shard_stride, const uint64_t* d_ids,
+    size_t id_shard_stride, float* d_out_dists, uint64_t* d_out_ids, void* hip_stream
 ) {
     if (metric < 0 || metric > 2) return fail(SVSX_INVALID_ARGUMENT, "unknown metric %d", metric);
     if (n_shards == 0 || n_shards > 64) return fail(SVSX_INVALID_ARGUMENT, "n_shards must be in [1, 64]");
@@ -684,9 +684,18 @@ int svsx_merge_topk_device(
     a.n_shards = static_cast<uint32_t>(n_shards);
     a.nq = static_cast<uint32_t>(nq);
     a.k = static_cast<uint32_t>(k);
+    a.dist_shard_stride = dist_shard_stride;
+    a.id_shard_stride = id_shard_stride;
     hipError_t e = launch_merge(metric, a, static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "merge kernel launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
+}
+
+int svsx_merge_topk_device(
+    int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, const uint64_t* d_ids, float* d_out_dists,
+    uint64_t* d_out_ids, void* hip_stream
+) {
+    return svsx_merge_topk_strided_device(metric, n_shards, nq, k, d_dists, 0, d_ids, 0, d_out_dists, d_out_ids, hip_stream);
 }
 
 } // extern "C"

@@ -76,43 +76,57 @@ hipError_t launch_distance(int b_dtype, int metric, int qmode, const DistanceArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One thread per query: S cursors over sorted lists; pick the best head, ties -> lowest shard (strict compare).
-template <bool GREATER> __global__ void merge_kernel(const MergeArgs a) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= a.nq) return;
+// One wave per query, lane s = cursor of shard s (S <= 64): every step is a wave-wide arg-best over the list heads,
+// ties -> lowest shard (then position, the lists being sorted); the winning lane emits its head and advances.
+template <bool GREATER> __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
     if (a.gate64 != nullptr && a.gate64[q >> 6] == 0u) return;
-    constexpr int MAXS = 64;
-    uint16_t cur[MAXS];
-    for (uint32_t s = 0; s < a.n_shards; ++s) cur[s] = 0;
+    const bool shard = lane < a.n_shards;
+    const size_t dense = static_cast<size_t>(a.nq) * a.k;
+    const size_t sl = shard ? lane : 0u;
+    const size_t dbase = sl * (a.dist_shard_stride ? a.dist_shard_stride : dense) + static_cast<size_t>(q) * a.k;
+    const size_t ibase = sl * (a.id_shard_stride ? a.id_shard_stride : dense) + static_cast<size_t>(q) * a.k;
+    uint32_t cur = 0;
+    float hd = 0.0f;
+    uint64_t hid = ~0ull;
+    bool live = false;
+    auto fetch = [&]() {
+        live = shard && cur < a.k;
+        if (live) {
+            hid = a.ids[ibase + cur];
+            if (hid == ~0ull) live = false; // padded tail
+            else hd = a.dists[dbase + cur];
+        }
+    };
+    fetch();
     for (uint32_t j = 0; j < a.k; ++j) {
-        int best = -1;
-        float bd = 0.0f;
-        for (uint32_t s = 0; s < a.n_shards; ++s) {
-            if (cur[s] >= a.k) continue;
-            const size_t o = (static_cast<size_t>(s) * a.nq + q) * a.k + cur[s];
-            if (a.ids[o] == ~0ull) { cur[s] = static_cast<uint16_t>(a.k); continue; } // padded tail
-            const float dd = a.dists[o];
-            if (best < 0 || cmpf<GREATER>(dd, bd)) {
-                best = static_cast<int>(s);
-                bd = dd;
-            }
+        float bd = hd;
+        uint32_t bl = live ? lane : 64u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(bd, off);
+            const uint32_t ol = static_cast<uint32_t>(__shfl_xor(static_cast<int>(bl), off));
+            const bool take = ol != 64u && (bl == 64u || cmpf<GREATER>(od, bd) || (!cmpf<GREATER>(bd, od) && ol < bl));
+            if (take) { bd = od; bl = ol; }
         }
         const size_t oo = static_cast<size_t>(q) * a.k + j;
-        if (best < 0) {
-            a.out_ids[oo] = ~0ull;
-            a.out_dists[oo] = __builtin_inff();
-        } else {
-            const size_t o = (static_cast<size_t>(best) * a.nq + q) * a.k + cur[best];
-            a.out_ids[oo] = a.ids[o];
-            a.out_dists[oo] = bd;
-            cur[best]++;
+        if (bl == 64u) {
+            if (lane == 0) {
+                a.out_ids[oo] = ~0ull;
+                a.out_dists[oo] = __builtin_inff();
+            }
+        } else if (lane == bl) {
+            a.out_ids[oo] = hid;
+            a.out_dists[oo] = hd;
+            ++cur;
+            fetch();
         }
     }
 }
 
 hipError_t launch_merge(int metric, const MergeArgs& a, hipStream_t stream) {
     if (a.n_shards == 0 || a.n_shards > 64 || a.k > 65535) return hipErrorInvalidValue;
-    const dim3 block(128), grid((a.nq + 127) / 128);
+    const dim3 block(64), grid(a.nq);
     if (metric == M_L2) hipLaunchKernelGGL(merge_kernel<false>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(merge_kernel<true>, grid, block, 0, stream, a);
     return hipGetLastError();

@@ -74,6 +74,7 @@ struct MergeArgs {
     float* out_dists;       // [nq][k]
     uint64_t* out_ids;      // [nq][k]
     uint32_t n_shards, nq, k;
+    size_t dist_shard_stride, id_shard_stride; // elements between consecutive shards; 0 = dense (nq * k)
     const uint32_t* gate64;  // optional: one word per 64 queries; a query is merged only if its word is non-zero
 };
 hipError_t launch_merge(int metric, const MergeArgs& a, hipStream_t stream);

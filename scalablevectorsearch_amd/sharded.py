@@ -2,8 +2,8 @@
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank owns an independent Vamana
 sub-index over a contiguous id range (own graph, own entry point); a query batch is searched on every shard and the
-per-shard top-k -- `nq*k*(4+8)` bytes per shard, 1.2 MB at nq=10^4, k=10 -- are exchanged with ONE all-gather and
-merged per query with the metric's comparator (ties: lower shard, then position), so every rank ends with the same
+per-shard top-k -- `nq*k*(4+8)` bytes per shard, 1.2 MB at nq=10^4, k=10, distances and ids packed into one buffer --
+are exchanged with ONE all-gather and merged per query with the metric's comparator (ties: lower shard, then position), so every rank ends with the same
 global top-k.  No other data-path collective exists: graph and vectors never move.
 """
 from __future__ import annotations
@@ -32,11 +32,27 @@ def hip_merge(metric: int, gathered_d, gathered_i, k: int):
     if not gathered_d.is_cuda:
         raise _lib.SvsxError(_lib.RUNTIME_ERROR, "shard merge runs on the GPU only (no CPU fallback)")
     S, nq, kk = gathered_d.shape
+    for t in (gathered_d, gathered_i):  # rows of a shard dense, shards at any stride (views into a packed gather buffer)
+        if t.stride(2) != 1 or t.stride(1) != kk:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "shard lists must be dense [nq, k] blocks")
     out_d = torch.empty((nq, k), dtype=torch.float32, device=gathered_d.device)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=gathered_d.device)
-    _lib.check(_lib.lib().svsx_merge_topk_device(int(metric), S, nq, k, gathered_d.data_ptr(), gathered_i.data_ptr(), out_d.data_ptr(), out_i.data_ptr(),
-                                                 C.c_void_p(torch.cuda.current_stream(gathered_d.device).cuda_stream)))
+    _lib.check(_lib.lib().svsx_merge_topk_strided_device(
+        int(metric), S, nq, k, gathered_d.data_ptr(), gathered_d.stride(0) if S > 1 else 0, gathered_i.data_ptr(),
+        gathered_i.stride(0) if S > 1 else 0, out_d.data_ptr(), out_i.data_ptr(),
+        C.c_void_p(torch.cuda.current_stream(gathered_d.device).cuda_stream)))
     return out_d, out_i
+
+
+def packed_views(buf, world: int, nq: int, k: int):
+    """Views into a packed (distances | ids) buffer of `world` shards: int32 [world, 3*nq*k] -> (f32 [world,nq,k], i64 [world,nq,k])."""
+    import torch
+
+    m = nq * k
+    b = buf.view(world, 3 * m)
+    d = b[:, :m].view(torch.float32).view(world, nq, k)
+    i = b[:, m:].view(torch.int64).view(world, nq, k)
+    return d, i
 
 
 class ShardedSearcher:
@@ -64,8 +80,14 @@ class ShardedSearcher:
         if self.world == 1:
             return self.merge(self.metric, d_local[None], i_local[None], k)
         nq = d_local.shape[0]
-        all_d = torch.empty((self.world, nq, k), dtype=d_local.dtype, device=d_local.device)
-        all_i = torch.empty((self.world, nq, k), dtype=i_local.dtype, device=i_local.device)
-        dist.all_gather_into_tensor(all_d.view(-1), d_local.contiguous().view(-1), group=self.group)
-        dist.all_gather_into_tensor(all_i.view(-1), i_local.contiguous().view(-1), group=self.group)
+        m = nq * k
+        if (m * 4) % 8:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "nq * k must be even (8-byte alignment of the packed ids)")
+        # one packed buffer per shard -> ONE collective: [nq*k f32 distances | nq*k i64 ids] as 3*nq*k int32 words
+        loc = torch.empty(3 * m, dtype=torch.int32, device=d_local.device)
+        loc[:m].view(torch.float32).copy_(d_local.reshape(-1))
+        loc[m:].view(torch.int64).copy_(i_local.reshape(-1))
+        allb = torch.empty(self.world * 3 * m, dtype=torch.int32, device=d_local.device)
+        dist.all_gather_into_tensor(allb, loc, group=self.group)
+        all_d, all_i = packed_views(allb, self.world, nq, k)
         return self.merge(self.metric, all_d, all_i, k)
