@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="exercise the multi-GPU code path (RCCL all-gather + merge) even at world size 1")
     ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
     ap.add_argument("--bound-codes", type=int, default=1, help="1: build the 128-B bound-code rows (result-neutral lower-bound rejection); 0: off")
+    ap.add_argument("--pipeline", action="store_true", help="multi-GPU: overlap the gather + merge of a batch with the next search (PipelinedShardSearch; measured neutral on one GPU)")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph here (lets a profiler run skip the build)")
     args = ap.parse_args()
 
@@ -223,12 +224,30 @@ def main():
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
-        ev[i][1].record()
+    if multi and args.pipeline:
+        # throughput form: batch i's gather + merge (second stream) overlaps batch i+1's search kernel; all K batches
+        # are complete before the closing synchronize + barrier
+        from scalablevectorsearch_amd.sharded import PipelinedShardSearch
+
+        pipe = PipelinedShardSearch(index, 0, nq, k, depth=2, device=device)
+        for _ in range(2):
+            pipe.submit(q, sp)
+        pipe.drain()
         if multi:
-            gather_and_merge()
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            slot = pipe.submit(q, sp, events=ev[i])
+        pipe.drain()
+        assert torch.equal(pipe.out_i[slot], out_i) and torch.equal(pipe.out_d[slot], out_d), "pipelined result differs from the step-by-step one"
+    else:
+        for i in range(args.steps):
+            ev[i][0].record()
+            index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
+            ev[i][1].record()
+            if multi:
+                gather_and_merge()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     }
 
     bool full = buf.size == buf.capacity;
-    float worst = (full && buf.capacity > 0u) ? __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(buf.e[buf.capacity - 1].x)))) : 0.0f;
+    float worst = (full && buf.capacity > 0u) ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
 
     // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
     while (!wave_done(buf)) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                     if (wave_insert<GREATER>(buf, dd, id, lane)) {
                         ++n_ins;
                         full = buf.size == buf.capacity;
-                        if (full) worst = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(buf.e[buf.capacity - 1].x))));
+                        if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
                     }
                 }
             }

@@ -91,3 +91,74 @@ class ShardedSearcher:
         dist.all_gather_into_tensor(allb, loc, group=self.group)
         all_d, all_i = packed_views(allb, self.world, nq, k)
         return self.merge(self.metric, all_d, all_i, k)
+
+
+class PipelinedShardSearch:
+    """Throughput form of the sharded search for a stream of equally shaped query batches: the gather + merge leg of batch i
+    (latency-bound: one small collective, one small kernel) runs on a second stream while the search kernel of batch i+1
+    already occupies the GPU.  `depth` packed buffers rotate; `submit()` enqueues one batch and returns the index of the
+    buffer set its merged result will land in, `drain()` waits for everything.  Same collective sequence on every rank.
+
+    index: VamanaIndex (this rank's shard, ids offset to global); results: `out_d[slot]`, `out_i[slot]` ([nq, k] each)."""
+
+    def __init__(self, index, metric: int, nq: int, k: int, group=None, depth: int = 2, device=None):
+        import torch
+        import torch.distributed as dist
+
+        if (nq * k * 4) % 8:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "nq * k must be even (8-byte alignment of the packed ids)")
+        self.index, self.metric, self.nq, self.k, self.group = index, int(metric), nq, k, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = dist.is_initialized()
+        m = nq * k
+        self.depth = depth
+        self.loc = [torch.empty(3 * m, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.allb = [torch.empty(self.world * 3 * m, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.out_d = [torch.empty((nq, k), dtype=torch.float32, device=device) for _ in range(depth)]
+        self.out_i = [torch.empty((nq, k), dtype=torch.int64, device=device) for _ in range(depth)]
+        self.s_merge = torch.cuda.Stream(device=device)
+        self.ev_search = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_done = [torch.cuda.Event() for _ in range(depth)]
+        self.used = [False] * depth
+        self.n = 0
+
+    def submit(self, d_queries, search_parameters, events=None) -> int:
+        import torch
+
+        slot = self.n % self.depth
+        self.n += 1
+        m = self.nq * self.k
+        cur = torch.cuda.current_stream(d_queries.device)
+        if self.used[slot]:
+            cur.wait_event(self.ev_done[slot])  # the merge that last read this buffer set has finished
+        loc = self.loc[slot]
+        if events is not None:
+            events[0].record(cur)
+        self.index.search_device(d_queries, self.k, search_parameters, d_ids64=loc[m:].view(torch.int64).view(self.nq, self.k),
+                                 d_dists=loc[:m].view(torch.float32).view(self.nq, self.k))
+        if events is not None:
+            events[1].record(cur)
+        self.ev_search[slot].record(cur)
+        with torch.cuda.stream(self.s_merge):
+            self.s_merge.wait_event(self.ev_search[slot])
+            if self.collective:
+                import torch.distributed as dist
+
+                dist.all_gather_into_tensor(self.allb[slot], loc, group=self.group)
+                src = self.allb[slot]
+            else:
+                src = loc
+            all_d, all_i = packed_views(src, self.world, self.nq, self.k)
+            _lib.check(_lib.lib().svsx_merge_topk_strided_device(
+                self.metric, self.world, self.nq, self.k, all_d.data_ptr(), all_d.stride(0) if self.world > 1 else 0, all_i.data_ptr(),
+                all_i.stride(0) if self.world > 1 else 0, self.out_d[slot].data_ptr(), self.out_i[slot].data_ptr(),
+                C.c_void_p(self.s_merge.cuda_stream)))
+            self.ev_done[slot].record(self.s_merge)
+        self.used[slot] = True
+        return slot
+
+    def drain(self) -> None:
+        import torch
+
+        torch.cuda.current_stream().synchronize()
+        self.s_merge.synchronize()
