@@ -118,3 +118,31 @@ def test_filter_vs_reference_headers(oracle, ref):
         assert bool(oracle.lib.svso_filter_contains(f, key)) == bool(ref.lib.svsref_filter_contains(C.c_void_p(rf), key))
         assert bool(oracle.lib.svso_filter_emplace(f, key)) == bool(ref.lib.svsref_filter_emplace(C.c_void_p(rf), key))
     ref.lib.svsref_filter_free(C.c_void_p(rf))
+
+
+def test_live_buffer_nan_distances_vs_reference_headers(oracle, ref):
+    """NaN distances (cosine of a zero query): every comparison is false, lower_bound lands at the end and the duplicate scan
+    of insert_inner (search_buffer.h:377-389) degenerates to an ids-only scan.  Mixed NaN / ordinary inserts, op by op."""
+    rng = np.random.default_rng(0)
+
+    def same(u, v):
+        return u == v or (u != u and v != v)
+
+    for trial in range(40):
+        greater = bool(trial & 1)
+        w = int(rng.integers(2, 40))
+        c = w + int(rng.integers(0, 20))
+        a, b = oracle.buffer(w, c, greater), ref.buffer(w, c, greater)
+        for step in range(250):
+            if not a.done() and rng.random() < 0.25:
+                assert a.done() == b.done()
+                x, y = a.next(), b.next()
+                assert x[0] == y[0] and same(x[1], y[1])
+            else:
+                i = int(rng.integers(0, 60))
+                dd = float("nan") if rng.random() < 0.5 else float(i % 7)
+                assert a.insert(i, dd) == b.insert(i, dd), (trial, step)
+            sa, sb = a.state(), b.state()
+            assert len(sa) == len(sb)
+            for u, v in zip(sa, sb):
+                assert u[0] == v[0] and u[2] == v[2] and same(u[1], v[1]), (trial, step, u, v)
