@@ -276,12 +276,12 @@ int svsx_index_build_bound_codes(svsx_index* ix, int enable) {
         return SVSX_SUCCESS;
     }
     if (ix->d_codes) return SVSX_SUCCESS;
-    if (ix->metric != M_L2 || ix->data_dtype != DT_F32 || ix->sq_enabled || (ix->d != 96 && ix->d != 128))
-        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 L2 indexes of dimension 96 or 128");
+    if (ix->metric != M_L2 || (ix->data_dtype != DT_F32 && ix->data_dtype != DT_F16) || ix->sq_enabled || (ix->d != 96 && ix->d != 128))
+        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 / float16 L2 indexes of dimension 96 or 128");
     const uint32_t dc = static_cast<uint32_t>(ix->d < 120 ? ix->d : 120);
     DeviceBuffer mm;
     HIP_TRY(mm.alloc(12));
-    HIP_TRY(launch_codes_minmax(ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, static_cast<uint32_t*>(mm.p), nullptr));
+    HIP_TRY(launch_codes_minmax(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, static_cast<uint32_t*>(mm.p), nullptr));
     uint32_t h[3];
     HIP_TRY(hipMemcpy(h, mm.p, sizeof(h), hipMemcpyDeviceToHost));
     if (h[2] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
@@ -290,7 +290,7 @@ int svsx_index_build_bound_codes(svsx_index* ix, int enable) {
     if (!(scale > 0.0f) || !(scale < 3.0e38f)) scale = 1.0f;
     void* codes = nullptr;
     HIP_TRY(hipMalloc(&codes, ix->n * 128 + 128));
-    hipError_t e = launch_codes_build(ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, scale, lo, codes, nullptr);
+    hipError_t e = launch_codes_build(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, scale, lo, codes, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipFree(codes);

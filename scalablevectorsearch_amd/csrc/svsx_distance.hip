@@ -160,12 +160,13 @@ __device__ __forceinline__ uint32_t order_key(float f) { // monotone float -> u3
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ void codes_minmax_kernel(const float* __restrict__ data, size_t row_floats, uint32_t n, uint32_t dc, uint32_t* __restrict__ mm) {
+template <typename T>
+__global__ void codes_minmax_kernel(const T* __restrict__ data, size_t row_floats, uint32_t n, uint32_t dc, uint32_t* __restrict__ mm) {
     float lo = __builtin_inff(), hi = -__builtin_inff();
     bool bad = false;
     for (size_t r = blockIdx.x; r < n; r += gridDim.x) {
         for (uint32_t j = threadIdx.x; j < dc; j += blockDim.x) {
-            const float v = data[r * row_floats + j];
+            const float v = static_cast<float>(data[r * row_floats + j]); // float16 rows widen exactly, like the reference's loads
             bad = bad || !(__builtin_fabsf(v) <= 3.0e38f);
             lo = v < lo ? v : lo;
             hi = v > hi ? v : hi;
@@ -183,11 +184,12 @@ __global__ void codes_minmax_kernel(const float* __restrict__ data, size_t row_f
     }
 }
 
-__global__ void codes_build_kernel(const float* __restrict__ data, size_t row_floats, uint32_t n, uint32_t dc, float scale, float bias,
+template <typename T>
+__global__ void codes_build_kernel(const T* __restrict__ data, size_t row_floats, uint32_t n, uint32_t dc, float scale, float bias,
                                    unsigned char* __restrict__ codes) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const float* x = data + static_cast<size_t>(r) * row_floats;
+    const T* x = data + static_cast<size_t>(r) * row_floats;
     uint32_t* out = reinterpret_cast<uint32_t*>(codes + static_cast<size_t>(r) * 128);
     const float inv = 1.0f / scale;
     double err2 = 0.0;
@@ -197,7 +199,7 @@ __global__ void codes_build_kernel(const float* __restrict__ data, size_t row_fl
         for (uint32_t t = 0; t < 4; ++t) {
             const uint32_t j = w * 4 + t;
             if (j < dc) {
-                const float v = x[j];
+                const float v = static_cast<float>(x[j]);
                 float c = __builtin_rintf((v - bias) * inv);
                 c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
                 const int ci = static_cast<int>(c);
@@ -215,12 +217,14 @@ __global__ void codes_build_kernel(const float* __restrict__ data, size_t row_fl
     out[31] = static_cast<uint32_t>(xx);
 }
 
-hipError_t launch_codes_minmax(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, uint32_t* d_mm3, hipStream_t stream) {
+hipError_t launch_codes_minmax(int dtype, const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, uint32_t* d_mm3, hipStream_t stream) {
     const uint32_t init[3] = {0xFFFFFFFFu, 0u, 0u};
     hipError_t e = hipMemcpyAsync(d_mm3, init, sizeof(init), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
     const uint32_t blocks = n < 4096u ? n : 4096u;
-    hipLaunchKernelGGL(codes_minmax_kernel, dim3(blocks), dim3(64), 0, stream, static_cast<const float*>(d_data), row_bytes / 4, n, dc, d_mm3);
+    if (dtype == DT_F32) hipLaunchKernelGGL(codes_minmax_kernel<float>, dim3(blocks), dim3(64), 0, stream, static_cast<const float*>(d_data), row_bytes / 4, n, dc, d_mm3);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(codes_minmax_kernel<_Float16>, dim3(blocks), dim3(64), 0, stream, static_cast<const _Float16*>(d_data), row_bytes / 2, n, dc, d_mm3);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -231,9 +235,14 @@ float codes_key_to_float(uint32_t k) {
     return f;
 }
 
-hipError_t launch_codes_build(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, float scale, float bias, void* d_codes, hipStream_t stream) {
-    hipLaunchKernelGGL(codes_build_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, static_cast<const float*>(d_data), row_bytes / 4, n, dc, scale, bias,
-                       static_cast<unsigned char*>(d_codes));
+hipError_t launch_codes_build(int dtype, const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, float scale, float bias, void* d_codes, hipStream_t stream) {
+    if (dtype == DT_F32)
+        hipLaunchKernelGGL(codes_build_kernel<float>, dim3((n + 127) / 128), dim3(128), 0, stream, static_cast<const float*>(d_data), row_bytes / 4, n, dc, scale,
+                           bias, static_cast<unsigned char*>(d_codes));
+    else if (dtype == DT_F16)
+        hipLaunchKernelGGL(codes_build_kernel<_Float16>, dim3((n + 127) / 128), dim3(128), 0, stream, static_cast<const _Float16*>(d_data), row_bytes / 2, n, dc,
+                           scale, bias, static_cast<unsigned char*>(d_codes));
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

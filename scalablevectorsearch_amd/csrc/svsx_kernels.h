@@ -155,9 +155,9 @@ hipError_t launch_rerank2(int data_dtype, int metric, int qmode, const RerankArg
 
 // layout conversion kernels (index creation)
 // bound codes (svsx_index_build_bound_codes): d_mm3 = {min key, max key, non-finite count}
-hipError_t launch_codes_minmax(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, uint32_t* d_mm3, hipStream_t stream);
+hipError_t launch_codes_minmax(int dtype, const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, uint32_t* d_mm3, hipStream_t stream);
 float codes_key_to_float(uint32_t key);
-hipError_t launch_codes_build(const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, float scale, float bias, void* d_codes, hipStream_t stream);
+hipError_t launch_codes_build(int dtype, const void* d_data, size_t row_bytes, uint32_t n, uint32_t dc, float scale, float bias, void* d_codes, hipStream_t stream);
 hipError_t launch_pack_graph(const uint32_t* d_svs_graph, uint32_t svs_stride, uint32_t n, uint32_t* d_out, uint32_t out_stride, uint32_t* d_bad2,
                              hipStream_t stream);
 

@@ -473,7 +473,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODE
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
     if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
-    if constexpr (QMODE == QM_FLOAT && DT == DT_F32 && METRIC == M_L2) {
+    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && METRIC == M_L2) {
         if (a.codes != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, true>(a, stream);
         if (a.codes != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, true>(a, stream);
     }

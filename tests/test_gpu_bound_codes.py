@@ -53,6 +53,25 @@ def test_bound_codes_small_world(svs, oracle, small_world):
     assert rej > 1000  # the bound really removes row fetches
 
 
+@pytest.mark.parametrize("qdt", [np.float32, np.float16])
+def test_bound_codes_float16_rows(svs, oracle, small_world, qdt):
+    """float16 data (192- / 256-byte rows): same codes, same bound, exact path = the block-cyclic f16 kernel"""
+    sw = small_world
+    rej = _check(svs, oracle, sw["x"].astype(np.float16), sw["graph"], sw["entry"], sw["q"].astype(qdt), CONFIGS)
+    assert rej > 1000
+    x = deep_like(2000, 128, 24, seed=21).astype(np.float16)
+    q = deep_like(32, 128, 24, seed=22).astype(qdt)
+    g, e = oracle.build_vamana(L2, x, R=24, L=40)
+    _check(svs, oracle, x, g, e, q, CONFIGS)
+    rng = np.random.default_rng(9)  # un-normalised, offset, with outliers
+    x = (deep_like(900, 96, 10, seed=23, normalize=False) * np.float32(3.0) + np.float32(7.0))
+    x[rng.integers(0, 900, 4)] *= np.float32(20.0)
+    x = x.astype(np.float16)
+    q = (x[rng.integers(0, 900, 16)].astype(np.float32) + rng.standard_normal((16, 96)).astype(np.float32)).astype(qdt)
+    g, e = oracle.build_vamana(L2, x, R=16, L=32)
+    _check(svs, oracle, x, g, e, q, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], expect_rejects=False)
+
+
 def test_bound_codes_d128(svs, oracle):
     x = deep_like(2000, 128, 24, seed=21)
     q = deep_like(32, 128, 24, seed=22)
@@ -94,7 +113,7 @@ def test_bound_codes_equidistant_candidates(svs, oracle):
 
 def test_bound_codes_scope(svs, oracle, small_world):
     sw = small_world
-    idx = svs.VamanaIndex(sw["graph"], sw["x"].astype(np.float16), svs.DistanceL2(), sw["entry"])
+    idx = svs.VamanaIndex(sw["graph"], sw["x"].astype(np.float16), svs.DistanceCosineSimilarity(), sw["entry"])
     with pytest.raises(svs.SvsxError) as e:
         idx.build_bound_codes()
     assert e.value.code == 3  # NOT_IMPLEMENTED
