@@ -222,7 +222,7 @@ int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
  * 8-bit codes of its first min(d, 120) components and the exact coding error.  The search kernel turns them into a
  * rigorous LOWER BOUND of the L2 distance and drops candidates that can_skip (search_buffer.h:338-340) would drop anyway
  * before their full row is fetched -- ids and distances returned are unchanged, HBM traffic per candidate falls from 3
- * lines to about 1.  float32 data, L2, d = 96 or 128 (SVSX_NOT_IMPLEMENTED otherwise); +128 B of HBM per vector.
+ * lines to about 1.  float32 or float16 data, L2, d = 96 or 128 (SVSX_NOT_IMPLEMENTED otherwise); +128 B of HBM per vector.
  * enable = 0 frees them.  Call while no search is in flight on this index. */
 int svsx_index_build_bound_codes(svsx_index* index, int enable);
 
