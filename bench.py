@@ -151,7 +151,7 @@ def main():
     d_entry = torch.tensor([entry], dtype=torch.int32, device=device)
     index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n, d, np.float32, device=local_rank, id_offset=rank * n)
     if args.bound_codes:
-        index.build_bound_codes()
+        index.build_bound_codes(args.bound_codes)
     sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window), search_buffer_visited_set=args.visited)
 
     ids = torch.empty((nq, k), dtype=torch.int64, device=device)  # written as uint64

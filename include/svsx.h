@@ -111,6 +111,13 @@ typedef struct {
     uint32_t* history_len;
     size_t history_cap;
     size_t query_row_stride_bytes;  /* 0 = dense */
+    /* The `cancel` predicate of VamanaIndex::search (index/vamana/index.h:541-545,564-570), polled once per graph hop like
+     * greedy_search.h:155 and once per query like extensions.h:575-578.  A word the caller may set to non-zero from any
+     * thread while the call is in flight: svsx_search takes a HOST pointer (the library mirrors it into a device word the
+     * kernel polls); svsx_search_device takes a DEVICE pointer (set it with an agent-scope store from another stream).
+     * After cancellation the call still returns SVSX_SUCCESS; rows of queries that had not started stay untouched,
+     * rows of queries in flight hold whatever their buffer contained (the reference leaves both unspecified). */
+    const volatile int* cancel_flag;
 } svsx_search_aux;
 
 /* auto_assemble / VamanaIndex ctor (index/vamana/index.h:363-377,1017-1046);
@@ -218,13 +225,18 @@ int svsx_iterator_next_device(
  * [6] flags: 1 = next search restarts from the entry points, 2 = exhausted; done() (:230) = [4] == n || flags & 2. */
 int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
 
-/* Bound codes (no reference counterpart; result-neutral): builds, next to the vectors, one 128-byte row per vector with
- * 8-bit codes of its first min(d, 120) components and the exact coding error.  The search kernel turns them into a
- * rigorous LOWER BOUND of the L2 distance and drops candidates that can_skip (search_buffer.h:338-340) would drop anyway
- * before their full row is fetched -- ids and distances returned are unchanged, HBM traffic per candidate falls from 3
- * lines to about 1.  float32 or float16 data, L2, d = 96 or 128 (SVSX_NOT_IMPLEMENTED otherwise); +128 B of HBM per vector.
- * enable = 0 frees them.  Call while no search is in flight on this index. */
-int svsx_index_build_bound_codes(svsx_index* index, int enable);
+/* Bound codes (no reference counterpart; result-neutral).  The search kernel turns them into a rigorous LOWER BOUND of
+ * the L2 distance and drops candidates that can_skip (search_buffer.h:338-340) would drop anyway before their full row
+ * is fetched -- ids and distances returned are unchanged, only the number of 128-byte lines requested per hop falls.
+ *   mode 1  one 128-byte row per vector: 8-bit codes of its first min(d, 120) components + exact coding error
+ *           (d = 96 or 128; +128 B of HBM per vector; one extra line per candidate)
+ *   mode 2  graph-inline records: every adjacency row carries a 32-byte record per neighbour (28 8-bit codes of the
+ *           leading components in a PCA basis of the data, coding error, norm of the uncoded tail), so one hop reads ONE
+ *           contiguous block of (4 + 32) * max_degree bytes and bounds all its neighbours at once
+ *           (32 <= d <= 128; +32 B x max_degree per vector)
+ *   mode 0  frees either.
+ * float32 or float16 data, L2 (SVSX_NOT_IMPLEMENTED otherwise).  Call while no search is in flight on this index. */
+int svsx_index_build_bound_codes(svsx_index* index, int mode);
 
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),
  * [5]=data row stride (bytes). */
@@ -235,6 +247,11 @@ const char* svsx_last_error(void);
 
 /* Library version string. */
 const char* svsx_version(void);
+
+/* Diagnostics: name of the search-kernel instantiation the last svsx_search* / svsx_iterator_next* call on this thread
+ * launched (K7 dispatch, SURVEY 8a: which static-dimension variant served the call), e.g.
+ * "search_kernel<dt=1,metric=1,qmode=0,ds=128,general=0,codes=0>".  Empty before the first search. */
+const char* svsx_last_kernel_info(void);
 
 #ifdef __cplusplus
 }

@@ -53,7 +53,7 @@ class SearchParams(C.Structure):
 class SearchAux(C.Structure):
     _fields_ = [
         ("stats", C.c_void_p), ("history_ids", C.c_void_p), ("history_dists", C.c_void_p), ("history_len", C.c_void_p),
-        ("history_cap", C.c_size_t), ("query_row_stride_bytes", C.c_size_t),
+        ("history_cap", C.c_size_t), ("query_row_stride_bytes", C.c_size_t), ("cancel_flag", C.c_void_p),
     ]
 
 
@@ -62,6 +62,7 @@ EXPORTS = [
     "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
     "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
     "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
+    "svsx_last_kernel_info",
 ]
 
 _lib = None
@@ -96,6 +97,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         L.svsx_last_error.restype = C.c_char_p
         L.svsx_version.restype = C.c_char_p
+        L.svsx_last_kernel_info.restype = C.c_char_p
         L.svsx_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_create_device_view.argtypes = [C.POINTER(DeviceIndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_destroy.argtypes = [C.c_void_p]

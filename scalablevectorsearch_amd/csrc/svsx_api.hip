@@ -8,6 +8,8 @@
 #include "svsx_device.h"
 #include "svsx_kernels.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +43,11 @@ struct svsx_index {
     // bound codes (svsx_index_build_bound_codes): 128 B per vector
     void* d_codes = nullptr;
     float code_scale = 1.0f, code_bias = 0.0f;
+    // graph-inline records (svsx_index_build_bound_codes mode 2; svsx_codes.hip)
+    void* d_fat = nullptr;
+    size_t fat_stride = 0;
+    float* d_pca = nullptr;      // [d][128] transposed rotation | [128] mean | [32] bias
+    float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_eps = 0.0f, pca_eq_abs = 0.0f;
 };
 
 namespace {
@@ -126,7 +133,8 @@ int validate_common(int metric, int dtype, size_t n, size_t d) {
 extern "C" {
 
 const char* svsx_last_error(void) { return g_error.c_str(); }
-const char* svsx_version(void) { return "svsx 0.1.0 (gfx950)"; }
+const char* svsx_version(void) { return "svsx 0.2.0 (gfx950)"; }
+const char* svsx_last_kernel_info(void) { return last_search_instantiation(); }
 
 int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
     if (!desc || !out) return fail(SVSX_INVALID_ARGUMENT, "null argument");
@@ -251,6 +259,8 @@ void svsx_index_destroy(svsx_index* ix) {
     if (ix->d_half) (void)hipFree(ix->d_half);
     if (ix->d_norm2) (void)hipFree(ix->d_norm2);
     if (ix->d_codes) (void)hipFree(ix->d_codes);
+    if (ix->d_fat) (void)hipFree(ix->d_fat);
+    if (ix->d_pca) (void)hipFree(ix->d_pca);
     delete ix;
 }
 
@@ -265,19 +275,211 @@ int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
     return SVSX_SUCCESS;
 }
 
-int svsx_index_build_bound_codes(svsx_index* ix, int enable) {
+} // extern "C"
+
+namespace {
+
+// cyclic Jacobi eigen-decomposition of a symmetric d x d matrix (row-major, f64): A -> diagonal, V columns = eigenvectors
+void jacobi_eigh(std::vector<double>& A, int d, std::vector<double>& V) {
+    V.assign(static_cast<size_t>(d) * d, 0.0);
+    for (int i = 0; i < d; ++i) V[static_cast<size_t>(i) * d + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) (i == j ? diag : off) += A[static_cast<size_t>(i) * d + j] * A[static_cast<size_t>(i) * d + j];
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < d - 1; ++p) {
+            for (int q = p + 1; q < d; ++q) {
+                const double apq = A[static_cast<size_t>(p) * d + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[static_cast<size_t>(q) * d + q] - A[static_cast<size_t>(p) * d + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < d; ++k) { // columns p, q
+                    const double akp = A[static_cast<size_t>(k) * d + p], akq = A[static_cast<size_t>(k) * d + q];
+                    A[static_cast<size_t>(k) * d + p] = c * akp - sn * akq;
+                    A[static_cast<size_t>(k) * d + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < d; ++k) { // rows p, q
+                    const double apk = A[static_cast<size_t>(p) * d + k], aqk = A[static_cast<size_t>(q) * d + k];
+                    A[static_cast<size_t>(p) * d + k] = c * apk - sn * aqk;
+                    A[static_cast<size_t>(q) * d + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < d; ++k) {
+                    const double vkp = V[static_cast<size_t>(k) * d + p], vkq = V[static_cast<size_t>(k) * d + q];
+                    V[static_cast<size_t>(k) * d + p] = c * vkp - sn * vkq;
+                    V[static_cast<size_t>(k) * d + q] = sn * vkp + c * vkq;
+                }
+            }
+        }
+    }
+}
+
+float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (h & 0x8000u) << 16, ex = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
+    uint32_t u;
+    if (ex == 0) {
+        if (man == 0) u = sign;
+        else {
+            int e = -1;
+            uint32_t m = man;
+            do { ++e; m <<= 1; } while (!(m & 0x400u));
+            u = sign | ((127 - 15 - e) << 23) | ((m & 0x3FFu) << 13);
+        }
+    } else if (ex == 31) u = sign | 0x7F800000u | (man << 13);
+    else u = sign | ((ex + 112) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+constexpr uint32_t kFatDc = 28;     // coded components per record
+constexpr uint32_t kPcaPd = 128;    // padded component count of the rotation rows
+
+// graph-inline records: sample -> PCA rotation (host, f64) -> per-vector records (device) -> node rows (device)
+int build_fat_rows(svsx_index* ix) {
+    const uint32_t d = static_cast<uint32_t>(ix->d), n = static_cast<uint32_t>(ix->n);
+    const size_t es = dtype_size(ix->data_dtype);
+    // 1. sample (evenly strided, <= 65536 rows) -> host, f64
+    const size_t ns = n < 65536u ? n : 65536u;
+    const size_t step = n / ns;
+    std::vector<unsigned char> raw(ns * d * es);
+    HIP_TRY(hipMemcpy2D(raw.data(), d * es, ix->d_data, step * ix->row_bytes, d * es, ns, hipMemcpyDeviceToHost));
+    std::vector<double> xs(ns * d);
+    for (size_t i = 0; i < ns * d; ++i) {
+        if (ix->data_dtype == DT_F32) xs[i] = reinterpret_cast<const float*>(raw.data())[i];
+        else xs[i] = half_bits_to_float(reinterpret_cast<const uint16_t*>(raw.data())[i]);
+        if (!(xs[i] - xs[i] == 0.0)) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
+    }
+    std::vector<double> mean(d, 0.0);
+    for (size_t r = 0; r < ns; ++r)
+        for (uint32_t j = 0; j < d; ++j) mean[j] += xs[r * d + j];
+    for (uint32_t j = 0; j < d; ++j) mean[j] /= static_cast<double>(ns);
+    std::vector<float> mean_f(kPcaPd, 0.0f);
+    for (uint32_t j = 0; j < d; ++j) mean_f[j] = static_cast<float>(mean[j]);
+    std::vector<double> cov(static_cast<size_t>(d) * d, 0.0), row(d);
+    for (size_t r = 0; r < ns; ++r) {
+        for (uint32_t j = 0; j < d; ++j) row[j] = xs[r * d + j] - static_cast<double>(mean_f[j]);
+        for (uint32_t i = 0; i < d; ++i) {
+            const double ri = row[i];
+            double* c = &cov[static_cast<size_t>(i) * d];
+            for (uint32_t j = i; j < d; ++j) c[j] += ri * row[j];
+        }
+    }
+    for (uint32_t i = 0; i < d; ++i)
+        for (uint32_t j = i; j < d; ++j) {
+            const double v = cov[static_cast<size_t>(i) * d + j] / static_cast<double>(ns);
+            cov[static_cast<size_t>(i) * d + j] = v;
+            cov[static_cast<size_t>(j) * d + i] = v;
+        }
+    // 2. eigenvectors by descending eigenvalue -> P (rows), rounded to float32; eps from the ROUNDED matrix
+    std::vector<double> V;
+    jacobi_eigh(cov, static_cast<int>(d), V);
+    std::vector<uint32_t> order(d);
+    for (uint32_t i = 0; i < d; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cov[static_cast<size_t>(x) * d + x] > cov[static_cast<size_t>(y) * d + y]; });
+    std::vector<float> host(static_cast<size_t>(d) * kPcaPd + kPcaPd + 32, 0.0f); // pt | mean | bias
+    std::vector<double> P(static_cast<size_t>(d) * d);
+    for (uint32_t i = 0; i < d; ++i)
+        for (uint32_t j = 0; j < d; ++j) {
+            const float f = static_cast<float>(V[static_cast<size_t>(j) * d + order[i]]);
+            host[static_cast<size_t>(j) * kPcaPd + i] = f;
+            P[static_cast<size_t>(i) * d + j] = f;
+        }
+    double fro = 0.0;
+    for (uint32_t i = 0; i < d; ++i)
+        for (uint32_t k = 0; k < d; ++k) {
+            double g = 0.0;
+            for (uint32_t j = 0; j < d; ++j) g += P[static_cast<size_t>(i) * d + j] * P[static_cast<size_t>(k) * d + j];
+            g -= (i == k) ? 1.0 : 0.0;
+            fro += g * g;
+        }
+    const double eps = std::sqrt(fro) * 1.01 + 1e-7;
+    if (!(eps < 1e-3)) return fail(SVSX_RUNTIME_ERROR, "PCA rotation is not orthonormal enough (eps = %g)", eps);
+    for (uint32_t j = 0; j < d; ++j) host[static_cast<size_t>(d) * kPcaPd + j] = mean_f[j];
+    if (!ix->d_pca) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pca), host.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(ix->d_pca, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    // 3. per-component range of y over ALL vectors (device), clipped to +-8 sigma; step, biases, tail unit
+    DeviceBuffer st;
+    HIP_TRY(st.alloc((2 * kPcaPd + 2) * 4));
+    std::vector<uint32_t> init(2 * kPcaPd + 2, 0u);
+    for (uint32_t i = 0; i < kPcaPd; ++i) init[i] = 0xFFFFFFFFu;
+    HIP_TRY(hipMemcpy(st.p, init.data(), init.size() * 4, hipMemcpyHostToDevice));
+    PcaArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.pd = kPcaPd; pa.dc = kFatDc;
+    pa.pt = ix->d_pca; pa.mean = ix->d_pca + static_cast<size_t>(d) * kPcaPd; pa.bias = pa.mean + kPcaPd;
+    pa.stat_min = static_cast<uint32_t*>(st.p); pa.stat_max = pa.stat_min + kPcaPd; pa.stat_tail = pa.stat_max + kPcaPd; pa.stat_bad = pa.stat_tail + 1;
+    HIP_TRY(launch_pca_stats(pa, nullptr));
+    std::vector<uint32_t> stats(2 * kPcaPd + 2);
+    HIP_TRY(hipMemcpy(stats.data(), st.p, stats.size() * 4, hipMemcpyDeviceToHost));
+    if (stats[2 * kPcaPd + 1] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
+    double range = 0.0, bmax = 0.0;
+    std::vector<float> bias(32, 0.0f);
+    for (uint32_t i = 0; i < kFatDc; ++i) {
+        double lo = pca_key_to_float(stats[i]), hi = pca_key_to_float(stats[kPcaPd + i]);
+        const double sig = std::sqrt(std::max(cov[static_cast<size_t>(order[i]) * d + order[i]], 0.0));
+        if (sig > 0.0) { // outliers beyond 8 sigma clamp (their coding error is in their own ex)
+            lo = std::max(lo, -8.0 * sig);
+            hi = std::min(hi, 8.0 * sig);
+        }
+        if (!(hi > lo)) hi = lo;
+        bias[i] = static_cast<float>(lo);
+        range = std::max(range, hi - lo);
+        bmax = std::max(bmax, std::fabs(static_cast<double>(bias[i])));
+    }
+    float stepf = static_cast<float>(range / 255.0);
+    if (!(stepf > 0.0f) || !(stepf < 3.0e38f)) stepf = 1.0f;
+    float tail_max = pca_key_to_float(stats[2 * kPcaPd]);
+    if (!(tail_max > 0.0f)) tail_max = 1.0f;
+    const float tail_unit = tail_max / 60000.0f;
+    HIP_TRY(hipMemcpy(ix->d_pca + static_cast<size_t>(d) * kPcaPd + kPcaPd, bias.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
+    // 4. records, then node rows
+    DeviceBuffer rec;
+    HIP_TRY(rec.alloc(static_cast<size_t>(n) * 32 + 32));
+    pa.step = stepf; pa.tail_unit = tail_unit; pa.records = static_cast<uint32_t*>(rec.p);
+    HIP_TRY(launch_pca_encode(pa, nullptr));
+    const size_t fat_stride = (ix->gstride * 36 + 127) & ~size_t(127);
+    void* fat = nullptr;
+    if (hipMalloc(&fat, static_cast<size_t>(n) * fat_stride + 128) != hipSuccess)
+        return fail(SVSX_RUNTIME_ERROR, "hipMalloc(%zu) for the graph-inline records failed", static_cast<size_t>(n) * fat_stride);
+    hipError_t e = launch_fat_build(ix->d_graph, static_cast<uint32_t>(ix->gstride), n, rec.p, fat, fat_stride, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(fat);
+        return fail(SVSX_RUNTIME_ERROR, "graph-inline record kernels failed: %s", hipGetErrorString(e));
+    }
+    ix->d_fat = fat;
+    ix->fat_stride = fat_stride;
+    ix->pca_step = stepf;
+    ix->pca_tail_unit = tail_unit;
+    ix->pca_eps = static_cast<float>(eps);
+    // rounding of fl(b + s c) in the query's residual: <= 2^-23 (|b| + 255 s) per component, 28 components
+    ix->pca_eq_abs = static_cast<float>(5.2915 * 1.2e-7 * (bmax + 255.0 * stepf) * 1.01);
+    return SVSX_SUCCESS;
+}
+
+} // namespace
+
+extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
     if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows) or 2 (graph-inline records)");
     HIP_TRY(hipSetDevice(ix->device));
     std::lock_guard<std::mutex> lock(ix->shadow_mutex);
-    if (!enable) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (ix->d_codes) (void)hipFree(ix->d_codes);
-        ix->d_codes = nullptr;
-        return SVSX_SUCCESS;
+    HIP_TRY(hipDeviceSynchronize());
+    // one scheme at a time: drop what the new mode does not use
+    if (mode != 1 && ix->d_codes) { (void)hipFree(ix->d_codes); ix->d_codes = nullptr; }
+    if (mode != 2 && ix->d_fat) { (void)hipFree(ix->d_fat); ix->d_fat = nullptr; }
+    if (mode == 0) return SVSX_SUCCESS;
+    if (ix->metric != M_L2 || (ix->data_dtype != DT_F32 && ix->data_dtype != DT_F16) || ix->sq_enabled)
+        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 / float16 L2 indexes");
+    if (mode == 2) {
+        if (ix->d_fat) return SVSX_SUCCESS;
+        if (ix->d < 32 || ix->d > 128 || !ix->d_graph) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover graph indexes of dimension 32..128");
+        return build_fat_rows(ix);
     }
     if (ix->d_codes) return SVSX_SUCCESS;
-    if (ix->metric != M_L2 || (ix->data_dtype != DT_F32 && ix->data_dtype != DT_F16) || ix->sq_enabled || (ix->d != 96 && ix->d != 128))
-        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 / float16 L2 indexes of dimension 96 or 128");
+    if (ix->d != 96 && ix->d != 128) return fail(SVSX_NOT_IMPLEMENTED, "128-byte bound-code rows cover dimension 96 or 128");
     const uint32_t dc = static_cast<uint32_t>(ix->d < 120 ? ix->d : 120);
     DeviceBuffer mm;
     HIP_TRY(mm.alloc(12));
@@ -302,6 +504,8 @@ int svsx_index_build_bound_codes(svsx_index* ix, int enable) {
     return SVSX_SUCCESS;
 }
 
+extern "C" {
+
 static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, int q_dtype, size_t q_row_bytes, size_t nq) {
     SearchArgs a;
     memset(&a, 0, sizeof(a));
@@ -325,6 +529,18 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
         a.codes = static_cast<const unsigned char*>(ix->d_codes);
         a.code_scale = ix->code_scale;
         a.code_bias = ix->code_bias;
+    }
+    if (ix->d_fat && !a.general) { // graph-inline records: same guarantee, one contiguous block per expansion
+        a.fat = static_cast<const unsigned char*>(ix->d_fat);
+        a.fat_stride = ix->fat_stride;
+        a.pca_t = ix->d_pca;
+        a.pca_mean = ix->d_pca + ix->d * kPcaPd;
+        a.pca_bias = a.pca_mean + kPcaPd;
+        a.pca_pd = kPcaPd;
+        a.pca_step = ix->pca_step;
+        a.pca_tail_unit = ix->pca_tail_unit;
+        a.pca_eps = ix->pca_eps;
+        a.pca_eq_abs = ix->pca_eq_abs;
     }
     return a;
 }
@@ -351,6 +567,8 @@ static int search_common(
         capacity = k;
     }
     if (capacity == 0) return fail(SVSX_INVALID_ARGUMENT, "search window size must be positive");
+    if (d_ids32 != nullptr && ix->id_offset + ix->n > (uint64_t(1) << 32))
+        return fail(SVSX_INVALID_ARGUMENT, "32-bit ids cannot hold id_offset + n = %llu: ask for 64-bit ids", static_cast<unsigned long long>(ix->id_offset + ix->n));
     if (capacity > 16000) return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu exceeds the LDS budget of one wave", capacity);
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0)

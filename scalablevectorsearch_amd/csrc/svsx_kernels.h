@@ -40,6 +40,19 @@ struct SearchArgs {
     // optional 128-B bound-code rows (f32 L2, d = 96 or 128): rigorous lower-bound rejection before a row is fetched
     const unsigned char* codes;
     float code_scale, code_bias;
+    // graph-inline records (svsx_codes.hip; CODES == 2): node rows [ids | plane 0 | plane 1] per chunk of <= 64 slots
+    const unsigned char* fat;
+    size_t fat_stride;        // bytes per node
+    const float* pca_t;       // [d][pca_pd] transposed rotation: pca_t[j * pca_pd + i] = P[i][j]
+    const float* pca_mean;    // [d]
+    const float* pca_bias;    // [28] per-component code bias b_i
+    uint32_t pca_pd;
+    float pca_step;           // s
+    float pca_tail_unit;      // tx = half(tx16) * tail_unit
+    float pca_eps;            // >= || P P^T - I ||_F
+    float pca_eq_abs;         // absolute slack of the query coding error (rounding of b + s c)
+    // cancellation (index/vamana/index.h:541-545, greedy_search.h:155): device word polled once per expansion; non-zero = stop
+    const int* cancel;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
     uint32_t general;
     // BatchIterator (index/vamana/iterator.h): per-query state in HBM.  meta = 8 u32 per query:
@@ -152,6 +165,29 @@ struct RerankArgs {
 };
 hipError_t launch_rerank(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
 hipError_t launch_rerank2(int data_dtype, int metric, int qmode, const RerankArgs& a, hipStream_t stream);
+
+// graph-inline bound codes (svsx_codes.hip)
+struct PcaArgs {
+    const void* data;
+    size_t row_bytes;
+    int dtype;
+    uint32_t n, d, pd, dc;
+    const float* pt;        // [d][pd]
+    const float* mean;      // [d]
+    const float* bias;      // [dc]            (encode)
+    float step, tail_unit;  //                 (encode)
+    uint32_t* stat_min;     // [d] order keys  (stats; init 0xFFFFFFFF)
+    uint32_t* stat_max;     // [d] order keys  (stats; init 0)
+    uint32_t* stat_tail;    // max tail norm key (init 0)
+    uint32_t* stat_bad;     // vectors with a non-finite component (init 0)
+    uint32_t* records;      // [n][8]          (encode)
+};
+hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream);
+hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream);
+hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, void* d_fat, size_t fat_stride, hipStream_t stream);
+float pca_key_to_float(uint32_t key);
+// name of the search_kernel instantiation launch_search picked last on this thread (tests assert which one ran)
+const char* last_search_instantiation();
 
 // layout conversion kernels (index creation)
 // bound codes (svsx_index_build_bound_codes): d_mm3 = {min key, max key, non-finite count}

@@ -19,6 +19,8 @@
 #include "svsx_device.h"
 #include "svsx_kernels.h"
 
+#include <cstdio>
+
 #ifndef SVSX_CODE_BATCH
 // bound-code passes (16 candidates each) whose loads are issued together.  Measured on the bench workload: 1 -> 4.90,
 // 2 -> 5.17, 3 -> 5.13, 4 -> 4.55 M QPS (4 needs 105 VGPRs = 4 waves/SIMD); profiles/r01_notes.md
@@ -27,7 +29,7 @@
 
 namespace svsx {
 
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODES = false>
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0>
 __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     const bool tag8 = a.filter_tag8 != 0u;
     const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES) ? 256u : 0u)); // GENERAL only
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES != 0) ? 256u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -88,6 +90,9 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
             resume = (it_meta[6] & 1u) == 0u;
         }
     }
+    if constexpr (!GENERAL) {
+        if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return; // extensions.h:575-578
+    }
     const uint32_t fmask = a.filter_entries - 1u;
     const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));
     for (uint32_t i = lane; i < filt_bytes / 4u; i += 64) reinterpret_cast<uint32_t*>(filt)[i] = 0xFFFFFFFFu;
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     int code_qq = 0;
     float code_eq = 0.0f;
     uint32_t n_code_rej = 0;
-    if constexpr (CODES) {
+    if constexpr (CODES == 1) {
         static_assert(G == 4 && DS > 0, "bound codes: f32 rows of static dimension");
         constexpr int DC = DS < 120 ? DS : 120;
         const float inv = 1.0f / a.code_scale;
@@ -146,6 +151,63 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         code_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, code_eq)));
     }
 
+    // ---- graph-inline records (svsx_codes.hip; CODES == 2): rotate and code the query once ---------------------------------
+    //   u = P (q - mean) in f32 (v_j = fl(q_j - mean_j), one fma chain per component: |error_i| <= (d + 1) 2^-24 ||P_i|| ||q - mean||),
+    //   codes of u_0..27 with the index' (step, bias), eq >= ||u_C - (b + s cq)|| + rotation error, tq = ||u_T||.
+    uint32_t fq[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int fat_qq = 0;
+    float fat_eq = 0.0f, fat_tq = 0.0f, fat_et0 = 0.0f, fat_s2m = 0.0f;
+    if constexpr (CODES == 2) {
+        constexpr int DC = 28;
+        float u0 = 0.0f, u1 = 0.0f, vv = 0.0f;
+        for (int j = 0; j < d; ++j) {
+            const float v = qf[j] - a.pca_mean[j];
+            const float* pr = a.pca_t + static_cast<size_t>(j) * a.pca_pd; // rows zero padded to 128 components
+            u0 = __builtin_fmaf(pr[lane], v, u0);
+            u1 = __builtin_fmaf(pr[lane + 64], v, u1);
+            vv = __builtin_fmaf(v, v, vv);
+        }
+        float r2 = 0.0f, t2 = u1 * u1;
+        int ci = 0;
+        if (lane < static_cast<uint32_t>(DC)) {
+            const float b = a.pca_bias[lane];
+            float c = __builtin_rintf((u0 - b) / a.pca_step);
+            c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
+            if (!(c == c)) c = 0.0f;
+            ci = static_cast<int>(c);
+            const float r = u0 - (b + a.pca_step * c);
+            r2 = r * r;
+        } else {
+            t2 = __builtin_fmaf(u0, u0, t2);
+        }
+        int qq = ci * ci;
+        for (int off = 32; off >= 1; off >>= 1) {
+            r2 += __shfl_xor(r2, off);
+            t2 += __shfl_xor(t2, off);
+            qq += __shfl_xor(qq, off);
+        }
+        uint8_t* cb = reinterpret_cast<uint8_t*>(compact);
+        if (lane < 32u) cb[lane] = static_cast<uint8_t>(ci); // lanes 28..31 write 0
+        lds_order();
+#pragma unroll
+        for (int w = 0; w < 7; ++w) fq[w] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(compact[w])));
+        lds_order();
+        fat_qq = __builtin_amdgcn_readfirstlane(qq);
+        const float vn = __builtin_sqrtf(vv) * 1.00001f;
+        const float urel = static_cast<float>(d + 2) * 5.9604645e-8f * 1.01f; // (d + 2) 2^-24
+        float eq = __builtin_sqrtf(r2) * 1.0001f + 5.2915f * urel * vn + a.pca_eq_abs;            // sqrt(28) = 5.2915
+        const float tq = __builtin_sqrtf(t2);
+        float et0 = __builtin_sqrtf(static_cast<float>(d > DC ? d - DC : 1)) * urel * vn + tq * 1.0e-5f + a.pca_tail_unit * 6.0e-8f;
+        if (!(eq < 3.0e38f) || !(et0 < 3.0e38f)) { // non-finite query: the bound never fires
+            eq = __builtin_inff();
+            et0 = __builtin_inff();
+        }
+        fat_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, eq)));
+        fat_tq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tq)));
+        fat_et0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, et0)));
+        fat_s2m = a.pca_step * a.pca_step * 0.99999f;
+    }
+
     // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
     // candidate out (l2_row_distance_two_phase); result-neutral, removes the third line of most rows at d = 96
     constexpr bool TWO_PHASE = QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && DS > 64 && DS <= 128;
@@ -156,7 +218,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         const unsigned char* row = data + static_cast<size_t>(active ? cid : 0u) * a.row_bytes;
         float fmain = 0.0f, fnrm = 0.0f;
         int ab = 0, bb = 0;
-        if constexpr (TWO_PHASE && !CODES) { // survivors of the bound codes are close to the worst entry: fetch whole rows
+        if constexpr (TWO_PHASE && CODES == 0) { // survivors of the bound codes are close to the worst entry: fetch whole rows
             bool rejected = false;
             const float dd = l2_row_distance_two_phase<DT, (DS > 64 && DS <= 128) ? DS : 96>(row, active, qf, sub, thr, rejected);
             n_early += __popcll(__ballot(active && rejected && sub == 0));
@@ -196,11 +258,13 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
                 const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
                 ++n_eval;
-                if (a.filter_entries != 0u && lane == 0) {
-                    if (tag8) filt8[id & fmask] = static_cast<uint8_t>(id >> fshift);
-                    else filt[id & fmask] = static_cast<uint16_t>(id >> fshift);
-                }
                 if (buf.size < buf.capacity) {
+                    // EntryPointInitializer never touches the visited set (greedy_search.h:69-90); marking an entry point that was
+                    // really pushed is result-neutral (re-encountering it would be a duplicate), one that push_back dropped is not
+                    if (a.filter_entries != 0u && lane == 0) {
+                        if (tag8) filt8[id & fmask] = static_cast<uint8_t>(id >> fshift);
+                        else filt[id & fmask] = static_cast<uint16_t>(id >> fshift);
+                    }
                     // push_back + (stable) sort == ordered insert without the duplicate check
                     uint32_t pos = append_then_sort ? buf.size : 0u;
                     for (uint32_t i0 = 0; !append_then_sort && i0 < buf.size; i0 += 64) {
@@ -238,7 +302,12 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     float worst = (full && buf.capacity > 0u) ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
 
     // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
+    int cancel_seen = 0;
     while (!wave_done(buf)) {
+        if (a.cancel != nullptr) { // greedy_search.h:155: `if (cancel()) return;` -- the word read here is consumed one expansion later
+            if (cancel_seen != 0) break;
+            cancel_seen = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         float node_dist;
         const uint32_t node = wave_next(buf, lane, node_dist);
         if (a.history_ids != nullptr && lane == 0 && n_exp < a.history_cap) {
@@ -249,11 +318,73 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
         const uint32_t* grow = a.graph + static_cast<size_t>(node) * a.gstride;
         for (uint32_t gbase = 0; gbase < a.gstride; gbase += 64) {
             uint32_t nid = kInvalidId;
-            if (gbase + lane < a.gstride) nid = grow[gbase + lane];
+            [[maybe_unused]] uint4 rec0 = make_uint4(0u, 0u, 0u, 0u), rec1 = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (CODES == 2) {
+                // one contiguous block per chunk: [ids | plane 0 | plane 1]; lane c owns neighbour c and its 32-byte record
+                const uint32_t cs = (a.gstride - gbase) < 64u ? (a.gstride - gbase) : 64u;
+                const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(gbase) * 36u);
+                const uint4* p0 = reinterpret_cast<const uint4*>(fids + cs);
+                if (lane < cs) {
+                    nid = fids[lane];
+                    rec0 = p0[lane];
+                    rec1 = p0[cs + lane];
+                }
+            } else {
+                if (gbase + lane < a.gstride) nid = grow[gbase + lane];
+            }
             const uint32_t deg_here = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
             n_slots += deg_here;
             uint32_t cnt = deg_here;
-            if (a.filter_entries != 0u) {
+            if constexpr (CODES == 2) {
+                bool keep = nid != kInvalidId;
+                if (a.filter_entries != 0u && keep) { // emplace_visited (greedy_search.h:191-193)
+                    const uint32_t h = nid & fmask;
+                    const uint32_t tag = nid >> fshift;
+                    if (tag8) {
+                        keep = static_cast<uint32_t>(filt8[h]) != tag;
+                        filt8[h] = static_cast<uint8_t>(tag);
+                    } else {
+                        keep = static_cast<uint32_t>(filt[h]) != tag;
+                        filt[h] = static_cast<uint16_t>(tag);
+                    }
+                }
+                if (full) {
+                    // lower bound of every candidate of this chunk, lane-parallel.  With A = max(0, s sqrt(I) - e), e = eq + ex, and
+                    // B = max(0, | ||u_T|| - ||y_T|| | - slack):  (1 + eps) dist >= A^2 + B^2.  Reject iff A^2 + B^2 > W' := worst (1 + eps) 1.0001,
+                    // which is implied by  s^2 I > W' - B^2 + e (2 sqrt(W') + e)   (sqrt(W' - B^2) <= sqrt(W'): one square root per expansion).
+                    // `worst` can only improve while this expansion's survivors are inserted, so the bound stays valid.
+                    const float wp = worst * (1.0f + a.pca_eps) * 1.0001f;
+                    const float r2 = 2.0f * __builtin_amdgcn_sqrtf(wp) * 1.00001f;
+                    uint32_t dqx = 0u, dxx = 0u;
+                    dqx = __builtin_amdgcn_udot4(rec0.x, fq[0], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.x, rec0.x, dxx, false);
+                    dqx = __builtin_amdgcn_udot4(rec0.y, fq[1], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.y, rec0.y, dxx, false);
+                    dqx = __builtin_amdgcn_udot4(rec0.z, fq[2], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.z, rec0.z, dxx, false);
+                    dqx = __builtin_amdgcn_udot4(rec0.w, fq[3], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.w, rec0.w, dxx, false);
+                    dqx = __builtin_amdgcn_udot4(rec1.x, fq[4], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.x, rec1.x, dxx, false);
+                    dqx = __builtin_amdgcn_udot4(rec1.y, fq[5], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.y, rec1.y, dxx, false);
+                    dqx = __builtin_amdgcn_udot4(rec1.z, fq[6], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.z, rec1.z, dxx, false);
+                    const float fi = static_cast<float>(fat_qq + static_cast<int>(dxx) - 2 * static_cast<int>(dqx)); // sum (cq - cx)^2 < 2^24: exact
+                    const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w & 0xFFFFu))) * a.pca_step;
+                    const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w >> 16))) * a.pca_tail_unit;
+                    const float e = fat_eq + ex;
+                    const float t = __builtin_fabsf(fat_tq - tx) - (fat_et0 + tx * 4.94e-4f); // tx is a nearest float16: 2^-11 relative
+                    const float bb = (t > 0.0f ? t : 0.0f) * 0.99999f;
+                    const float rhs = wp - bb * bb + e * (r2 + e) * 1.00001f;
+                    const bool rej = fi * fat_s2m > rhs; // false for NaN / inf thresholds
+                    const uint32_t nrej = __popcll(__ballot(keep && rej));
+                    n_code_rej += nrej;
+                    n_eval += nrej;
+                    keep = keep && !rej;
+                }
+                const unsigned long long km = __ballot(keep);
+                cnt = __popcll(km);
+                const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
+                lds_order();
+                if (keep) compact[rank] = nid;
+                lds_order();
+                nid = lane < cnt ? compact[lane] : kInvalidId;
+                lds_order();
+            } else if (a.filter_entries != 0u) {
                 // emplace_visited (greedy_search.h:191-193): drop ids already evaluated, keep adjacency order
                 bool keep = nid != kInvalidId;
                 if (keep) {
@@ -276,7 +407,7 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                 nid = lane < cnt ? compact[lane] : kInvalidId;
                 lds_order();
             }
-            if constexpr (CODES) {
+            if constexpr (CODES == 1) {
                 if (full && cnt > 0u) {
                     // bound pass over all candidates of this expansion; survivors keep their adjacency order.  `worst` can
                     // only improve while they are inserted, so a bound taken against the current worst stays valid.
@@ -453,14 +584,18 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODES = false> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+static thread_local char g_last_inst[96] = "";
+const char* last_search_instantiation() { return g_last_inst; }
+
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+    snprintf(g_last_inst, sizeof(g_last_inst), "search_kernel<dt=%d,metric=%d,qmode=%d,ds=%d,general=%d,codes=%d>", DT, METRIC, QMODE, DS, GENERAL ? 1 : 0, CODES);
     const int d = static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       ((a.filter_entries || CODES) ? 64 * 4 : 0) + (GENERAL ? 64 * 8 : 0);
+                       ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES>;
     if (lds > 48 * 1024) {
@@ -474,8 +609,11 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, bool CODE
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
     if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && METRIC == M_L2) {
-        if (a.codes != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, true>(a, stream);
-        if (a.codes != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, true>(a, stream);
+        if (a.fat != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 2>(a, stream);
+        if (a.fat != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 2>(a, stream);
+        if (a.fat != nullptr) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+        if (a.codes != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 1>(a, stream);
+        if (a.codes != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 1>(a, stream);
     }
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         if (a.d == 96) return launch_one<DT, METRIC, QMODE, 96>(a, stream);

@@ -200,9 +200,15 @@ class VamanaIndex:
         res = QueryResult(ids, dists)
         return (res, st) if stats else res
 
-    def build_bound_codes(self, enable: bool = True) -> None:
-        """svsx_index_build_bound_codes: result-neutral lower-bound rejection (float32 L2, d = 96 / 128)."""
-        _lib.check(_lib.lib().svsx_index_build_bound_codes(self._h, int(enable)))
+    def build_bound_codes(self, mode: int | bool = 1) -> None:
+        """svsx_index_build_bound_codes: result-neutral lower-bound rejection for float32 / float16 L2 indexes.
+        mode 1 (True): 128-byte code row per vector (d = 96 / 128); mode 2: graph-inline 32-byte records per neighbour
+        (32 <= d <= 128); 0 (False): off."""
+        _lib.check(_lib.lib().svsx_index_build_bound_codes(self._h, int(mode)))
+
+    def last_kernel_info(self) -> str:
+        """svsx_last_kernel_info: which search-kernel instantiation the last search on this thread launched."""
+        return _lib.lib().svsx_last_kernel_info().decode()
 
     def batch_iterator(self, queries, extra_search_buffer_capacity: int | None = None):
         """VamanaIndex::make_batch_iterator (index/vamana/index.h:936), one iterator per query of the batch."""

@@ -21,9 +21,12 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def _check(svs, oracle, x, graph, entry, q, configs, expect_rejects=True):
+MODES = [1, 2]  # 1: 128-byte code row per vector; 2: graph-inline 32-byte records (PCA basis)
+
+
+def _check(svs, oracle, x, graph, entry, q, configs, expect_rejects=True, mode=1):
     idx = svs.VamanaIndex(graph, x, svs.DistanceL2(), entry)
-    idx.build_bound_codes()
+    idx.build_bound_codes(mode)
     rej = 0
     for w, c, k, vis in configs:
         sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis)
@@ -34,6 +37,7 @@ def _check(svs, oracle, x, graph, entry, q, configs, expect_rejects=True):
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
         if not vis:
             assert (st[:, 2] == ost[:, 2]).all()  # every candidate is still accounted for
+        assert f"codes={mode}" in idx.last_kernel_info(), idx.last_kernel_info()
         rej += int(st[:, 5].sum())
     if expect_rejects:
         assert rej > 0
@@ -47,40 +51,67 @@ def _check(svs, oracle, x, graph, entry, q, configs, expect_rejects=True):
 CONFIGS = [(10, 10, 10, 0), (32, 32, 10, 1), (20, 40, 10, 0), (128, 128, 10, 1), (5, 5, 5, 0), (64, 64, 64, 0)]
 
 
-def test_bound_codes_small_world(svs, oracle, small_world):
+@pytest.mark.parametrize("mode", MODES)
+def test_bound_codes_small_world(svs, oracle, small_world, mode):
     sw = small_world
-    rej = _check(svs, oracle, sw["x"], sw["graph"], sw["entry"], sw["q"], CONFIGS)
+    rej = _check(svs, oracle, sw["x"], sw["graph"], sw["entry"], sw["q"], CONFIGS, mode=mode)
     assert rej > 1000  # the bound really removes row fetches
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("qdt", [np.float32, np.float16])
-def test_bound_codes_float16_rows(svs, oracle, small_world, qdt):
+def test_bound_codes_float16_rows(svs, oracle, small_world, qdt, mode):
     """float16 data (192- / 256-byte rows): same codes, same bound, exact path = the block-cyclic f16 kernel"""
     sw = small_world
-    rej = _check(svs, oracle, sw["x"].astype(np.float16), sw["graph"], sw["entry"], sw["q"].astype(qdt), CONFIGS)
+    rej = _check(svs, oracle, sw["x"].astype(np.float16), sw["graph"], sw["entry"], sw["q"].astype(qdt), CONFIGS, mode=mode)
     assert rej > 1000
     x = deep_like(2000, 128, 24, seed=21).astype(np.float16)
     q = deep_like(32, 128, 24, seed=22).astype(qdt)
     g, e = oracle.build_vamana(L2, x, R=24, L=40)
-    _check(svs, oracle, x, g, e, q, CONFIGS)
+    _check(svs, oracle, x, g, e, q, CONFIGS, mode=mode)
     rng = np.random.default_rng(9)  # un-normalised, offset, with outliers
     x = (deep_like(900, 96, 10, seed=23, normalize=False) * np.float32(3.0) + np.float32(7.0))
     x[rng.integers(0, 900, 4)] *= np.float32(20.0)
     x = x.astype(np.float16)
     q = (x[rng.integers(0, 900, 16)].astype(np.float32) + rng.standard_normal((16, 96)).astype(np.float32)).astype(qdt)
     g, e = oracle.build_vamana(L2, x, R=16, L=32)
-    _check(svs, oracle, x, g, e, q, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], expect_rejects=False)
+    _check(svs, oracle, x, g, e, q, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], expect_rejects=False, mode=mode)
 
 
-def test_bound_codes_d128(svs, oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_bound_codes_d128(svs, oracle, mode):
     x = deep_like(2000, 128, 24, seed=21)
     q = deep_like(32, 128, 24, seed=22)
     g, e = oracle.build_vamana(L2, x, R=24, L=40)
-    _check(svs, oracle, x, g, e, q, CONFIGS)
+    _check(svs, oracle, x, g, e, q, CONFIGS, mode=mode)
 
 
+@pytest.mark.parametrize("d,R", [(32, 16), (40, 24), (64, 64), (100, 32), (112, 70), (127, 128)])
+def test_inline_records_any_dimension_and_degree(svs, oracle, d, R):
+    """mode 2 serves every 32 <= d <= 128 (runtime-d kernel, ragged tails) and every max degree (rows of 16 .. 128 slots,
+    two chunks above 64)"""
+    x = deep_like(1200, d, 12, seed=d)
+    q = deep_like(24, d, 12, seed=d + 1)
+    g, e = oracle.build_vamana(L2, x, R=R, L=max(48, R + 8))
+    rej = _check(svs, oracle, x, g, e, q, [(16, 16, 10, 0), (40, 60, 20, 1), (128, 128, 10, 1)], mode=2)
+    assert rej > 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_bound_codes_offset_band(svs, oracle, mode):
+    """data in a narrow band far from the origin (|x| / spread ~ 1e3 .. 1e5): the rounding of the query's own coding has to
+    be covered by an explicit error term, not by a relative margin"""
+    rng = np.random.default_rng(77)
+    for off, spread in ((1.0e3, 1.0), (3.0e4, 0.5), (-2.0e5, 4.0)):
+        x = (deep_like(900, 96, 12, seed=5, normalize=False) * np.float32(spread) + np.float32(off)).astype(np.float32)
+        q = x[rng.integers(0, 900, 16)] + rng.standard_normal((16, 96)).astype(np.float32) * np.float32(spread)
+        g, e = oracle.build_vamana(L2, x, R=24, L=40)
+        _check(svs, oracle, x, g, e, q, [(16, 16, 10, 0), (64, 64, 10, 1), (128, 128, 10, 0)], expect_rejects=False, mode=mode)
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("seed", range(6))
-def test_bound_codes_fuzz(svs, oracle, seed):
+def test_bound_codes_fuzz(svs, oracle, seed, mode):
     """scales from 1e-3 to 1e4, offsets, outliers that stretch the code range, queries far outside the data range"""
     rng = np.random.default_rng(100 + seed)
     d = 96 if seed % 2 == 0 else 128
@@ -93,10 +124,11 @@ def test_bound_codes_fuzz(svs, oracle, seed):
     q[:4] *= np.float32(30.0)  # far outside [min, max]: clamped query codes
     q[4] = x[7]                # a database point itself
     g, e = oracle.build_vamana(L2, x, R=int(rng.integers(8, 40)), L=48)
-    _check(svs, oracle, x, g, e, q, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], expect_rejects=False)
+    _check(svs, oracle, x, g, e, q, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], expect_rejects=False, mode=mode)
 
 
-def test_bound_codes_equidistant_candidates(svs, oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_bound_codes_equidistant_candidates(svs, oracle, mode):
     """every database point at (almost) the same distance from the query: the bound sits right at the threshold"""
     rng = np.random.default_rng(5)
     n, d = 1200, 96
@@ -105,29 +137,30 @@ def test_bound_codes_equidistant_candidates(svs, oracle):
     q = np.zeros((8, d), np.float32)
     q[1:] = rng.standard_normal((7, d)).astype(np.float32) * np.float32(1e-4)
     g, e = oracle.build_vamana(L2, x, R=24, L=40)
-    _check(svs, oracle, x, g, e, q, CONFIGS, expect_rejects=False)
+    _check(svs, oracle, x, g, e, q, CONFIGS, expect_rejects=False, mode=mode)
     x2 = np.concatenate([x[:600], x[:600]])  # exact duplicates: ties at the worst entry
     g2, e2 = oracle.build_vamana(L2, x2, R=24, L=40)
-    _check(svs, oracle, x2, g2, e2, x2[:16] + np.float32(1e-3), CONFIGS, expect_rejects=False)
+    _check(svs, oracle, x2, g2, e2, x2[:16] + np.float32(1e-3), CONFIGS, expect_rejects=False, mode=mode)
 
 
-def test_bound_codes_scope(svs, oracle, small_world):
+@pytest.mark.parametrize("mode", MODES)
+def test_bound_codes_scope(svs, oracle, small_world, mode):
     sw = small_world
     idx = svs.VamanaIndex(sw["graph"], sw["x"].astype(np.float16), svs.DistanceCosineSimilarity(), sw["entry"])
     with pytest.raises(svs.SvsxError) as e:
-        idx.build_bound_codes()
+        idx.build_bound_codes(mode)
     assert e.value.code == 3  # NOT_IMPLEMENTED
     idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceIP(), sw["entry"])
     with pytest.raises(svs.SvsxError):
-        idx.build_bound_codes()
+        idx.build_bound_codes(mode)
     bad = sw["x"].copy()
     bad[3, 5] = np.inf
     idx = svs.VamanaIndex(sw["graph"], bad, svs.DistanceL2(), sw["entry"])
     with pytest.raises(svs.SvsxError):
-        idx.build_bound_codes()
+        idx.build_bound_codes(mode)
     # the iterator and f16 queries keep working on an index with codes
     idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
-    idx.build_bound_codes()
+    idx.build_bound_codes(mode)
     res = idx.search(sw["q"].astype(np.float16), 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(30)))
     ids, dists = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"].astype(np.float16), 10, 30)
     assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all()
