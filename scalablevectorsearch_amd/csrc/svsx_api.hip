@@ -46,7 +46,7 @@ struct svsx_index {
     // graph-inline records (svsx_index_build_bound_codes mode 2; svsx_codes.hip)
     void* d_fat = nullptr;
     size_t fat_stride = 0;
-    float* d_pca = nullptr;      // [d][128] transposed rotation | [128] mean | [32] bias
+    float* d_pca = nullptr;      // [128][dpad] rotation (row-major, zero padded) | [128] mean | [32] bias
     float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_eps = 0.0f, pca_eq_abs = 0.0f;
 };
 
@@ -334,7 +334,7 @@ float half_bits_to_float(uint16_t h) {
 }
 
 constexpr uint32_t kFatDc = 28;     // coded components per record
-constexpr uint32_t kPcaPd = 128;    // padded component count of the rotation rows
+constexpr uint32_t kPcaRows = 128;  // rows of the device copy of the rotation (components; zero rows beyond d)
 
 // graph-inline records: sample -> PCA rotation (host, f64) -> per-vector records (device) -> node rows (device)
 int build_fat_rows(svsx_index* ix) {
@@ -355,7 +355,7 @@ int build_fat_rows(svsx_index* ix) {
     for (size_t r = 0; r < ns; ++r)
         for (uint32_t j = 0; j < d; ++j) mean[j] += xs[r * d + j];
     for (uint32_t j = 0; j < d; ++j) mean[j] /= static_cast<double>(ns);
-    std::vector<float> mean_f(kPcaPd, 0.0f);
+    std::vector<float> mean_f(kPcaRows, 0.0f);
     for (uint32_t j = 0; j < d; ++j) mean_f[j] = static_cast<float>(mean[j]);
     std::vector<double> cov(static_cast<size_t>(d) * d, 0.0), row(d);
     for (size_t r = 0; r < ns; ++r) {
@@ -378,12 +378,14 @@ int build_fat_rows(svsx_index* ix) {
     std::vector<uint32_t> order(d);
     for (uint32_t i = 0; i < d; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cov[static_cast<size_t>(x) * d + x] > cov[static_cast<size_t>(y) * d + y]; });
-    std::vector<float> host(static_cast<size_t>(d) * kPcaPd + kPcaPd + 32, 0.0f); // pt | mean | bias
+    const uint32_t pd = (d + 15u) & ~15u;                      // floats per row of the device copy
+    const size_t p_floats = static_cast<size_t>(kPcaRows) * pd;  // 128 rows: lane i of the search kernel owns rows i, i + 64
+    std::vector<float> host(p_floats + kPcaRows + 32, 0.0f);    // P | mean | bias
     std::vector<double> P(static_cast<size_t>(d) * d);
     for (uint32_t i = 0; i < d; ++i)
         for (uint32_t j = 0; j < d; ++j) {
             const float f = static_cast<float>(V[static_cast<size_t>(j) * d + order[i]]);
-            host[static_cast<size_t>(j) * kPcaPd + i] = f;
+            host[static_cast<size_t>(i) * pd + j] = f;
             P[static_cast<size_t>(i) * d + j] = f;
         }
     double fro = 0.0;
@@ -396,19 +398,20 @@ int build_fat_rows(svsx_index* ix) {
         }
     const double eps = std::sqrt(fro) * 1.01 + 1e-7;
     if (!(eps < 1e-3)) return fail(SVSX_RUNTIME_ERROR, "PCA rotation is not orthonormal enough (eps = %g)", eps);
-    for (uint32_t j = 0; j < d; ++j) host[static_cast<size_t>(d) * kPcaPd + j] = mean_f[j];
+    for (uint32_t j = 0; j < d; ++j) host[p_floats + j] = mean_f[j];
     if (!ix->d_pca) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pca), host.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(ix->d_pca, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     // 3. per-component range of y over ALL vectors (device), clipped to +-8 sigma; step, biases, tail unit
     DeviceBuffer st;
+    constexpr uint32_t kPcaPd = kPcaRows; // stride of the statistics arrays
     HIP_TRY(st.alloc((2 * kPcaPd + 2) * 4));
     std::vector<uint32_t> init(2 * kPcaPd + 2, 0u);
     for (uint32_t i = 0; i < kPcaPd; ++i) init[i] = 0xFFFFFFFFu;
     HIP_TRY(hipMemcpy(st.p, init.data(), init.size() * 4, hipMemcpyHostToDevice));
     PcaArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.pd = kPcaPd; pa.dc = kFatDc;
-    pa.pt = ix->d_pca; pa.mean = ix->d_pca + static_cast<size_t>(d) * kPcaPd; pa.bias = pa.mean + kPcaPd;
+    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.pd = pd; pa.dc = kFatDc;
+    pa.pt = ix->d_pca; pa.mean = ix->d_pca + p_floats; pa.bias = pa.mean + kPcaRows;
     pa.stat_min = static_cast<uint32_t*>(st.p); pa.stat_max = pa.stat_min + kPcaPd; pa.stat_tail = pa.stat_max + kPcaPd; pa.stat_bad = pa.stat_tail + 1;
     HIP_TRY(launch_pca_stats(pa, nullptr));
     std::vector<uint32_t> stats(2 * kPcaPd + 2);
@@ -433,7 +436,7 @@ int build_fat_rows(svsx_index* ix) {
     float tail_max = pca_key_to_float(stats[2 * kPcaPd]);
     if (!(tail_max > 0.0f)) tail_max = 1.0f;
     const float tail_unit = tail_max / 60000.0f;
-    HIP_TRY(hipMemcpy(ix->d_pca + static_cast<size_t>(d) * kPcaPd + kPcaPd, bias.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->d_pca + p_floats + kPcaRows, bias.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
     // 4. records, then node rows
     DeviceBuffer rec;
     HIP_TRY(rec.alloc(static_cast<size_t>(n) * 32 + 32));
@@ -533,10 +536,10 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     if (ix->d_fat && !a.general) { // graph-inline records: same guarantee, one contiguous block per expansion
         a.fat = static_cast<const unsigned char*>(ix->d_fat);
         a.fat_stride = ix->fat_stride;
+        a.pca_pd = static_cast<uint32_t>((ix->d + 15) & ~size_t(15));
         a.pca_t = ix->d_pca;
-        a.pca_mean = ix->d_pca + ix->d * kPcaPd;
-        a.pca_bias = a.pca_mean + kPcaPd;
-        a.pca_pd = kPcaPd;
+        a.pca_mean = ix->d_pca + static_cast<size_t>(kPcaRows) * a.pca_pd;
+        a.pca_bias = a.pca_mean + kPcaRows;
         a.pca_step = ix->pca_step;
         a.pca_tail_unit = ix->pca_tail_unit;
         a.pca_eps = ix->pca_eps;

@@ -55,11 +55,12 @@ __device__ __forceinline__ void project(const PcaArgs& a, const unsigned char* r
     y[0] = 0.0;
     y[1] = 0.0;
     const bool has0 = lane < a.d, has1 = lane + 64 < a.d;
+    const float* r0 = a.pt + static_cast<size_t>(lane) * a.pd;       // row-major rotation, `pd` floats per row
+    const float* r1 = a.pt + static_cast<size_t>(lane + 64u) * a.pd;
     for (uint32_t j = 0; j < a.d; ++j) {
         const double v = vs[j];
-        const float* pr = a.pt + static_cast<size_t>(j) * a.pd;
-        if (has0) y[0] = __builtin_fma(static_cast<double>(pr[lane]), v, y[0]);
-        if (has1) y[1] = __builtin_fma(static_cast<double>(pr[lane + 64]), v, y[1]);
+        if (has0) y[0] = __builtin_fma(static_cast<double>(r0[j]), v, y[0]);
+        if (has1) y[1] = __builtin_fma(static_cast<double>(r1[j]), v, y[1]);
     }
     __syncthreads();
 }

@@ -43,7 +43,7 @@ struct SearchArgs {
     // graph-inline records (svsx_codes.hip; CODES == 2): node rows [ids | plane 0 | plane 1] per chunk of <= 64 slots
     const unsigned char* fat;
     size_t fat_stride;        // bytes per node
-    const float* pca_t;       // [d][pca_pd] transposed rotation: pca_t[j * pca_pd + i] = P[i][j]
+    const float* pca_t;       // [128][pca_pd] rotation, row-major: pca_t[i * pca_pd + j] = P[i][j], zero padded (pca_pd = d rounded up to 16)
     const float* pca_mean;    // [d]
     const float* pca_bias;    // [28] per-component code bias b_i
     uint32_t pca_pd;
@@ -172,7 +172,7 @@ struct PcaArgs {
     size_t row_bytes;
     int dtype;
     uint32_t n, d, pd, dc;
-    const float* pt;        // [d][pd]
+    const float* pt;        // [128][pd] row-major rotation (pd = d rounded up to 16), zero padded
     const float* mean;      // [d]
     const float* bias;      // [dc]            (encode)
     float step, tail_unit;  //                 (encode)

@@ -29,8 +29,14 @@
 
 namespace svsx {
 
+#ifdef SVSX_WAVES_PER_EU
+#define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(SVSX_WAVES_PER_EU)))
+#else
+#define SVSX_KERNEL_ATTR
+#endif
+
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0>
-__global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
+__global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
     constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
@@ -159,13 +165,30 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
     float fat_eq = 0.0f, fat_tq = 0.0f, fat_et0 = 0.0f, fat_s2m = 0.0f;
     if constexpr (CODES == 2) {
         constexpr int DC = 28;
+        // lane i owns rows i and i + 64 of P (row-major, `dpad` floats per row, 128 rows, zero padded): 16-byte loads of its
+        // own rows (L1 / L2 resident: the matrix is shared by every query), v_j = q_j - mean_j broadcast from LDS / scalar loads
         float u0 = 0.0f, u1 = 0.0f, vv = 0.0f;
-        for (int j = 0; j < d; ++j) {
-            const float v = qf[j] - a.pca_mean[j];
-            const float* pr = a.pca_t + static_cast<size_t>(j) * a.pca_pd; // rows zero padded to 128 components
-            u0 = __builtin_fmaf(pr[lane], v, u0);
-            u1 = __builtin_fmaf(pr[lane + 64], v, u1);
-            vv = __builtin_fmaf(v, v, vv);
+        const float4* prow0 = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(lane) * dpad);
+        const float4* prow1 = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(lane + 64u) * dpad);
+        const bool two = d > 64;
+#pragma unroll 1
+        for (int j0 = 0; j0 < dpad; j0 += 8) { // rolled: the rotation must not raise the kernel's register peak
+            float4 pa[2], pb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pa[t] = prow0[(j0 >> 2) + t];
+                pb[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (two) pb[t] = prow1[(j0 >> 2) + t];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 qv = *reinterpret_cast<const float4*>(qf + j0 + 4 * t);
+                const float4 mv = *reinterpret_cast<const float4*>(a.pca_mean + j0 + 4 * t);
+                const float v0 = qv.x - mv.x, v1 = qv.y - mv.y, v2 = qv.z - mv.z, v3 = qv.w - mv.w;
+                u0 = __builtin_fmaf(pa[t].x, v0, u0); u0 = __builtin_fmaf(pa[t].y, v1, u0); u0 = __builtin_fmaf(pa[t].z, v2, u0); u0 = __builtin_fmaf(pa[t].w, v3, u0);
+                u1 = __builtin_fmaf(pb[t].x, v0, u1); u1 = __builtin_fmaf(pb[t].y, v1, u1); u1 = __builtin_fmaf(pb[t].z, v2, u1); u1 = __builtin_fmaf(pb[t].w, v3, u1);
+                vv = __builtin_fmaf(v0, v0, vv); vv = __builtin_fmaf(v1, v1, vv); vv = __builtin_fmaf(v2, v2, vv); vv = __builtin_fmaf(v3, v3, vv);
+            }
         }
         float r2 = 0.0f, t2 = u1 * u1;
         int ci = 0;
@@ -337,17 +360,12 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
             uint32_t cnt = deg_here;
             if constexpr (CODES == 2) {
                 bool keep = nid != kInvalidId;
-                if (a.filter_entries != 0u && keep) { // emplace_visited (greedy_search.h:191-193)
-                    const uint32_t h = nid & fmask;
-                    const uint32_t tag = nid >> fshift;
-                    if (tag8) {
-                        keep = static_cast<uint32_t>(filt8[h]) != tag;
-                        filt8[h] = static_cast<uint8_t>(tag);
-                    } else {
-                        keep = static_cast<uint32_t>(filt[h]) != tag;
-                        filt[h] = static_cast<uint16_t>(tag);
-                    }
-                }
+                // visited filter (greedy_search.h:191-193), here holding only the ids whose rows were really fetched: a candidate the
+                // bound rejected is rejected again by the bound (worst only improves) at no memory cost, so it need not be
+                // remembered -- the same table then covers the whole query almost without evictions.  A hit = this id went
+                // through the exact path earlier in this query, re-inserting it would be a no-op.
+                const uint32_t fh = nid & fmask, ftag = nid >> fshift;
+                if (a.filter_entries != 0u && keep) keep = (tag8 ? static_cast<uint32_t>(filt8[fh]) : static_cast<uint32_t>(filt[fh])) != ftag;
                 if (full) {
                     // lower bound of every candidate of this chunk, lane-parallel.  With A = max(0, s sqrt(I) - e), e = eq + ex, and
                     // B = max(0, | ||u_T|| - ||y_T|| | - slack):  (1 + eps) dist >= A^2 + B^2.  Reject iff A^2 + B^2 > W' := worst (1 + eps) 1.0001,
@@ -375,6 +393,10 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchArgs a) {
                     n_code_rej += nrej;
                     n_eval += nrej;
                     keep = keep && !rej;
+                }
+                if (a.filter_entries != 0u && keep) {
+                    if (tag8) filt8[fh] = static_cast<uint8_t>(ftag);
+                    else filt[fh] = static_cast<uint16_t>(ftag);
                 }
                 const unsigned long long km = __ballot(keep);
                 cnt = __popcll(km);

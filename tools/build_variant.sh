@@ -1,0 +1,15 @@
+#!/bin/bash
+# A/B builds of libsvsx.so with extra hipcc defines:  tools/build_variant.sh <name> [-DFOO=1 ...]
+# -> variants/<name>/libsvsx.so (git-ignored; travels with gpurun).  Select at run time with SVSX_LIB=variants/<name>/libsvsx.so
+set -e
+NAME=$1; shift
+R=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$R/variants/$NAME
+mkdir -p $OUT
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-unused-function"
+cd $R/scalablevectorsearch_amd/csrc
+for f in svsx_search; do /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o $OUT/$f.o & done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsvsx.so $OUT/svsx_search.o svsx_api.o svsx_distance.o svsx_build.o svsx_flat.o svsx_codes.o
+rm -f $OUT/*.o
+echo built $OUT/libsvsx.so

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""One PMC target: build (or load) one shard of the bench workload and launch the search kernel `--launches` times at ONE
+configuration, nothing else -- so every search_kernel dispatch a rocprofv3 pass sees belongs to the workload named by
+`workload_key` (the key bench.py looks profiles/*_pmc.json up by).  Prints one JSON line with the key, the kernel source
+hash and the designed lines of a launch.
+   python tools/pmc_target.py --n 1000000 --window 128 --codes 2 [--matched] --graph-cache /tmp/g"""
+import argparse, json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import scalablevectorsearch_amd as svs
+from bench import LINE, brute_force_topk, build_or_load_graph, deep_like_device, designed_lines, kernel_src_sha, recall_at
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c2"); ap.add_argument("--n", type=int, default=1_000_000); ap.add_argument("--nq", type=int, default=10_000)
+ap.add_argument("--window", type=int, default=128); ap.add_argument("--codes", type=int, default=2); ap.add_argument("--visited", type=int, default=1)
+ap.add_argument("--degree", type=int, default=64); ap.add_argument("--launches", type=int, default=5); ap.add_argument("--graph-cache", default="")
+ap.add_argument("--matched", action="store_true", help="use the smallest window with recall@10 >= 0.9 instead of --window")
+ap.add_argument("--sid", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+d, k, R = 96, 10, a.degree
+x = deep_like_device(a.n, d, 24, seed=1 + 1000 * a.sid, device=dev)
+q = deep_like_device(a.nq, d, 24, seed=2, device=dev)
+cache = f"{a.graph_cache}.s{a.sid}.n{a.n}" if a.graph_cache else ""
+graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache)
+idx = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), torch.tensor([entry], dtype=torch.int32, device=dev), a.n, d, np.float32)
+if a.codes:
+    idx.build_bound_codes(a.codes)
+ids = torch.empty((a.nq, k), dtype=torch.int64, device=dev); dist = torch.empty((a.nq, k), device=dev)
+window = a.window
+if a.matched:
+    gt = brute_force_topk(x, q, k)
+    lo, hi = k, a.window
+    while lo < hi:
+        mid = (lo + hi) // 2
+        idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(mid), a.visited), d_ids64=ids, d_dists=dist); torch.cuda.synchronize()
+        if recall_at(gt, ids, k) >= 0.9: hi = mid
+        else: lo = mid + 1
+    window = lo
+sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(window), a.visited)
+stats = torch.zeros((a.nq, 6), dtype=torch.int32, device=dev)
+# marker launches bracket the target launches: window 1 searches (tiny LDS block) are easy to tell apart in the dispatch list
+mark = svs.VamanaSearchParameters(svs.SearchBufferConfig(1), 0)
+idx.search_device(q[:64], 1, mark, d_ids64=ids[:64, :1], d_dists=dist[:64, :1]); torch.cuda.synchronize()
+for i in range(a.launches):
+    idx.search_device(q, k, sp, d_ids64=ids, d_dists=dist, d_stats=stats if i == 0 else None)
+torch.cuda.synchronize()
+idx.search_device(q[:64], 1, mark, d_ids64=ids[:64, :1], d_dists=dist[:64, :1]); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.launches): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dist)
+e1.record(); torch.cuda.synchronize()
+lines = designed_lines(stats.to(torch.int64), (R + 15) // 16 * 16, d * 4, a.codes, d, k)
+print(json.dumps({"workload_key": f"{a.config}:n={a.n}:nq={a.nq}:window={window}:R={R}:visited={a.visited}:codes={a.codes}", "kernel_src_sha": kernel_src_sha(),
+                  "window": window, "launches": a.launches, "designed_lines_per_launch": lines, "designed_bytes_per_launch": lines["total"] * LINE,
+                  "kernel_ms_unprofiled_or_profiled": e0.elapsed_time(e1) / a.launches, "kernel": idx.last_kernel_info(),
+                  "stats_per_query": {"expansions": float(stats[:, 0].sum()) / a.nq, "evals": float(stats[:, 2].sum()) / a.nq, "bound_rejects": float(stats[:, 5].sum()) / a.nq}}))

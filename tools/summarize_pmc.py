@@ -1,69 +1,88 @@
 #!/usr/bin/env python3
-"""gpurun_out/<round>/pmc_* (tools/collect_pmc.sh) -> profiles/<round>_pmc.json + <round>_bench_kernel_stats.csv"""
+"""gpurun_out/<tag>/ (tools/collect_pmc.sh) -> profiles/<tag>_pmc.json (+ <tag>_kernel_stats.csv).
+Per-launch means over the search_kernel dispatches BETWEEN the two marker launches of tools/pmc_target.py."""
 import collections, csv, glob, json, os, statistics, sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-visited = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-bound_codes = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-base = f"gpurun_out/{rnd}"
+tag = sys.argv[1]
+base = f"gpurun_out/{tag}"
+target = json.loads(open(f"{base}/target.json").read().strip().splitlines()[-1])
+n_launch = target["launches"]
+
+
+def target_dispatches(rows):
+    """rows of search_kernel dispatches in launch order -> those between the two window-1 marker launches (LDS_Block_Size smallest)"""
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    lds = {int(r["Dispatch_Id"]): int(r["LDS_Block_Size"]) for r in rows}
+    grid = {int(r["Dispatch_Id"]): int(r["Grid_Size"]) for r in rows}
+    marks = [i for i in ids if grid[i] == 64 * 64]
+    assert len(marks) >= 2, marks
+    return [i for i in ids if marks[0] < i < marks[1]][:n_launch]
 
 
 def per_kernel(dirn, kname):
-    """counter sums per dispatch; for the search kernel only the window-128 launches (largest LDS block: the
-    candidate buffer is sized by the window) -- bench.py also launches smaller windows while calibrating."""
-    acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    lds = {}
+    rows = []
     for f in glob.glob(f"{base}/{dirn}/*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if kname in r["Kernel_Name"]:
-                acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
-                lds[r["Dispatch_Id"]] = int(r["LDS_Block_Size"])
-    if kname == "search_kernel":
-        # bench.py launches the window-128 searches FIRST (1 stats pass + warmup + steps); the calibration and
-        # matched-recall launches at smaller windows follow.  The PMC passes run with --steps 3 --warmup 1 -> first 5.
-        first = sorted(acc, key=lambda k: int(k))[:5]
-        acc = {k: acc[k] for k in first}
+        rows += [r for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
+    keep = set(target_dispatches(rows)) if kname == "search_kernel" else None
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rows:
+        if keep is None or int(r["Dispatch_Id"]) in keep:
+            acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
     return acc
 
 
 out = {}
 for d in sorted(glob.glob(f"{base}/pmc_*")):
-    dn = os.path.basename(d)
-    if dn == "pmc_calib":
-        continue
-    a = per_kernel(dn, "search_kernel")
+    a = per_kernel(os.path.basename(d), "search_kernel")
     for nm in sorted({k for v in a.values() for k in v}):
         out[nm] = statistics.mean(v[nm] for v in a.values())
-cal = list(per_kernel("pmc_calib", "distance_kernel").values())[0]["FETCH_SIZE"]
+cal_rows = []
+for f in glob.glob("gpurun_out/pmc_calib/*counter_collection.csv"):
+    cal_rows += [r for r in csv.DictReader(open(f)) if "distance_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+cal = sum(float(r["Counter_Value"]) for r in cal_rows)
 known = 3_000_000 * 96 * 4
-factor = known / (cal * 1024)
-s = {
-    "command": "rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --graph-cache /tmp/g1m.pt --no-cpu-baseline --steps 3 --warmup 1 (one pass per counter group; means over the search_kernel launches at window 128 of each pass)",
-    "workload": dict({"n": 1000000, "d": 96, "nq": 10000, "window": 128, "degree": 64, "visited": visited}, **({"bound_codes": bound_codes} if bound_codes else {})),
-    "kernel": "svsx::search_kernel<0,0,0,96,false,%s>" % ("true" if bound_codes else "false"),
+factor = known / (cal * 1024) if cal else float("nan")
+nq = 10000
+s = dict(target)
+s.update({
+    "command": "tools/collect_pmc.sh %s ... : rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python tools/pmc_target.py <args> (one pass per counter group; "
+               "per-launch means over the %d target launches between the marker launches)" % (tag, n_launch),
     "counters_per_launch": out,
     "fetch_size_calibration": {"known_bytes": known, "FETCH_SIZE_KB": cal, "factor": factor,
                                "pattern": "distance_kernel streaming 3e6 x 384-B rows once with the search kernel's row-group loads (4 lanes x 16 B)"},
     "hbm_read_bytes_per_launch": out["FETCH_SIZE"] * 1024 * round(factor),
     "hbm_write_bytes_per_launch": out["WRITE_SIZE"] * 1024,
     "l2_hit_rate": out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"]),
-}
+    "fetch_requests_per_launch": out["FETCH_SIZE"] * 1024 / 64,
+})
 s["traffic_bytes_per_launch"] = s["hbm_read_bytes_per_launch"] + s["hbm_write_bytes_per_launch"]
-json.dump(s, open(f"profiles/{rnd}_pmc.json", "w"), indent=1)
-print(json.dumps(s, indent=1))
+s["traffic_over_designed"] = s["traffic_bytes_per_launch"] / s["designed_bytes_per_launch"]
+if "SQ_WAVE_CYCLES" in out:
+    s["sq"] = {"wait_any_frac": out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"], "active_inst_frac": out["SQ_ACTIVE_INST_ANY"] / out["SQ_WAVE_CYCLES"],
+               "valu_per_query": out["SQ_INSTS_VALU"] / out["SQ_WAVES"], "salu_per_query": out["SQ_INSTS_SALU"] / out["SQ_WAVES"], "lds_per_query": out["SQ_INSTS_LDS"] / out["SQ_WAVES"],
+               "wave_quad_cycles_per_query": out["SQ_WAVE_CYCLES"] / out["SQ_WAVES"]}
 for f in glob.glob(f"{base}/trace/*kernel_trace.csv"):
     rows = [r for r in csv.DictReader(open(f)) if "search_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[:24]]  # 1 stats + 3 warmup + 20 timed, all window 128
-    s["kernel_trace_window128"] = {"launches": len(dur), "avg_ms": statistics.mean(dur) / 1e6, "min_ms": min(dur) / 1e6, "max_ms": max(dur) / 1e6,
-                                   "note": "rocprofv3 --kernel-trace --stats of the default bench command; the first 24 search_kernel launches = the window-128 ones (stats pass + 3 warmup + 20 timed); later launches are the calibration / matched-recall windows"}
-    json.dump(s, open(f"profiles/{rnd}_pmc.json", "w"), indent=1)
-    print(s["kernel_trace_window128"])
+    marks = [i for i, r in enumerate(rows) if int(r.get("Grid_Size", r.get("Grid_Size_X"))) == 64 * 64]
+    sel = rows[marks[0] + 1 : marks[1]][:n_launch]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
+    s["kernel_trace"] = {"launches": len(dur), "avg_ms": statistics.mean(dur) / 1e6, "min_ms": min(dur) / 1e6, "max_ms": max(dur) / 1e6,
+                         "vgpr": sel[0].get("VGPR_Count"), "sgpr": sel[0].get("SGPR_Count"), "lds": sel[0].get("LDS_Block_Size"),
+                         "note": "rocprofv3 --kernel-trace --stats of the same command, the target launches only"}
+    ms = s["kernel_trace"]["avg_ms"]
+    s["traffic_rate_GBs"] = s["traffic_bytes_per_launch"] / ms / 1e6
+    s["frac_traffic_of_8TBs"] = s["traffic_rate_GBs"] / 8000
+    s["designed_rate_GBs"] = s["designed_bytes_per_launch"] / ms / 1e6
+    s["fetch_request_rate_G_per_s"] = s["fetch_requests_per_launch"] / ms / 1e6
+os.makedirs("profiles", exist_ok=True)
+json.dump(s, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+print(json.dumps({k: s[k] for k in s if k not in ("counters_per_launch", "command")}, indent=1))
 for f in glob.glob(f"{base}/trace/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
-    with open(f"profiles/{rnd}_bench_kernel_stats.csv", "w") as o:
-        o.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --graph-cache /tmp/g1m.pt --no-cpu-baseline ({rnd}); top 15 kernels\n")
+    with open(f"profiles/{tag}_kernel_stats.csv", "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python tools/pmc_target.py ... ({tag}); top 12 kernels\n")
         w = csv.writer(o)
         w.writerow(rows[0].keys())
-        for r in rows[:15]:
+        for r in rows[:12]:
             w.writerow(r.values())
