@@ -780,6 +780,58 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
     return true;
 }
 
+// Batched form of insert_inner for one distance pass: every lane with `cand` holds one candidate (dist, id) -- lanes in
+// ascending order = adjacency order -- and all of them are merged into the sorted buffer at once.  Equal to inserting them one
+// after the other (search_buffer.h:342-403), because a sequence of bounded sorted inserts IS a stable merge truncated to the
+// capacity: old entries keep their order and come before new entries of equal distance (upper-bound position), new entries of
+// equal distance keep adjacency order, whatever ends at position >= capacity is dropped (a candidate that loses against a
+// `worst` that improved inside the pass would have been dropped, or pushed out, anyway), and best_unvisited = min(old, position
+// of the best new entry), which is the smallest position any of the sequential inserts reports.
+// Preconditions: capacity <= 128 (two entries per lane), no NaN distance in the buffer or among the candidates (comparisons must
+// be a strict weak order).  Returns false -- with LDS untouched -- if a candidate duplicates a buffer entry (same id at equal
+// distance, search_buffer.h:377-389); the caller then takes the sequential path for this pass.
+template <bool GREATER>
+__device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted) {
+    const uint32_t i0 = lane, i1 = lane + 64u;
+    const bool v0 = i0 < b.size, v1 = i1 < b.size;
+    uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
+    if (v0) e0 = b.e[i0];
+    if (v1) e1 = b.e[i1];
+    const float d0 = __uint_as_float(e0.x), d1 = __uint_as_float(e1.x);
+    const uint32_t id0 = e0.y & kIdMask, id1 = e1.y & kIdMask;
+    uint32_t c0 = 0, c1 = 0, rank = 0, oldle = 0, minpos = 0xFFFFFFFFu;
+    bool dup = false;
+    unsigned long long m = __ballot(cand);
+    const uint32_t ncand = static_cast<uint32_t>(__popcll(m));
+    while (m != 0ull) {
+        const int bl = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
+        const uint32_t idj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id), bl));
+        const bool lt0 = v0 && cmpf<GREATER>(dj, d0); // candidate j goes before this old entry
+        const bool lt1 = v1 && cmpf<GREATER>(dj, d1);
+        c0 += lt0 ? 1u : 0u;
+        c1 += lt1 ? 1u : 0u;
+        const uint32_t le = b.size - static_cast<uint32_t>(__popcll(__ballot(lt0)) + __popcll(__ballot(lt1))); // old entries that stay before j
+        dup = dup || (v0 && d0 == dj && id0 == idj) || (v1 && d1 == dj && id1 == idj);
+        rank += (cmpf<GREATER>(dj, dist) || (dj == dist && static_cast<uint32_t>(bl) < lane)) ? 1u : 0u; // new entries before mine
+        oldle = lane == static_cast<uint32_t>(bl) ? le : oldle;
+        minpos = le < minpos ? le : minpos;
+    }
+    if (__ballot(dup) != 0ull) return false;
+    lds_order();
+    const uint32_t p0 = i0 + c0, p1 = i1 + c1, pn = oldle + rank;
+    if (v0 && c0 != 0u && p0 < b.capacity) b.e[p0] = e0;
+    if (v1 && c1 != 0u && p1 < b.capacity) b.e[p1] = e1;
+    const bool placed = cand && pn < b.capacity;
+    if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
+    lds_order();
+    n_inserted += static_cast<uint32_t>(__popcll(__ballot(placed)));
+    b.size = (b.size + ncand < b.capacity) ? b.size + ncand : b.capacity;
+    b.best_unvisited = minpos < b.best_unvisited ? minpos : b.best_unvisited;
+    return true;
+}
+
 // SearchBuffer::next (search_buffer.h:294-304): returns the node id, marks it visited, advances best_unvisited.
 __device__ __forceinline__ uint32_t wave_next(WaveBuffer& b, uint32_t lane, float& node_dist) {
     const uint2 en = b.e[b.best_unvisited];

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     };
 
     uint32_t n_exp = 0, n_slots = 0, n_eval = 0, n_ins = 0;
+    [[maybe_unused]] bool nan_seen = false; // a NaN distance reached the buffer: comparisons stop being an order, inserts go one by one
 
     // ---- EntryPointInitializer: distances to the entry points, push_back, sort --------------------------------
     // (push_back + sort == ordered insert for <= 16 entry points, where std::sort is a stable insertion sort; the
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
                 const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
                 ++n_eval;
+                nan_seen = nan_seen || dd != dd;
                 if (buf.size < buf.capacity) {
                     // EntryPointInitializer never touches the visited set (greedy_search.h:69-90); marking an entry point that was
                     // really pushed is result-neutral (re-encountering it would be a duplicate), one that push_back dropped is not
@@ -505,8 +507,21 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 const bool act = ci < cnt;
                 const float dist = group_distance(cid, act, full ? worst * 1.00004f : __builtin_inff());
                 const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
-                unsigned long long m = __ballot(act && sub == 0 && !skip);
+                const bool cand = act && sub == 0 && !skip;
+                unsigned long long m = __ballot(cand);
                 n_eval += (cnt - p0) < static_cast<uint32_t>(RPP) ? (cnt - p0) : static_cast<uint32_t>(RPP);
+                if constexpr (!GENERAL) {
+                    // all accepted candidates of the pass in ONE merge (wave_merge_insert); NaN distances and duplicates of buffer
+                    // entries (possible when the visited filter is off or evicted) take the one-by-one path below
+                    if (m != 0ull && buf.capacity <= 128u) {
+                        nan_seen = nan_seen || (__ballot(cand && dist != dist) != 0ull);
+                        if (!nan_seen && wave_merge_insert<GREATER>(buf, cand, dist, cid, lane, n_ins)) {
+                            m = 0ull;
+                            full = buf.size == buf.capacity;
+                            if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
+                        }
+                    }
+                }
                 while (m != 0ull) {
                     const int bl = __builtin_ctzll(m);
                     m &= m - 1ull;
