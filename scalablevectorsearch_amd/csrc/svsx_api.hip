@@ -554,6 +554,7 @@ static void default_filter(const svsx_index* ix, SearchArgs& a, uint32_t fe) {
     while (fe <= 16384 && (ix->n >> __builtin_ctz(fe)) >= 0xFFFFu) fe <<= 1;
     a.filter_entries = fe <= 16384 ? fe : 0;
     a.filter_tag8 = (a.filter_entries && (ix->n >> __builtin_ctz(a.filter_entries)) < 0xFFu) ? 1u : 0u;
+    if (a.fat != nullptr) a.filter_tag8 = 0; // the inline-record kernel keeps only fetched rows in the filter: 16-bit tags, no variant
 }
 
 static int search_common(
@@ -587,7 +588,7 @@ static int search_common(
         if (params->visited_set == 1) {
             // default: 4 KB of LDS per wave (the measured optimum): 4096 entries with 8-bit tags when they identify the
             // id exactly ((n >> 12) < 255), else 2048 entries with 16-bit tags
-            fe = (ix->n >> 12) < 0xFFu ? 4096u : kDefaultFilterEntries;
+            fe = ((ix->n >> 12) < 0xFFu && !ix->d_fat) ? 4096u : kDefaultFilterEntries;
         } else {
             fe = static_cast<uint32_t>(params->visited_set);
             if (fe < 64) fe = 64;

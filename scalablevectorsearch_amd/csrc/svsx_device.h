@@ -149,8 +149,15 @@ __device__ __forceinline__ void float_row_distance(
     bool rejected = false;
 
     auto fetch = [&](int block, float (&x)[E]) {
-        zero_chunk<E>(x);
-        if (active) load_chunk<DT>(lane_row + block * (16 * Elem<DT>::BYTES), x);
+        // callers point inactive groups at row 0 (always mapped, cache resident), so the load needs no predicate -- an exec-masked
+        // load costs three scalar instructions, and the scalar unit is this kernel's scarce issue port; only the PRUNE form
+        // really stops fetching
+        if constexpr (PRUNE) {
+            zero_chunk<E>(x);
+            if (active) load_chunk<DT>(lane_row + block * (16 * Elem<DT>::BYTES), x);
+        } else {
+            load_chunk<DT>(lane_row + block * (16 * Elem<DT>::BYTES), x);
+        }
         if constexpr (DECOMP) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -395,10 +402,7 @@ __device__ __forceinline__ void float_row_distance_bc(
     auto load_block = [&](int c) -> BlockRaw<DT> {
         BlockRaw<DT> raw;
 #pragma unroll
-        for (int i = 0; i < BB / 16; ++i) {
-            raw.v[i] = make_uint4(0, 0, 0, 0);
-            if (active) raw.v[i] = *reinterpret_cast<const uint4*>(row + BB * c + 16 * i);
-        }
+        for (int i = 0; i < BB / 16; ++i) raw.v[i] = *reinterpret_cast<const uint4*>(row + BB * c + 16 * i); // inactive groups read row 0
         return raw;
     };
     auto accumulate = [&](int c, const BlockRaw<DT>& raw, int nvalid) {
@@ -548,16 +552,12 @@ __device__ __forceinline__ void int_row_sums(
     for (; m + 12 < nch; m += 16) { // four 16-B loads in flight per lane
         uint4 x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[i] = make_uint4(0, 0, 0, 0);
-            if (active) x[i] = *reinterpret_cast<const uint4*>(row + 16 * (m + 4 * i));
-        }
+        for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const uint4*>(row + 16 * (m + 4 * i)); // inactive groups read row 0
 #pragma unroll
         for (int i = 0; i < 4; ++i) dots(x[i], *reinterpret_cast<const uint4*>(qw + 4 * (m + 4 * i)));
     }
     for (; m < nch; m += 4) {
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (active) x = *reinterpret_cast<const uint4*>(row + 16 * m);
+        const uint4 x = *reinterpret_cast<const uint4*>(row + 16 * m);
         dots(x, *reinterpret_cast<const uint4*>(qw + 4 * m));
     }
     sab += xor1i(sab);
@@ -787,38 +787,51 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
 // equal distance keep adjacency order, whatever ends at position >= capacity is dropped (a candidate that loses against a
 // `worst` that improved inside the pass would have been dropped, or pushed out, anyway), and best_unvisited = min(old, position
 // of the best new entry), which is the smallest position any of the sequential inserts reports.
-// Preconditions: capacity <= 128 (two entries per lane), no NaN distance in the buffer or among the candidates (comparisons must
-// be a strict weak order).  Returns false -- with LDS untouched -- if a candidate duplicates a buffer entry (same id at equal
+// Preconditions: capacity <= 128 (two entries per lane), no NaN distance in the buffer, candidate distances finite (empty slots
+// are modelled as +-inf sentinels; comparisons must be a strict weak order).  Returns false -- with LDS untouched -- if a candidate duplicates a buffer entry (same id at equal
 // distance, search_buffer.h:377-389); the caller then takes the sequential path for this pass.
 template <bool GREATER>
 __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted) {
+    // Written to stay off the scalar unit (one SALU issue slot per CU per cycle is the scarce resource of this kernel): no
+    // boolean mask algebra -- validity is folded into sentinel values, counters advance with carry-in adds, the tie rule of
+    // the candidate ranks is one 64-bit compare of (order key, lane).
     const uint32_t i0 = lane, i1 = lane + 64u;
     const bool v0 = i0 < b.size, v1 = i1 < b.size;
-    uint2 e0 = make_uint2(0, 0), e1 = make_uint2(0, 0);
+    constexpr float kPast = GREATER ? -__builtin_inff() : __builtin_inff(); // no candidate compares better than an empty slot
+    uint2 e0 = make_uint2(__float_as_uint(kPast), kInvalidId), e1 = e0;
     if (v0) e0 = b.e[i0];
     if (v1) e1 = b.e[i1];
     const float d0 = __uint_as_float(e0.x), d1 = __uint_as_float(e1.x);
-    const uint32_t id0 = e0.y & kIdMask, id1 = e1.y & kIdMask;
-    uint32_t c0 = 0, c1 = 0, rank = 0, oldle = 0, minpos = 0xFFFFFFFFu;
-    bool dup = false;
+    const uint32_t id0 = e0.y & kIdMask, id1 = e1.y & kIdMask; // kInvalidId & kIdMask is no valid id either (ids < 2^31 - 1)
+    // total-order key of my own distance (+0.0 first: -0 and +0 compare equal as floats), ascending = better first
+    const uint32_t fb = __float_as_uint(dist + 0.0f);
+    uint32_t key = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+    if (GREATER) key = ~key;
+    const unsigned long long mykey = (static_cast<unsigned long long>(key) << 32) | lane;
+    uint32_t c0 = 0, c1 = 0, rank = 0, oldle = 0, minpos = 0xFFFFFFFFu, dupacc = 0xFFFFFFFFu;
     unsigned long long m = __ballot(cand);
     const uint32_t ncand = static_cast<uint32_t>(__popcll(m));
     while (m != 0ull) {
         const int bl = __builtin_ctzll(m);
-        m &= m - 1ull;
+        m &= ~(1ull << bl);
         const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
         const uint32_t idj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id), bl));
-        const bool lt0 = v0 && cmpf<GREATER>(dj, d0); // candidate j goes before this old entry
-        const bool lt1 = v1 && cmpf<GREATER>(dj, d1);
+        const uint32_t kj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), bl));
+        const bool lt0 = cmpf<GREATER>(dj, d0), lt1 = cmpf<GREATER>(dj, d1); // candidate j goes before these old entries (a suffix: sorted)
+        const unsigned long long b0 = __ballot(lt0), b1 = __ballot(lt1);
         c0 += lt0 ? 1u : 0u;
         c1 += lt1 ? 1u : 0u;
-        const uint32_t le = b.size - static_cast<uint32_t>(__popcll(__ballot(lt0)) + __popcll(__ballot(lt1))); // old entries that stay before j
-        dup = dup || (v0 && d0 == dj && id0 == idj) || (v1 && d1 == dj && id1 == idj);
-        rank += (cmpf<GREATER>(dj, dist) || (dj == dist && static_cast<uint32_t>(bl) < lane)) ? 1u : 0u; // new entries before mine
+        // old entries that stay before j; empty slots always count as "after", so they are subtracted again
+        const uint32_t le = 128u - static_cast<uint32_t>(__popcll(b0) + __popcll(b1));
+        const uint32_t x0 = id0 ^ idj, x1 = id1 ^ idj;
+        dupacc = x0 < dupacc ? x0 : dupacc;
+        dupacc = x1 < dupacc ? x1 : dupacc;
+        const unsigned long long kjl = (static_cast<unsigned long long>(kj) << 32) | static_cast<uint32_t>(bl);
+        rank += kjl < mykey ? 1u : 0u; // new entries before mine: better, or equal and earlier in adjacency order
         oldle = lane == static_cast<uint32_t>(bl) ? le : oldle;
         minpos = le < minpos ? le : minpos;
     }
-    if (__ballot(dup) != 0ull) return false;
+    if (__ballot(dupacc == 0u) != 0ull) return false;
     lds_order();
     const uint32_t p0 = i0 + c0, p1 = i1 + c1, pn = oldle + rank;
     if (v0 && c0 != 0u && p0 < b.capacity) b.e[p0] = e0;

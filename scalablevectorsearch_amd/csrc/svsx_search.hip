@@ -366,8 +366,8 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 // bound rejected is rejected again by the bound (worst only improves) at no memory cost, so it need not be
                 // remembered -- the same table then covers the whole query almost without evictions.  A hit = this id went
                 // through the exact path earlier in this query, re-inserting it would be a no-op.
-                const uint32_t fh = nid & fmask, ftag = nid >> fshift;
-                if (a.filter_entries != 0u && keep) keep = (tag8 ? static_cast<uint32_t>(filt8[fh]) : static_cast<uint32_t>(filt[fh])) != ftag;
+                const uint32_t fh = nid & fmask, ftag = nid >> fshift; // 16-bit tags only (the host never asks for 8-bit tags with inline records)
+                if (a.filter_entries != 0u && keep) keep = static_cast<uint32_t>(filt[fh]) != ftag;
                 if (full) {
                     // lower bound of every candidate of this chunk, lane-parallel.  With A = max(0, s sqrt(I) - e), e = eq + ex, and
                     // B = max(0, | ||u_T|| - ||y_T|| | - slack):  (1 + eps) dist >= A^2 + B^2.  Reject iff A^2 + B^2 > W' := worst (1 + eps) 1.0001,
@@ -396,10 +396,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                     n_eval += nrej;
                     keep = keep && !rej;
                 }
-                if (a.filter_entries != 0u && keep) {
-                    if (tag8) filt8[fh] = static_cast<uint8_t>(ftag);
-                    else filt[fh] = static_cast<uint16_t>(ftag);
-                }
+                if (a.filter_entries != 0u && keep) filt[fh] = static_cast<uint16_t>(ftag);
                 const unsigned long long km = __ballot(keep);
                 cnt = __popcll(km);
                 const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
@@ -515,7 +512,8 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                     // entries (possible when the visited filter is off or evicted) take the one-by-one path below
                     if (m != 0ull && buf.capacity <= 128u) {
                         nan_seen = nan_seen || (__ballot(cand && dist != dist) != 0ull);
-                        if (!nan_seen && wave_merge_insert<GREATER>(buf, cand, dist, cid, lane, n_ins)) {
+                        const bool finite = __ballot(cand && !(__builtin_fabsf(dist) < __builtin_inff())) == 0ull;
+                        if (!nan_seen && finite && wave_merge_insert<GREATER>(buf, cand, dist, cid, lane, n_ins)) {
                             m = 0ull;
                             full = buf.size == buf.capacity;
                             if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
