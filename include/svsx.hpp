@@ -13,12 +13,15 @@
 
 #include "svsx.h"
 
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <functional>
 #include <limits>
 #include <span>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace svsx {
@@ -111,16 +114,36 @@ template <typename T, typename Dist> class VamanaIndex {
     VamanaSearchParameters get_search_parameters() const { return defaults_; }
     void set_search_parameters(const VamanaSearchParameters& p) { defaults_ = p; }
 
-    // index/vamana/index.h:564-611.  `cancel` is polled once before the batch is enqueued (host-side only).
+    // index/vamana/index.h:564-611.  Without a predicate the batch is simply enqueued.  With one, `cancel` (thread-safe by the
+    // reference's contract, index.h:541-545) is polled from a helper thread while the batch runs; once it returns true the
+    // library raises the device word the kernel polls at every hop (greedy_search.h:155) and the call returns early.
     template <typename Q>
-    void search(QueryResultView<size_t> result, const Q* queries, const VamanaSearchParameters& sp,
-                const std::function<bool()>& cancel = [] { return false; }) const {
-        if (cancel()) return;
+    void search(QueryResultView<size_t> result, const Q* queries, const VamanaSearchParameters& sp) const {
         svsx_search_params p{sp.buffer_config_.get_search_window_size(), sp.buffer_config_.get_total_capacity(),
                              sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
         static_assert(sizeof(size_t) == sizeof(uint64_t));
         check(svsx_search(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), &p,
                           reinterpret_cast<uint64_t*>(result.indices), nullptr, result.distances, nullptr));
+    }
+    template <typename Q>
+    void search(QueryResultView<size_t> result, const Q* queries, const VamanaSearchParameters& sp, const std::function<bool()>& cancel) const {
+        if (cancel()) return; // extensions.h:575-578: nothing starts
+        svsx_search_params p{sp.buffer_config_.get_search_window_size(), sp.buffer_config_.get_total_capacity(),
+                             sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
+        std::atomic<int> flag{0}, finished{0};
+        svsx_search_aux aux{};
+        aux.cancel_flag = reinterpret_cast<const volatile int*>(&flag);
+        std::thread poller([&] {
+            while (!finished.load(std::memory_order_acquire)) {
+                if (cancel()) { flag.store(1, std::memory_order_release); return; }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        });
+        const int rc = svsx_search(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), &p,
+                                   reinterpret_cast<uint64_t*>(result.indices), nullptr, result.distances, &aux);
+        finished.store(1, std::memory_order_release);
+        poller.join();
+        check(rc);
     }
     template <typename Q> QueryResult<size_t> search(const Q* queries, size_t nq, size_t k) const {
         QueryResult<size_t> r(nq, k);

@@ -9,7 +9,9 @@
 #include "svsx_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -607,6 +609,7 @@ static int search_common(
         a.history_dists = aux->history_dists;
         a.history_len = aux->history_len;
         a.history_cap = static_cast<uint32_t>(aux->history_cap);
+        a.cancel = const_cast<const int*>(aux->cancel_flag); // device word here (svsx_search mirrors the caller's host word into one)
     }
     hipError_t e = launch_search(ix->data_dtype, ix->metric, qmode, a, stream);
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "search kernel launch failed: %s", hipGetErrorString(e));
@@ -666,6 +669,14 @@ int svsx_search(
         if (aux->history_dists && aux->history_cap) { HIP_TRY(dhd.alloc(nq * aux->history_cap * 4, cs.s)); daux.history_dists = static_cast<float*>(dhd.p); }
         if (aux->history_len) { HIP_TRY(dhl.alloc(nq * 4, cs.s)); daux.history_len = static_cast<uint32_t*>(dhl.p); }
     }
+    StreamBuffer dcancel;
+    const volatile int* host_cancel = aux ? aux->cancel_flag : nullptr;
+    if (host_cancel) {
+        HIP_TRY(dcancel.alloc(4, cs.s));
+        HIP_TRY(hipMemsetAsync(dcancel.p, 0, 4, cs.s));
+        if (*host_cancel) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dcancel.p), 1, 1, cs.s)); // already requested: no query starts
+        daux.cancel_flag = static_cast<const volatile int*>(dcancel.p);
+    }
     if (int rc = search_common(ix, dq.p, q_dtype, nq, k, params, static_cast<uint64_t*>(d64.p), static_cast<uint32_t*>(d32.p), static_cast<float*>(dd.p), &daux, cs.s))
         return rc;
     if (ids64) HIP_TRY(hipMemcpyAsync(ids64, d64.p, nq * k * 8, hipMemcpyDeviceToHost, cs.s));
@@ -676,6 +687,22 @@ int svsx_search(
         if (daux.history_ids) HIP_TRY(hipMemcpyAsync(aux->history_ids, dhi.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost, cs.s));
         if (daux.history_dists) HIP_TRY(hipMemcpyAsync(aux->history_dists, dhd.p, nq * aux->history_cap * 4, hipMemcpyDeviceToHost, cs.s));
         if (aux->history_len) HIP_TRY(hipMemcpyAsync(aux->history_len, dhl.p, nq * 4, hipMemcpyDeviceToHost, cs.s));
+    }
+    if (host_cancel) {
+        // `cancel` of VamanaIndex::search (index.h:541-545): the caller may raise its word from any thread while the batch runs.
+        // Poll it while the stream drains and forward it ONCE through a second stream (a one-thread kernel doing an agent-scope
+        // store); the search kernel polls the device word once per hop with an agent-scope load.
+        CallStream side;
+        bool raised = *host_cancel != 0;
+        while (hipStreamQuery(cs.s) == hipErrorNotReady) {
+            if (!raised && *host_cancel != 0) {
+                raised = true;
+                if (!side.s) HIP_TRY(side.create());
+                HIP_TRY(launch_set_word(static_cast<int*>(dcancel.p), 1, side.s));
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        if (side.s) HIP_TRY(hipStreamSynchronize(side.s));
     }
     HIP_TRY(hipStreamSynchronize(cs.s));
     return SVSX_SUCCESS;
@@ -722,7 +749,7 @@ int svsx_flat_search_device(
 ) {
     if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k, false)) return rc;
     if (nq == 0) return SVSX_SUCCESS;
-    if (k > 128) return fail(SVSX_INVALID_ARGUMENT, "flat search supports k <= 128");
+    if (k > 96) return fail(SVSX_INVALID_ARGUMENT, "flat search supports k <= 96 (the float16 shortlist keeps min(128, max(4k, k + 32)) candidates: at least 32 spare ranks for float16 rounding)");
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
     HIP_TRY(hipSetDevice(ix->device));

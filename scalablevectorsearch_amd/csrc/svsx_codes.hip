@@ -175,6 +175,13 @@ __global__ __launch_bounds__(64) void fat_build_kernel(const uint32_t* __restric
     }
 }
 
+__global__ void set_word_kernel(int* w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+hipError_t launch_set_word(int* d_word, int value, hipStream_t stream) {
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, stream, d_word, value);
+    return hipGetLastError();
+}
+
 float pca_key_to_float(uint32_t k) {
     const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
     float f;

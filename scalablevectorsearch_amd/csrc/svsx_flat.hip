@@ -12,7 +12,7 @@
 //   3. rerank_kernel      recomputes the shortlisted distances with the SAME exact-order routines as the graph search
 //                         (bit-identical to the reference's distance kernels) and emits the k best by
 //                         (distance, then id).
-// The f16 stage is only a filter (kk = max(4k, k+32) <= 128), so the final ids/distances do not depend on f16
+// The f16 stage is only a filter (kk = min(128, max(4k, k+32)); the host limits k to 96 so that kk >= k + 32), so the final ids/distances do not depend on f16
 // rounding unless a true neighbour is pushed out of the shortlist, which needs an f16 error larger than the gap to
 // the kk-th candidate.  Values must fit float16 (|x| < 65504).
 #include "svsx_device.h"

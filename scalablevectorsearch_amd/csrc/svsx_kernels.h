@@ -186,6 +186,7 @@ hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream);
 hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream);
 hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, void* d_fat, size_t fat_stride, hipStream_t stream);
 float pca_key_to_float(uint32_t key);
+hipError_t launch_set_word(int* d_word, int value, hipStream_t stream); // one agent-scope store (cancellation)
 // name of the search_kernel instantiation launch_search picked last on this thread (tests assert which one ran)
 const char* last_search_instantiation();
 

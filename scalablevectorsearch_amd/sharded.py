@@ -93,6 +93,32 @@ class ShardedSearcher:
         return self.merge(self.metric, all_d, all_i, k)
 
 
+class MultiShardSearcher(ShardedSearcher):
+    """Fixed-shard-count form ("each GPU holds 8/G shards"): this rank owns SEVERAL shards -- contiguous shard
+    ids, shard `rank * len(local_searches) + s` -- searches them one after the other, merges their lists locally (ties ->
+    lower shard, then position: the same rule, so merging local shards first and ranks second equals one global merge over
+    all shards in shard order), and ships ONE packed list through the same single all-gather as ShardedSearcher.
+
+    local_searches: one callable per local shard, each `(queries, k) -> (dists [nq,k], GLOBAL ids [nq,k])`."""
+
+    def __init__(self, local_searches, distance, group=None, merge=hip_merge):
+        import torch
+
+        self.local_searches = list(local_searches)
+
+        def local(queries, k):
+            parts = [f(queries, k) for f in self.local_searches]
+            if len(parts) == 1:
+                return parts[0]
+            return self.merge(self.metric, torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+
+        super().__init__(local, distance, group=group, merge=merge)
+
+    @property
+    def shards_total(self) -> int:
+        return self.world * len(self.local_searches)
+
+
 class PipelinedShardSearch:
     """Throughput form of the sharded search for a stream of equally shaped query batches: the gather + merge leg of batch i
     (latency-bound: one small collective, one small kernel) runs on a second stream while the search kernel of batch i+1

@@ -24,6 +24,14 @@ int main(int argc, char**) {
         index.search(result.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}));
         std::printf("%zu %zu %zu\n", result.index(0, 0), result.index(0, 1), result.index(0, 2));
         if (!(result.index(0, 0) == 5 && result.index(0, 1) == 6 && result.index(0, 2) == 4)) return 1;
+        // the cancel predicate of VamanaIndex::search (index.h:564-570): false -> same answer; true -> nothing is written
+        svsx::QueryResult<size_t> r2(1, 3);
+        index.search(r2.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}), [] { return false; });
+        if (!(r2.index(0, 0) == 5 && r2.index(0, 1) == 6 && r2.index(0, 2) == 4)) return 7;
+        svsx::QueryResult<size_t> r3(1, 3);
+        r3.view().indices[0] = 12345;
+        index.search(r3.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}), [] { return true; });
+        if (r3.index(0, 0) != 12345) return 8;
         // BatchIterator: 8 points on a ring, batches of 3 -> 5 6 4 | 7 3 2 | 1 0 | (done)
         svsx::BatchIterator<float> it(index, q.data(), 1);
         const size_t want[8] = {5, 6, 4, 7, 3, 2, 1, 0};

@@ -203,3 +203,67 @@ def test_config2_full_size_ids_identical_to_reference(svs, ref):
             torch.cuda.synchronize()
             assert (ids.cpu().numpy() == rid.astype(np.int64)).all(), (window, mode)
             assert (_bits(dist.cpu().numpy()) == _bits(rd)).all(), (window, mode)
+
+
+# ---- cancellation (index/vamana/index.h:541-545,564-570; greedy_search.h:155; extensions.h:575-578) ---------------------------------
+def test_cancel_flag_device_and_host(svs, oracle, small_world):
+    import ctypes as C
+    import threading
+    import time
+
+    import torch
+
+    from scalablevectorsearch_amd import _lib
+
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    L = _lib.lib()
+    nq, k = 64, 10
+    q = torch.from_numpy(sw["q"]).cuda()
+    ids = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+    dist = torch.full((nq, k), -7.0, dtype=torch.float32, device="cuda")
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(32))._c()
+    want, _ = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], k, 32)
+
+    def run(flag_value):
+        flag = torch.tensor([flag_value], dtype=torch.int32, device="cuda")
+        aux = _lib.SearchAux()
+        aux.cancel_flag = flag.data_ptr()
+        ids.fill_(-7)
+        _lib.check(L.svsx_search_device(idx._h, q.data_ptr(), 0, nq, k, C.byref(sp), ids.data_ptr(), None, dist.data_ptr(), C.byref(aux),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        return ids.cpu().numpy()
+
+    assert (run(0) == want.astype(np.int64)).all()         # a lowered flag changes nothing
+    assert (run(1) == -7).all()                            # raised before the launch: no query starts, rows stay untouched
+    # host entry point: the caller's HOST word, raised up front and raised from another thread mid-flight
+    big = np.tile(sw["q"], (400, 1))                      # 25 600 queries at window 256: a few milliseconds of work
+    flag = C.c_int(1)
+    aux = _lib.SearchAux()
+    aux.cancel_flag = C.addressof(flag)
+    hid = np.full((big.shape[0], k), 7, np.uint64)
+    hd = np.zeros((big.shape[0], k), np.float32)
+    spb = svs.VamanaSearchParameters(svs.SearchBufferConfig(256))._c()
+    _lib.check(L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux)))
+    full, _ = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], k, 256)
+    full = np.tile(full.astype(np.uint64), (400, 1))
+    assert not (hid == full).all()                         # cancelled before anything ran
+    flag.value = 0
+    t = threading.Thread(target=lambda: (time.sleep(0.0005), setattr(flag, "value", 1)))
+    t.start()
+    rc = L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux))
+    t.join()
+    assert rc == 0                                         # cancellation is not an error (the reference returns normally)
+    flag.value = 0                                         # and a lowered flag gives the full, exact answer again
+    _lib.check(L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux)))
+    assert (hid == full).all()
+
+
+def test_flat_search_k_limit(svs):
+    x = deep_like(500, 32, 8, seed=3)
+    f = svs.FlatIndex(x, svs.DistanceL2())
+    assert f.search(x[:4], 96).indices.shape == (4, 96)
+    with pytest.raises(svs.SvsxError) as e:
+        f.search(x[:4], 97)
+    assert e.value.code == 2 and "k <= 96" in e.value.message

@@ -81,6 +81,65 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
+def _worker_multi(rank, world, port, tmp):
+    """config 5 shape in small: 4 shards over 2 ranks (2 per rank), local merge -> one all-gather -> global merge, against a
+    single-process merge over all 4 shards in shard order; ids offset beyond 2^32."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import deep_like
+        from oracle.oracle import L2, Oracle, merge_topk_ref
+
+        import scalablevectorsearch_amd as svs
+        from scalablevectorsearch_amd.sharded import MultiShardSearcher
+
+        o = Oracle()
+        S, per, d, nq, k = 4, 400, 32, 16, 5
+        base = (1 << 32) + 77
+        q = deep_like(nq, d, 8, seed=12)
+        q[3] = q[2]  # identical queries -> identical rows
+        shards = []
+        for sid in range(S):
+            xs = deep_like(per, d, 8, seed=100 + sid)
+            if sid == 2:
+                xs[:50] = deep_like(per, d, 8, seed=100)[:50]  # duplicates of shard 0 vectors: exact distance ties across shards
+            g, e = o.build_vamana(L2, xs, R=16, L=24)
+            shards.append((xs, g, e))
+
+        def make(sid):
+            xs, g, e = shards[sid]
+
+            def f(queries, kk):
+                ids, dists = o.search(L2, xs, g, e, queries.numpy(), kk, 24)
+                return torch.from_numpy(dists), torch.from_numpy(np.where(ids == 0xFFFFFFFF, -1, ids.astype(np.int64) + sid * base))
+
+            return f
+
+        def merge(metric, gd, gi, kk):
+            a, b = merge_topk_ref(metric, gd.numpy(), gi.numpy(), kk)
+            return torch.from_numpy(a), torch.from_numpy(b)
+
+        local = [make(rank * 2), make(rank * 2 + 1)]
+        s = MultiShardSearcher(local, svs.DistanceL2(), merge=merge)
+        assert s.shards_total == S
+        dd, ii = s.search(torch.from_numpy(q), k)
+        parts = [make(sid)(torch.from_numpy(q), k) for sid in range(S)]
+        md, mi = merge_topk_ref(L2, np.stack([p[0].numpy() for p in parts]), np.stack([p[1].numpy() for p in parts]), k)
+        assert (mi == ii.numpy()).all() and (md.view(np.uint32) == dd.numpy().view(np.uint32)).all()
+        assert int(ii.max()) > (1 << 32) and (ii[2] == ii[3]).all()
+        open(os.path.join(tmp, f"multi{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_two_shards_each_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_multi, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "multi0") and os.path.exists(tmp_path / "multi1")
+
+
 def test_two_rank_sharded_search_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
