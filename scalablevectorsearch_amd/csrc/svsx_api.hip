@@ -48,8 +48,8 @@ struct svsx_index {
     // graph-inline records (svsx_index_build_bound_codes mode 2; svsx_codes.hip)
     void* d_fat = nullptr;
     size_t fat_stride = 0;
-    float* d_pca = nullptr;      // [128][dpad] rotation (row-major, zero padded) | [128] mean | [32] bias
-    float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_eps = 0.0f, pca_eq_abs = 0.0f;
+    float* d_pca = nullptr;      // [32][dpad] leading directions (float32, row-major, zero padded) | [dpad] mean | [32] bias
+    float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_delta = 0.0f, pca_eq_abs = 0.0f, pca_ref_extra = 0.0f;
 };
 
 namespace {
@@ -335,33 +335,77 @@ float half_bits_to_float(uint16_t h) {
     return f;
 }
 
-constexpr uint32_t kFatDc = 28;     // coded components per record
-constexpr uint32_t kPcaRows = 128;  // rows of the device copy of the rotation (components; zero rows beyond d)
+constexpr uint32_t kPcaRows = 32;   // rows of the float32 device copy of the directions (rows >= dc are zero)
 
-// graph-inline records: sample -> PCA rotation (host, f64) -> per-vector records (device) -> node rows (device)
+// modified Gram-Schmidt on the m columns of V (d x m, column j at V[i * m + j]); twice for orthogonality to rounding
+void orthonormalize_columns(std::vector<double>& V, uint32_t d, uint32_t m) {
+    for (int rep = 0; rep < 2; ++rep)
+        for (uint32_t j = 0; j < m; ++j) {
+            for (uint32_t k = 0; k < j; ++k) {
+                double dot = 0.0;
+                for (uint32_t i = 0; i < d; ++i) dot += V[static_cast<size_t>(i) * m + j] * V[static_cast<size_t>(i) * m + k];
+                for (uint32_t i = 0; i < d; ++i) V[static_cast<size_t>(i) * m + j] -= dot * V[static_cast<size_t>(i) * m + k];
+            }
+            double nrm = 0.0;
+            for (uint32_t i = 0; i < d; ++i) nrm += V[static_cast<size_t>(i) * m + j] * V[static_cast<size_t>(i) * m + j];
+            nrm = std::sqrt(nrm);
+            if (!(nrm > 1e-300)) { // degenerate direction: replace by a unit vector and let the next repetition clean it up
+                for (uint32_t i = 0; i < d; ++i) V[static_cast<size_t>(i) * m + j] = (i == j % d) ? 1.0 : 0.0;
+                nrm = 1.0;
+            }
+            for (uint32_t i = 0; i < d; ++i) V[static_cast<size_t>(i) * m + j] /= nrm;
+        }
+}
+
+// graph-inline records: sample -> leading principal directions (host, f64) -> per-vector records (device) -> node rows (device)
 int build_fat_rows(svsx_index* ix) {
     const uint32_t d = static_cast<uint32_t>(ix->d), n = static_cast<uint32_t>(ix->n);
     const size_t es = dtype_size(ix->data_dtype);
-    // 1. sample (evenly strided, <= 65536 rows) -> host, f64
-    const size_t ns = n < 65536u ? n : 65536u;
+    const bool l2 = ix->metric == M_L2, cosine = ix->metric == M_COS;
+    const uint32_t dc = l2 ? 28u : 26u;
+    // 1. sample (evenly strided) -> host, the vector the metric sees (decompressed / normalised), f64
+    const size_t want = d <= 128 ? 65536 : (d <= 256 ? 32768 : 8192);
+    const size_t ns = n < want ? n : want;
     const size_t step = n / ns;
     std::vector<unsigned char> raw(ns * d * es);
     HIP_TRY(hipMemcpy2D(raw.data(), d * es, ix->d_data, step * ix->row_bytes, d * es, ns, hipMemcpyDeviceToHost));
     std::vector<double> xs(ns * d);
     for (size_t i = 0; i < ns * d; ++i) {
-        if (ix->data_dtype == DT_F32) xs[i] = reinterpret_cast<const float*>(raw.data())[i];
-        else xs[i] = half_bits_to_float(reinterpret_cast<const uint16_t*>(raw.data())[i]);
+        float f;
+        switch (ix->data_dtype) {
+            case DT_F32: f = reinterpret_cast<const float*>(raw.data())[i]; break;
+            case DT_F16: f = half_bits_to_float(reinterpret_cast<const uint16_t*>(raw.data())[i]); break;
+            case DT_I8: f = static_cast<float>(reinterpret_cast<const int8_t*>(raw.data())[i]); break;
+            default: f = static_cast<float>(raw[i]); break;
+        }
+        if (ix->sq_enabled) {
+            const float t = ix->sq_scale * f;
+            f = t + ix->sq_bias;
+        }
+        xs[i] = f;
         if (!(xs[i] - xs[i] == 0.0)) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
     }
-    std::vector<double> mean(d, 0.0);
-    for (size_t r = 0; r < ns; ++r)
-        for (uint32_t j = 0; j < d; ++j) mean[j] += xs[r * d + j];
-    for (uint32_t j = 0; j < d; ++j) mean[j] /= static_cast<double>(ns);
-    std::vector<float> mean_f(kPcaRows, 0.0f);
-    for (uint32_t j = 0; j < d; ++j) mean_f[j] = static_cast<float>(mean[j]);
-    std::vector<double> cov(static_cast<size_t>(d) * d, 0.0), row(d);
+    if (cosine)
+        for (size_t r = 0; r < ns; ++r) {
+            double nrm = 0.0;
+            for (uint32_t j = 0; j < d; ++j) nrm += xs[r * d + j] * xs[r * d + j];
+            nrm = nrm > 0.0 ? 1.0 / std::sqrt(nrm) : 0.0;
+            for (uint32_t j = 0; j < d; ++j) xs[r * d + j] *= nrm;
+        }
+    const uint32_t pd = (d + 15u) & ~15u;
+    std::vector<float> mean_f(pd, 0.0f);
+    if (l2) {
+        std::vector<double> mean(d, 0.0);
+        for (size_t r = 0; r < ns; ++r)
+            for (uint32_t j = 0; j < d; ++j) mean[j] += xs[r * d + j];
+        for (uint32_t j = 0; j < d; ++j) mean_f[j] = static_cast<float>(mean[j] / static_cast<double>(ns));
+        for (size_t r = 0; r < ns; ++r)
+            for (uint32_t j = 0; j < d; ++j) xs[r * d + j] -= static_cast<double>(mean_f[j]);
+    }
+    // 2. second-moment matrix (upper triangle, then mirrored)
+    std::vector<double> cov(static_cast<size_t>(d) * d, 0.0);
     for (size_t r = 0; r < ns; ++r) {
-        for (uint32_t j = 0; j < d; ++j) row[j] = xs[r * d + j] - static_cast<double>(mean_f[j]);
+        const double* row = &xs[r * d];
         for (uint32_t i = 0; i < d; ++i) {
             const double ri = row[i];
             double* c = &cov[static_cast<size_t>(i) * d];
@@ -374,72 +418,127 @@ int build_fat_rows(svsx_index* ix) {
             cov[static_cast<size_t>(i) * d + j] = v;
             cov[static_cast<size_t>(j) * d + i] = v;
         }
-    // 2. eigenvectors by descending eigenvalue -> P (rows), rounded to float32; eps from the ROUNDED matrix
-    std::vector<double> V;
-    jacobi_eigh(cov, static_cast<int>(d), V);
-    std::vector<uint32_t> order(d);
-    for (uint32_t i = 0; i < d; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cov[static_cast<size_t>(x) * d + x] > cov[static_cast<size_t>(y) * d + y]; });
-    const uint32_t pd = (d + 15u) & ~15u;                      // floats per row of the device copy
-    const size_t p_floats = static_cast<size_t>(kPcaRows) * pd;  // 128 rows: lane i of the search kernel owns rows i, i + 64
-    std::vector<float> host(p_floats + kPcaRows + 32, 0.0f);    // P | mean | bias
-    std::vector<double> P(static_cast<size_t>(d) * d);
-    for (uint32_t i = 0; i < d; ++i)
-        for (uint32_t j = 0; j < d; ++j) {
-            const float f = static_cast<float>(V[static_cast<size_t>(j) * d + order[i]]);
-            host[static_cast<size_t>(i) * pd + j] = f;
-            P[static_cast<size_t>(i) * d + j] = f;
+    // 3. leading directions by subspace iteration + Rayleigh-Ritz (ANY orthonormal set is valid for the bound; a good one
+    //    makes it tight).  m >= dc columns for convergence margin.
+    const uint32_t m = d < 40u ? d : 40u;
+    std::vector<double> V(static_cast<size_t>(d) * m), W(static_cast<size_t>(d) * m);
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    for (auto& v : V) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        v = static_cast<double>(static_cast<int64_t>(lcg >> 11) % 2000001 - 1000000) * 1e-6;
+    }
+    orthonormalize_columns(V, d, m);
+    for (int it = 0; it < 48; ++it) {
+        std::fill(W.begin(), W.end(), 0.0);
+        for (uint32_t i = 0; i < d; ++i) {
+            double* w = &W[static_cast<size_t>(i) * m];
+            const double* c = &cov[static_cast<size_t>(i) * d];
+            for (uint32_t k = 0; k < d; ++k) {
+                const double cik = c[k];
+                const double* v = &V[static_cast<size_t>(k) * m];
+                for (uint32_t j = 0; j < m; ++j) w[j] += cik * v[j];
+            }
         }
-    double fro = 0.0;
+        V.swap(W);
+        orthonormalize_columns(V, d, m);
+    }
+    // Rayleigh-Ritz: T = V^T C V (m x m), eigenvectors Z, V <- V Z ordered by decreasing eigenvalue
+    std::fill(W.begin(), W.end(), 0.0);
     for (uint32_t i = 0; i < d; ++i)
         for (uint32_t k = 0; k < d; ++k) {
-            double g = 0.0;
-            for (uint32_t j = 0; j < d; ++j) g += P[static_cast<size_t>(i) * d + j] * P[static_cast<size_t>(k) * d + j];
-            g -= (i == k) ? 1.0 : 0.0;
-            fro += g * g;
+            const double cik = cov[static_cast<size_t>(i) * d + k];
+            for (uint32_t j = 0; j < m; ++j) W[static_cast<size_t>(i) * m + j] += cik * V[static_cast<size_t>(k) * m + j];
         }
-    const double eps = std::sqrt(fro) * 1.01 + 1e-7;
-    if (!(eps < 1e-3)) return fail(SVSX_RUNTIME_ERROR, "PCA rotation is not orthonormal enough (eps = %g)", eps);
-    for (uint32_t j = 0; j < d; ++j) host[p_floats + j] = mean_f[j];
-    if (!ix->d_pca) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pca), host.size() * sizeof(float)));
+    std::vector<double> T(static_cast<size_t>(m) * m, 0.0), Z;
+    for (uint32_t a = 0; a < m; ++a)
+        for (uint32_t b = 0; b < m; ++b) {
+            double t = 0.0;
+            for (uint32_t i = 0; i < d; ++i) t += V[static_cast<size_t>(i) * m + a] * W[static_cast<size_t>(i) * m + b];
+            T[static_cast<size_t>(a) * m + b] = t;
+        }
+    for (uint32_t a = 0; a < m; ++a)
+        for (uint32_t b = a + 1; b < m; ++b) {
+            const double t = 0.5 * (T[static_cast<size_t>(a) * m + b] + T[static_cast<size_t>(b) * m + a]);
+            T[static_cast<size_t>(a) * m + b] = T[static_cast<size_t>(b) * m + a] = t;
+        }
+    jacobi_eigh(T, static_cast<int>(m), Z);
+    std::vector<uint32_t> order(m);
+    for (uint32_t i = 0; i < m; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return T[static_cast<size_t>(x) * m + x] > T[static_cast<size_t>(y) * m + y]; });
+    const uint32_t dcu = dc < m ? dc : m; // directions really used (d < dc cannot happen: d >= 32)
+    std::vector<double> Q(static_cast<size_t>(d) * dcu), sigma(dcu);
+    for (uint32_t c = 0; c < dcu; ++c) {
+        for (uint32_t i = 0; i < d; ++i) {
+            double v = 0.0;
+            for (uint32_t j = 0; j < m; ++j) v += V[static_cast<size_t>(i) * m + j] * Z[static_cast<size_t>(j) * m + order[c]];
+            Q[static_cast<size_t>(i) * dcu + c] = v;
+        }
+        sigma[c] = std::sqrt(std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0));
+    }
+    orthonormalize_columns(Q, d, dcu);
+    // device copies: float32 rows for the query side (+ delta = how far they are from the f64 directions), f64 rows for the data side
+    std::vector<float> host(static_cast<size_t>(kPcaRows) * pd + pd + 32, 0.0f); // P | mean | bias
+    std::vector<double> q64(static_cast<size_t>(dcu) * d);
+    double delta = 0.0;
+    for (uint32_t c = 0; c < dcu; ++c) {
+        double e2 = 0.0;
+        for (uint32_t j = 0; j < d; ++j) {
+            const double q = Q[static_cast<size_t>(j) * dcu + c];
+            const float f = static_cast<float>(q);
+            host[static_cast<size_t>(c) * pd + j] = f;
+            q64[static_cast<size_t>(c) * d + j] = q;
+            e2 += (static_cast<double>(f) - q) * (static_cast<double>(f) - q);
+        }
+        delta = std::max(delta, std::sqrt(e2));
+    }
+    for (uint32_t j = 0; j < d; ++j) host[static_cast<size_t>(kPcaRows) * pd + j] = mean_f[j];
+    if (ix->d_pca) { (void)hipFree(ix->d_pca); ix->d_pca = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pca), host.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(ix->d_pca, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
-    // 3. per-component range of y over ALL vectors (device), clipped to +-8 sigma; step, biases, tail unit
+    DeviceBuffer dq;
+    HIP_TRY(dq.alloc(q64.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(dq.p, q64.data(), q64.size() * sizeof(double), hipMemcpyHostToDevice));
+    // 4. per-coordinate range of y over ALL vectors (device), clipped to +-8 sigma; step, biases, tail unit
     DeviceBuffer st;
-    constexpr uint32_t kPcaPd = kPcaRows; // stride of the statistics arrays
-    HIP_TRY(st.alloc((2 * kPcaPd + 2) * 4));
-    std::vector<uint32_t> init(2 * kPcaPd + 2, 0u);
-    for (uint32_t i = 0; i < kPcaPd; ++i) init[i] = 0xFFFFFFFFu;
+    HIP_TRY(st.alloc((2 * 32 + 2) * 4));
+    std::vector<uint32_t> init(2 * 32 + 2, 0u);
+    for (uint32_t i = 0; i < 32; ++i) init[i] = 0xFFFFFFFFu;
     HIP_TRY(hipMemcpy(st.p, init.data(), init.size() * 4, hipMemcpyHostToDevice));
     PcaArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.pd = pd; pa.dc = kFatDc;
-    pa.pt = ix->d_pca; pa.mean = ix->d_pca + p_floats; pa.bias = pa.mean + kPcaRows;
-    pa.stat_min = static_cast<uint32_t*>(st.p); pa.stat_max = pa.stat_min + kPcaPd; pa.stat_tail = pa.stat_max + kPcaPd; pa.stat_bad = pa.stat_tail + 1;
+    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.dc = dcu;
+    pa.decomp = ix->sq_enabled; pa.sq_scale = ix->sq_scale; pa.sq_bias = ix->sq_bias; pa.normalize = cosine ? 1 : 0; pa.signed_codes = l2 ? 0 : 1;
+    pa.q64 = static_cast<const double*>(dq.p);
+    pa.mean = ix->d_pca + static_cast<size_t>(kPcaRows) * pd; pa.bias = pa.mean + pd;
+    pa.stat_min = static_cast<uint32_t*>(st.p); pa.stat_max = pa.stat_min + 32; pa.stat_tail = pa.stat_max + 32; pa.stat_bad = pa.stat_tail + 1;
     HIP_TRY(launch_pca_stats(pa, nullptr));
-    std::vector<uint32_t> stats(2 * kPcaPd + 2);
+    std::vector<uint32_t> stats(2 * 32 + 2);
     HIP_TRY(hipMemcpy(stats.data(), st.p, stats.size() * 4, hipMemcpyDeviceToHost));
-    if (stats[2 * kPcaPd + 1] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
+    if (stats[2 * 32 + 1] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
     double range = 0.0, bmax = 0.0;
     std::vector<float> bias(32, 0.0f);
-    for (uint32_t i = 0; i < kFatDc; ++i) {
-        double lo = pca_key_to_float(stats[i]), hi = pca_key_to_float(stats[kPcaPd + i]);
-        const double sig = std::sqrt(std::max(cov[static_cast<size_t>(order[i]) * d + order[i]], 0.0));
-        if (sig > 0.0) { // outliers beyond 8 sigma clamp (their coding error is in their own ex)
-            lo = std::max(lo, -8.0 * sig);
-            hi = std::min(hi, 8.0 * sig);
+    for (uint32_t i = 0; i < dcu; ++i) {
+        double lo = pca_key_to_float(stats[i]), hi = pca_key_to_float(stats[32 + i]);
+        if (sigma[i] > 0.0) { // outliers beyond 8 sigma clamp (their coding error is in their own ex)
+            lo = std::max(lo, -8.0 * sigma[i]);
+            hi = std::min(hi, 8.0 * sigma[i]);
         }
         if (!(hi > lo)) hi = lo;
-        bias[i] = static_cast<float>(lo);
-        range = std::max(range, hi - lo);
-        bmax = std::max(bmax, std::fabs(static_cast<double>(bias[i])));
+        if (l2) {
+            bias[i] = static_cast<float>(lo);
+            range = std::max(range, hi - lo);
+            bmax = std::max(bmax, std::fabs(static_cast<double>(bias[i])));
+        } else {
+            range = std::max(range, std::max(std::fabs(lo), std::fabs(hi)));
+        }
     }
-    float stepf = static_cast<float>(range / 255.0);
+    float stepf = static_cast<float>(range / (l2 ? 255.0 : 127.0));
     if (!(stepf > 0.0f) || !(stepf < 3.0e38f)) stepf = 1.0f;
-    float tail_max = pca_key_to_float(stats[2 * kPcaPd]);
-    if (!(tail_max > 0.0f)) tail_max = 1.0f;
+    float tail_max = pca_key_to_float(stats[2 * 32]);
+    if (!(tail_max > 0.0f) || !(tail_max < 3.0e38f)) tail_max = 1.0f;
     const float tail_unit = tail_max / 60000.0f;
-    HIP_TRY(hipMemcpy(ix->d_pca + p_floats + kPcaRows, bias.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
-    // 4. records, then node rows
+    HIP_TRY(hipMemcpy(ix->d_pca + static_cast<size_t>(kPcaRows) * pd + pd, bias.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
+    // 5. records, then node rows
     DeviceBuffer rec;
     HIP_TRY(rec.alloc(static_cast<size_t>(n) * 32 + 32));
     pa.step = stepf; pa.tail_unit = tail_unit; pa.records = static_cast<uint32_t*>(rec.p);
@@ -458,9 +557,10 @@ int build_fat_rows(svsx_index* ix) {
     ix->fat_stride = fat_stride;
     ix->pca_step = stepf;
     ix->pca_tail_unit = tail_unit;
-    ix->pca_eps = static_cast<float>(eps);
-    // rounding of fl(b + s c) in the query's residual: <= 2^-23 (|b| + 255 s) per component, 28 components
-    ix->pca_eq_abs = static_cast<float>(5.2915 * 1.2e-7 * (bmax + 255.0 * stepf) * 1.01);
+    ix->pca_delta = static_cast<float>(delta * 1.01 + 1e-9);
+    // rounding of fl(b + s c) (L2) / fl(s c) (signed codes) in the query's residual: <= 2^-23 (|b| + 255 s) per coordinate
+    ix->pca_eq_abs = static_cast<float>(std::sqrt(static_cast<double>(dcu)) * 1.2e-7 * (bmax + 255.0 * stepf) * 1.01);
+    ix->pca_ref_extra = ix->sq_enabled ? static_cast<float>(2.0 * std::fabs(static_cast<double>(ix->sq_bias)) * std::sqrt(static_cast<double>(d)) * 1.01) : 0.0f;
     return SVSX_SUCCESS;
 }
 
@@ -476,13 +576,18 @@ extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
     if (mode != 1 && ix->d_codes) { (void)hipFree(ix->d_codes); ix->d_codes = nullptr; }
     if (mode != 2 && ix->d_fat) { (void)hipFree(ix->d_fat); ix->d_fat = nullptr; }
     if (mode == 0) return SVSX_SUCCESS;
-    if (ix->metric != M_L2 || (ix->data_dtype != DT_F32 && ix->data_dtype != DT_F16) || ix->sq_enabled)
-        return fail(SVSX_NOT_IMPLEMENTED, "bound codes cover float32 / float16 L2 indexes");
     if (mode == 2) {
+        // float32 / float16 rows (any metric) and scalar-quantized rows under inner product / cosine (the compressed L2 distance
+        // is taken between CODED query and data, scalar.h:58-105, and the raw int8 x int8 kernels are exact integer paths)
         if (ix->d_fat) return SVSX_SUCCESS;
-        if (ix->d < 32 || ix->d > 128 || !ix->d_graph) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover graph indexes of dimension 32..128");
+        const bool float_rows = (ix->data_dtype == DT_F32 || ix->data_dtype == DT_F16) && !ix->sq_enabled;
+        const bool sq_rows = ix->sq_enabled && ix->metric != M_L2;
+        if (!float_rows && !sq_rows) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover float32 / float16 rows and scalar-quantized rows under inner product or cosine");
+        if (ix->d < 32 || ix->d > 4096 || !ix->d_graph) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover graph indexes of dimension 32..4096");
         return build_fat_rows(ix);
     }
+    if (ix->metric != M_L2 || (ix->data_dtype != DT_F32 && ix->data_dtype != DT_F16) || ix->sq_enabled)
+        return fail(SVSX_NOT_IMPLEMENTED, "128-byte bound-code rows cover float32 / float16 L2 indexes");
     if (ix->d_codes) return SVSX_SUCCESS;
     if (ix->d != 96 && ix->d != 128) return fail(SVSX_NOT_IMPLEMENTED, "128-byte bound-code rows cover dimension 96 or 128");
     const uint32_t dc = static_cast<uint32_t>(ix->d < 120 ? ix->d : 120);
@@ -541,10 +646,11 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
         a.pca_pd = static_cast<uint32_t>((ix->d + 15) & ~size_t(15));
         a.pca_t = ix->d_pca;
         a.pca_mean = ix->d_pca + static_cast<size_t>(kPcaRows) * a.pca_pd;
-        a.pca_bias = a.pca_mean + kPcaRows;
+        a.pca_bias = a.pca_mean + a.pca_pd;
         a.pca_step = ix->pca_step;
         a.pca_tail_unit = ix->pca_tail_unit;
-        a.pca_eps = ix->pca_eps;
+        a.pca_delta = ix->pca_delta;
+        a.pca_ref_extra = ix->pca_ref_extra;
         a.pca_eq_abs = ix->pca_eq_abs;
     }
     return a;

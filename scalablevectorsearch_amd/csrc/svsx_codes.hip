@@ -1,29 +1,32 @@
-// svsx_codes.hip -- graph-inline bound codes ("fat" adjacency rows) for the greedy-search kernel (gfx950).
+// svsx_codes.hip -- graph-inline bound records ("fat" adjacency rows) for the greedy-search kernel (gfx950).
 //
 // No reference counterpart: a result-neutral traffic reduction.  The search kernel is bound by the number
 // of distinct 128-B lines it requests from the fabric (tools/ubench/gather_bench: ~49 G random lines/s whatever the row
-// size <= 128 B), and at window 128 most of those lines were per-candidate code rows.  Here every node's adjacency row
-// carries, next to the 64 neighbour ids, a 32-byte record PER NEIGHBOUR -- a copy of that neighbour's record -- so one
-// expansion reads ONE contiguous 2.3-KB block (18 lines, address known as soon as the node is) instead of 2 + ~50
-// scattered lines, and the lower bound of all 64 candidates is evaluated lane-parallel (lane c <-> neighbour c).
+// size <= 128 B).  Here every node's adjacency row carries, next to the neighbour ids, a 32-byte record PER NEIGHBOUR -- a
+// copy of that neighbour's record -- so one expansion reads ONE contiguous block of 36 bytes x degree slots (18 lines at
+// R = 64, address known as soon as the node is) and a bound on the distance of all 64 candidates is evaluated lane-parallel
+// (lane c <-> neighbour c); only candidates the bound cannot exclude have their vector row fetched.
 //
-// Record of vector x (32 B):  28 x u8 codes of the leading components of y = P (x - mean) | f16 ex | f16 tx
-//   P      d x d rotation, rows = eigenvectors of the sample covariance by descending eigenvalue (host: Jacobi, f64),
-//          stored as float32; eps >= || P P^T - I ||_F is measured in f64 AFTER the rounding to float32
-//   codes  c_i = clamp(rint((y_i - b_i) / s), 0, 255), one global step s, per-component bias b_i
-//   ex     || y_C - (b + s c) ||  in units of s, rounded UP to float16       (coding error incl. clamping)
-//   tx     || y_T ||  (the components the codes do not cover) in units of `tail_unit`, nearest float16
-// With u = P (q - mean) for the query, in real arithmetic
-//     (1 + eps) ||q - x||^2  >=  ||u_C - y_C||^2 + (||u_T|| - ||y_T||)^2 ,   ||u_C - y_C|| >= s sqrt(I) - eq - ex ,
-// I = sum (cq_i - cx_i)^2 an exact integer.  The kernel (svsx_search.hip, CODES == 2) rejects a candidate only if this
-// bound, with explicit slack for every float rounding on the query side, exceeds the worst buffer entry -- i.e. only
-// candidates SearchBuffer::can_skip (search_buffer.h:338-340) would drop anyway.
+// Geometry.  Q = DC orthonormal directions (rows; the leading principal directions of a data sample, host: svsx_api.hip),
+// z = the vector the metric sees (L2: x - mean; inner product: x; cosine: x / ||x||; scalar-quantized rows: the
+// decompressed values), y = Q z its DC coordinates, r = z - Q^T y the remainder, ||r||^2 = ||z||^2 - ||y||^2 exactly.
+// For a query with coordinates u and remainder norm tq:
+//     L2      ||q - x||^2  =  ||u - y||^2 + ||r_q - r_x||^2  >=  ||u - y||^2 + (tq - tx)^2
+//     IP/cos  q . z        =  u . y + r_q . r_x             <=  u . y + tq tx
+// Record (32 B), everything rounded in the SAFE direction:
+//     L2      28 x u8 codes c_i = clamp(rint((y_i - b_i) / s), 0, 255) | f16 ex (up) | f16 tx (nearest)
+//     IP/cos  26 x i8 codes c_i = clamp(rint(y_i / s), -127, 127)      | f16 ex (up) | f16 ny (up) | f16 tx (up)
+// ex >= ||y - yhat|| (coding error incl. clamping, in units of s), ny >= ||yhat|| (units of s), tx = ||r|| (units of
+// `tail_unit`).  The kernel (svsx_search.hip, CODES == 2) adds explicit slack for every float rounding on the query side and
+// rejects a candidate only if the bound proves SearchBuffer::can_skip (search_buffer.h:338-340) would drop it anyway.
 #include "svsx_device.h"
 #include "svsx_kernels.h"
 
 namespace svsx {
 
 namespace {
+
+constexpr int kMaxDc = 28;
 
 __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -35,117 +38,149 @@ __device__ __forceinline__ uint32_t f32_order_key(float f) { // monotone map flo
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// smallest float16 >= v (v >= 0); +inf when it does not fit
+// smallest float16 >= v (v >= 0); +inf when it does not fit (the bound then never fires for this vector)
 __device__ __forceinline__ uint16_t half_round_up(double v) {
+    if (!(v == v)) return 0x7C00u;
     _Float16 h = static_cast<_Float16>(static_cast<float>(v));
     uint16_t bits = __builtin_bit_cast(uint16_t, h);
     if (static_cast<double>(h) < v) bits = static_cast<uint16_t>(bits + 1u); // next representable (positive values; 0x7BFF + 1 = inf)
     return bits;
 }
 
-template <typename T> __device__ __forceinline__ double load_elem(const unsigned char* row, uint32_t j) {
-    return static_cast<double>(static_cast<float>(reinterpret_cast<const T*>(row)[j]));
+// element j of a row as the reference's kernels see it: widened exactly; scalar-quantized rows decompressed in float32 with
+// separately rounded multiply and add (quantization/scalar/scalar.h:44-46)
+template <int DT> __device__ __forceinline__ double load_elem(const PcaArgs& a, const unsigned char* row, uint32_t j) {
+    float f;
+    if constexpr (DT == DT_F32) f = reinterpret_cast<const float*>(row)[j];
+    else if constexpr (DT == DT_F16) f = static_cast<float>(reinterpret_cast<const _Float16*>(row)[j]);
+    else if constexpr (DT == DT_I8) f = static_cast<float>(static_cast<int>(reinterpret_cast<const int8_t*>(row)[j]));
+    else f = static_cast<float>(static_cast<unsigned>(row[j]));
+    if (a.decomp) {
+        const float t = a.sq_scale * f;
+        f = t + a.sq_bias;
+    }
+    return static_cast<double>(f);
 }
 
-// y = P (x - mean) in f64 for one vector, component i = lane + 64 t held by lane (t < 2: d <= 128).  vs = LDS, d doubles.
-template <typename T>
-__device__ __forceinline__ void project(const PcaArgs& a, const unsigned char* row, double* vs, uint32_t lane, double (&y)[2]) {
-    for (uint32_t j = lane; j < a.d; j += 64) vs[j] = load_elem<T>(row, j) - static_cast<double>(a.mean[j]);
-    __syncthreads();
-    y[0] = 0.0;
-    y[1] = 0.0;
-    const bool has0 = lane < a.d, has1 = lane + 64 < a.d;
-    const float* r0 = a.pt + static_cast<size_t>(lane) * a.pd;       // row-major rotation, `pd` floats per row
-    const float* r1 = a.pt + static_cast<size_t>(lane + 64u) * a.pd;
-    for (uint32_t j = 0; j < a.d; ++j) {
-        const double v = vs[j];
-        if (has0) y[0] = __builtin_fma(static_cast<double>(r0[j]), v, y[0]);
-        if (has1) y[1] = __builtin_fma(static_cast<double>(r1[j]), v, y[1]);
+// Coordinates of one vector: z into LDS (`vs`, d doubles), then y_i = Q_i . z for i < dc (every lane returns all of them in
+// y[]), n2 = ||z||^2.  Lane l owns the elements j = l, l + 64, ...: coalesced reads of the f64 basis rows.
+template <int DT>
+__device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned char* row, double* vs, uint32_t lane, double (&y)[kMaxDc], double& n2) {
+    double part = 0.0;
+    for (uint32_t j = lane; j < a.d; j += 64) {
+        const double z = load_elem<DT>(a, row, j) - static_cast<double>(a.mean[j]);
+        vs[j] = z;
+        part += z * z;
     }
+    n2 = wave_sum(part);
+    double scale = 1.0;
+    if (a.normalize) scale = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0; // cosine: the unit vector (a zero vector gets ex = inf below)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kMaxDc; ++i) y[i] = 0.0;
+    for (uint32_t j = lane; j < a.d; j += 64) {
+        const double z = vs[j] * scale;
+#pragma unroll
+        for (int i = 0; i < kMaxDc; ++i)
+            if (static_cast<uint32_t>(i) < a.dc) y[i] = __builtin_fma(a.q64[static_cast<size_t>(i) * a.d + j], z, y[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxDc; ++i) y[i] = wave_sum(y[i]);
+    if (a.normalize) n2 = n2 > 0.0 ? 1.0 : 0.0;
     __syncthreads();
 }
 
 } // namespace
 
-// pass 1: per-component min / max of y (order keys), max tail norm, count of non-finite vectors
-template <typename T> __global__ __launch_bounds__(64) void pca_stats_kernel(const PcaArgs a) {
-    __shared__ double vs[128];
+// pass 1: per-coordinate min / max of y (order keys), max remainder norm, count of non-finite vectors
+template <int DT> __global__ __launch_bounds__(64) void pca_stats_kernel(const PcaArgs a) {
+    extern __shared__ double vs[];
     const uint32_t lane = threadIdx.x;
-    float lo[2] = {__builtin_inff(), __builtin_inff()}, hi[2] = {-__builtin_inff(), -__builtin_inff()};
+    float lo = __builtin_inff(), hi = -__builtin_inff();
     double tmax = 0.0;
     uint32_t bad = 0;
     for (uint32_t r = blockIdx.x; r < a.n; r += gridDim.x) {
-        double y[2];
-        project<T>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, lane, y);
-        double t2 = 0.0;
+        double y[kMaxDc], n2;
+        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, lane, y, n2);
+        double ny2 = 0.0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const uint32_t i = lane + 64u * t;
-            if (i < a.d) {
-                const float f = static_cast<float>(y[t]);
-                if (!(f - f == 0.0f)) bad = 1;
-                lo[t] = f < lo[t] ? f : lo[t];
-                hi[t] = f > hi[t] ? f : hi[t];
-                if (i >= a.dc) t2 += y[t] * y[t];
-            }
-        }
-        t2 = wave_sum(t2);
-        const double tn = sqrt(t2);
-        tmax = tn > tmax ? tn : tmax;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const uint32_t i = lane + 64u * t;
-        if (i < a.d && lo[t] <= hi[t]) {
-            atomicMin(&a.stat_min[i], f32_order_key(lo[t]));
-            atomicMax(&a.stat_max[i], f32_order_key(hi[t]));
-        }
-    }
-    if (lane == 0) {
-        atomicMax(a.stat_tail, f32_order_key(static_cast<float>(tmax) * 1.0000002f));
-    }
-    if (__ballot(bad != 0) != 0ull && lane == 0) atomicAdd(a.stat_bad, 1u);
-}
-
-// pass 2: the 32-byte record of every vector
-template <typename T> __global__ __launch_bounds__(64) void pca_encode_kernel(const PcaArgs a) {
-    __shared__ double vs[128];
-    const uint32_t lane = threadIdx.x;
-    const double s = static_cast<double>(a.step), inv = 1.0 / s;
-    for (uint32_t r = blockIdx.x; r < a.n; r += gridDim.x) {
-        double y[2];
-        project<T>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, lane, y);
-        double e2 = 0.0, t2 = 0.0;
-        uint32_t code = 0;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const uint32_t i = lane + 64u * t;
-            if (i < a.d) {
-                if (i < a.dc) {
-                    const double b = static_cast<double>(a.bias[i]);
-                    double c = rint((y[t] - b) * inv);
-                    c = c < 0.0 ? 0.0 : (c > 255.0 ? 255.0 : c);
-                    if (!(c == c)) c = 0.0;
-                    code = static_cast<uint32_t>(c);
-                    const double rr = y[t] - (b + s * c);
-                    e2 += rr * rr;
-                } else {
-                    t2 += y[t] * y[t];
+        for (int i = 0; i < kMaxDc; ++i) {
+            if (static_cast<uint32_t>(i) < a.dc) {
+                ny2 += y[i] * y[i];
+                if (lane == static_cast<uint32_t>(i)) {
+                    const float f = static_cast<float>(y[i]);
+                    lo = f < lo ? f : lo;
+                    hi = f > hi ? f : hi;
                 }
             }
         }
-        e2 = wave_sum(e2);
-        t2 = wave_sum(t2);
-        // bytes 4w .. 4w+3 -> lane w (dc <= 28 -> 7 words)
-        uint32_t w = 0;
+        if (!(n2 - n2 == 0.0)) bad = 1;
+        const double t2 = n2 - ny2;
+        const double tn = t2 > 0.0 ? sqrt(t2) : 0.0;
+        tmax = tn > tmax ? tn : tmax;
+    }
+    if (lane < a.dc && lo <= hi) {
+        atomicMin(&a.stat_min[lane], f32_order_key(lo));
+        atomicMax(&a.stat_max[lane], f32_order_key(hi));
+    }
+    if (lane == 0) {
+        atomicMax(a.stat_tail, f32_order_key(static_cast<float>(tmax) * 1.0000002f));
+        if (bad) atomicAdd(a.stat_bad, 1u);
+    }
+}
+
+// pass 2: the 32-byte record of every vector
+template <int DT> __global__ __launch_bounds__(64) void pca_encode_kernel(const PcaArgs a) {
+    extern __shared__ double vs[];
+    const uint32_t lane = threadIdx.x;
+    const double s = static_cast<double>(a.step), inv = 1.0 / s;
+    for (uint32_t r = blockIdx.x; r < a.n; r += gridDim.x) {
+        double y[kMaxDc], n2;
+        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, lane, y, n2);
+        double e2 = 0.0, ny2 = 0.0, nh2 = 0.0;
+        uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) w |= (static_cast<uint32_t>(__shfl(static_cast<int>(code), static_cast<int>((lane & 7u) * 4u + t))) & 0xFFu) << (8 * t);
-        if (lane == 7) {
-            const uint16_t exh = half_round_up(sqrt(e2) * inv * (1.0 + 1e-12));
-            const _Float16 txh = static_cast<_Float16>(static_cast<float>(sqrt(t2) / static_cast<double>(a.tail_unit)));
-            w = static_cast<uint32_t>(exh) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, txh)) << 16);
+        for (int i = 0; i < kMaxDc; ++i) {
+            if (static_cast<uint32_t>(i) < a.dc) {
+                double c, yh;
+                if (a.signed_codes) {
+                    c = rint(y[i] * inv);
+                    c = c < -127.0 ? -127.0 : (c > 127.0 ? 127.0 : c);
+                    if (!(c == c)) c = 0.0;
+                    yh = s * c;
+                } else {
+                    const double b = static_cast<double>(a.bias[i]);
+                    c = rint((y[i] - b) * inv);
+                    c = c < 0.0 ? 0.0 : (c > 255.0 ? 255.0 : c);
+                    if (!(c == c)) c = 0.0;
+                    yh = b + s * c;
+                }
+                const double rr = y[i] - yh;
+                e2 += rr * rr;
+                ny2 += y[i] * y[i];
+                nh2 += yh * yh;
+                w[i >> 2] |= (static_cast<uint32_t>(static_cast<int>(c)) & 0xFFu) << (8 * (i & 3));
+            }
         }
-        if (lane < 8) a.records[static_cast<size_t>(r) * 8 + lane] = w;
+        const double t2 = n2 - ny2;
+        const double tail = t2 > 0.0 ? sqrt(t2) : 0.0;
+        uint16_t exh = half_round_up(sqrt(e2) * inv * (1.0 + 1e-12));
+        if (a.normalize && n2 == 0.0) exh = 0x7C00u; // zero vector under cosine: the reference's distance is NaN, never bound it
+        if (a.signed_codes) { // 26 codes | ex | ny | tx, all upper bounds
+            const uint16_t nyh = half_round_up(sqrt(nh2) * inv * (1.0 + 1e-12));
+            const uint16_t txh = half_round_up(tail / static_cast<double>(a.tail_unit) * (1.0 + 1e-12));
+            w[6] = (w[6] & 0xFFFFu) | (static_cast<uint32_t>(exh) << 16);
+            w[7] = static_cast<uint32_t>(nyh) | (static_cast<uint32_t>(txh) << 16);
+        } else {              // 28 codes | ex (up) | tx (nearest)
+            const _Float16 txn = static_cast<_Float16>(static_cast<float>(tail / static_cast<double>(a.tail_unit)));
+            w[7] = static_cast<uint32_t>(exh) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, txn)) << 16);
+        }
+        if (lane < 8) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) mine = lane == static_cast<uint32_t>(t) ? w[t] : mine;
+            a.records[static_cast<size_t>(r) * 8 + lane] = mine;
+        }
     }
 }
 
@@ -189,23 +224,28 @@ float pca_key_to_float(uint32_t k) {
     return f;
 }
 
-static uint32_t grid_for(uint32_t n) { return n < 65536u ? (n ? n : 1u) : 65536u; }
+static uint32_t grid_for(uint32_t n) { return n < 32768u ? (n ? n : 1u) : 32768u; }
 
-hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream) {
-    if (a.d > 128) return hipErrorInvalidValue;
-    if (a.dtype == DT_F32) hipLaunchKernelGGL(pca_stats_kernel<float>, dim3(grid_for(a.n)), dim3(64), 0, stream, a);
-    else if (a.dtype == DT_F16) hipLaunchKernelGGL(pca_stats_kernel<_Float16>, dim3(grid_for(a.n)), dim3(64), 0, stream, a);
-    else return hipErrorInvalidValue;
+template <int DT> static hipError_t launch_both(const PcaArgs& a, bool encode, hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(a.d) * sizeof(double);
+    if (lds > 64 * 1024 || a.dc > static_cast<uint32_t>(kMaxDc)) return hipErrorInvalidValue;
+    if (encode) hipLaunchKernelGGL(pca_encode_kernel<DT>, dim3(grid_for(a.n)), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL(pca_stats_kernel<DT>, dim3(grid_for(a.n)), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream) {
-    if (a.d > 128 || a.dc > 28) return hipErrorInvalidValue;
-    if (a.dtype == DT_F32) hipLaunchKernelGGL(pca_encode_kernel<float>, dim3(grid_for(a.n)), dim3(64), 0, stream, a);
-    else if (a.dtype == DT_F16) hipLaunchKernelGGL(pca_encode_kernel<_Float16>, dim3(grid_for(a.n)), dim3(64), 0, stream, a);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
+static hipError_t launch_by_dtype(const PcaArgs& a, bool encode, hipStream_t stream) {
+    switch (a.dtype) {
+        case DT_F32: return launch_both<DT_F32>(a, encode, stream);
+        case DT_F16: return launch_both<DT_F16>(a, encode, stream);
+        case DT_I8: return launch_both<DT_I8>(a, encode, stream);
+        case DT_U8: return launch_both<DT_U8>(a, encode, stream);
+    }
+    return hipErrorInvalidValue;
 }
+
+hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream) { return launch_by_dtype(a, false, stream); }
+hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream) { return launch_by_dtype(a, true, stream); }
 
 hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, void* d_fat, size_t fat_stride, hipStream_t stream) {
     hipLaunchKernelGGL(fat_build_kernel, dim3(grid_for(n)), dim3(64), 0, stream, d_graph, gstride, n, static_cast<const uint4*>(d_records),

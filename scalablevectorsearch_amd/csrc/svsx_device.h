@@ -709,8 +709,52 @@ struct WaveBuffer {
 __device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 
 // SearchBuffer::insert_inner (search_buffer.h:353-403).  d / id are wave-uniform.  Returns true if inserted.
+// `unordered`: a NaN distance has reached the buffer, so it is no longer partitioned by the comparison and "the insert position"
+// is whatever std::lower_bound's probe sequence finds (libstdc++ bits/stl_algobase.h __lower_bound: half = len >> 1, probe
+// first + half) -- replayed here step by step, followed by the reference's backward duplicate walk (search_buffer.h:377-389).
 template <bool GREATER>
-__device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id, uint32_t lane) {
+__device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id, uint32_t lane, bool unordered = false) {
+    if (unordered) {
+        uint32_t first = 0, len = b.size;
+        while (len > 0u) {
+            const uint32_t half = len >> 1, mid = first + half;
+            const float ed = __uint_as_float(b.e[mid].x); // wave-uniform address: LDS broadcast
+            if (!cmpf<GREATER>(d, ed)) {
+                first = mid + 1u;
+                len = len - half - 1u;
+            } else {
+                len = half;
+            }
+        }
+        const uint32_t pos = first;
+        if (pos != 0u) {
+            uint32_t back = pos;
+            do {
+                --back;
+                const uint2 en = b.e[back];
+                if (cmpf<GREATER>(__uint_as_float(en.x), d)) break;
+                if ((en.y & kIdMask) == id) return false;
+            } while (back != 0u);
+        }
+        lds_order();
+        const uint32_t end = b.size;
+        if (end > pos) {
+            const uint32_t nchunk = (end - pos + 63u) >> 6;
+            for (int c = static_cast<int>(nchunk) - 1; c >= 0; --c) {
+                const uint32_t i = pos + (static_cast<uint32_t>(c) << 6) + lane;
+                uint2 en = make_uint2(0, 0);
+                if (i < end) en = b.e[i];
+                lds_order();
+                if (i < end) b.e[i + 1] = en;
+                lds_order();
+            }
+        }
+        if (lane == 0) b.e[pos] = make_uint2(__float_as_uint(d), id);
+        lds_order();
+        b.size = (b.size + 1 < b.capacity) ? b.size + 1 : b.capacity;
+        b.best_unvisited = pos < b.best_unvisited ? pos : b.best_unvisited;
+        return true;
+    }
     if (b.size <= 128u) {
         // at most two entries per lane: one LDS read serves the position search, the duplicate scan AND the shift
         // (old[i] -> e[i + 1] straight from the registers: every read precedes every write, no chunk ordering needed)

@@ -43,14 +43,15 @@ struct SearchArgs {
     // graph-inline records (svsx_codes.hip; CODES == 2): node rows [ids | plane 0 | plane 1] per chunk of <= 64 slots
     const unsigned char* fat;
     size_t fat_stride;        // bytes per node
-    const float* pca_t;       // [128][pca_pd] rotation, row-major: pca_t[i * pca_pd + j] = P[i][j], zero padded (pca_pd = d rounded up to 16)
-    const float* pca_mean;    // [d]
-    const float* pca_bias;    // [28] per-component code bias b_i
+    const float* pca_t;       // [32][pca_pd] leading directions, row-major float32 (rows >= dc are zero), pca_pd = d rounded up to 16
+    const float* pca_mean;    // [pca_pd] (zeros unless L2)
+    const float* pca_bias;    // [32] per-coordinate code bias (L2)
     uint32_t pca_pd;
     float pca_step;           // s
     float pca_tail_unit;      // tx = half(tx16) * tail_unit
-    float pca_eps;            // >= || P P^T - I ||_F
+    float pca_delta;          // >= max_i || float32(Q_i) - Q_i ||: rounding of the directions the query is projected with
     float pca_eq_abs;         // absolute slack of the query coding error (rounding of b + s c)
+    float pca_ref_extra;      // scalar-quantized inner product: 2 |bias| sqrt(d), enters the slack for the reference's own rounding
     // cancellation (index/vamana/index.h:541-545, greedy_search.h:155): device word polled once per expansion; non-zero = stop
     const int* cancel;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
@@ -171,14 +172,18 @@ struct PcaArgs {
     const void* data;
     size_t row_bytes;
     int dtype;
-    uint32_t n, d, pd, dc;
-    const float* pt;        // [128][pd] row-major rotation (pd = d rounded up to 16), zero padded
-    const float* mean;      // [d]
-    const float* bias;      // [dc]            (encode)
+    uint32_t n, d, dc;      // dc = coded coordinates (28 unsigned / 26 signed)
+    int decomp;             // rows are scalar-quantized codes: decompress scale * c + bias in float32 first
+    float sq_scale, sq_bias;
+    int normalize;          // cosine: code the unit vector
+    int signed_codes;       // inner product / cosine record layout
+    const double* q64;      // [dc][d] orthonormal directions (f64)
+    const float* mean;      // [d] (zeros unless L2)
+    const float* bias;      // [dc] per-coordinate code bias (unsigned codes; encode)
     float step, tail_unit;  //                 (encode)
-    uint32_t* stat_min;     // [d] order keys  (stats; init 0xFFFFFFFF)
-    uint32_t* stat_max;     // [d] order keys  (stats; init 0)
-    uint32_t* stat_tail;    // max tail norm key (init 0)
+    uint32_t* stat_min;     // [dc] order keys (stats; init 0xFFFFFFFF)
+    uint32_t* stat_max;     // [dc] order keys (stats; init 0)
+    uint32_t* stat_tail;    // max remainder norm key (init 0)
     uint32_t* stat_bad;     // vectors with a non-finite component (init 0)
     uint32_t* records;      // [n][8]          (encode)
 };

@@ -157,78 +157,101 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
         code_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, code_eq)));
     }
 
-    // ---- graph-inline records (svsx_codes.hip; CODES == 2): rotate and code the query once ---------------------------------
-    //   u = P (q - mean) in f32 (v_j = fl(q_j - mean_j), one fma chain per component: |error_i| <= (d + 1) 2^-24 ||P_i|| ||q - mean||),
-    //   codes of u_0..27 with the index' (step, bias), eq >= ||u_C - (b + s cq)|| + rotation error, tq = ||u_T||.
+    // ---- graph-inline records (svsx_codes.hip; CODES == 2): coordinates, codes and remainder norm of the query, once --------
+    //   v = q - mean (mean = 0 unless L2);  u_i = P_i . v  for the DC leading directions (P = float32 copy of the orthonormal
+    //   f64 directions Q the records were built with):  |u_i - Q_i . v*| <= ((d + 2) 2^-24 + delta + 2^-24) ||v||  (fma chain,
+    //   rounding of P, rounding of q - mean).  Everything below carries that slack explicitly.
     uint32_t fq[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    int fat_qq = 0;
-    float fat_eq = 0.0f, fat_tq = 0.0f, fat_et0 = 0.0f, fat_s2m = 0.0f;
+    [[maybe_unused]] int fat_qq = 0;
+    [[maybe_unused]] float fat_eq = 0.0f, fat_tq_hi = 0.0f, fat_tq_lo = 0.0f, fat_s2m = 0.0f, fat_nuh = 0.0f, fat_nq = 0.0f;
     if constexpr (CODES == 2) {
-        constexpr int DC = 28;
-        // lane i owns rows i and i + 64 of P (row-major, `dpad` floats per row, 128 rows, zero padded): 16-byte loads of its
-        // own rows (L1 / L2 resident: the matrix is shared by every query), v_j = q_j - mean_j broadcast from LDS / scalar loads
-        float u0 = 0.0f, u1 = 0.0f, vv = 0.0f;
-        const float4* prow0 = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(lane) * dpad);
-        const float4* prow1 = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(lane + 64u) * dpad);
-        const bool two = d > 64;
+        constexpr int DC = METRIC == M_L2 ? 28 : 26;
+        const uint32_t ci = lane & 31u, half = lane >> 5; // lane -> coordinate ci, half of the element range
+        const int hlen = dpad >> 1;                       // dpad is a multiple of 16 -> 8-float steps
+        const float4* prow = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(ci) * a.pca_pd + half * hlen);
+        const float* qh = qf + half * hlen;
+        const float* mh = a.pca_mean + half * hlen;
+        float up = 0.0f, vvp = 0.0f;
 #pragma unroll 1
-        for (int j0 = 0; j0 < dpad; j0 += 8) { // rolled: the rotation must not raise the kernel's register peak
-            float4 pa[2], pb[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                pa[t] = prow0[(j0 >> 2) + t];
-                pb[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (two) pb[t] = prow1[(j0 >> 2) + t];
+        for (int j0 = 0; j0 < hlen; j0 += 8) { // rolled: the projection must not raise the kernel's register peak
+            const float4 p0 = prow[j0 >> 2], p1 = prow[(j0 >> 2) + 1];
+            float4 v0 = *reinterpret_cast<const float4*>(qh + j0), v1 = *reinterpret_cast<const float4*>(qh + j0 + 4);
+            if constexpr (METRIC == M_L2) {
+                const float4 m0 = *reinterpret_cast<const float4*>(mh + j0), m1 = *reinterpret_cast<const float4*>(mh + j0 + 4);
+                v0.x -= m0.x; v0.y -= m0.y; v0.z -= m0.z; v0.w -= m0.w;
+                v1.x -= m1.x; v1.y -= m1.y; v1.z -= m1.z; v1.w -= m1.w;
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float4 qv = *reinterpret_cast<const float4*>(qf + j0 + 4 * t);
-                const float4 mv = *reinterpret_cast<const float4*>(a.pca_mean + j0 + 4 * t);
-                const float v0 = qv.x - mv.x, v1 = qv.y - mv.y, v2 = qv.z - mv.z, v3 = qv.w - mv.w;
-                u0 = __builtin_fmaf(pa[t].x, v0, u0); u0 = __builtin_fmaf(pa[t].y, v1, u0); u0 = __builtin_fmaf(pa[t].z, v2, u0); u0 = __builtin_fmaf(pa[t].w, v3, u0);
-                u1 = __builtin_fmaf(pb[t].x, v0, u1); u1 = __builtin_fmaf(pb[t].y, v1, u1); u1 = __builtin_fmaf(pb[t].z, v2, u1); u1 = __builtin_fmaf(pb[t].w, v3, u1);
-                vv = __builtin_fmaf(v0, v0, vv); vv = __builtin_fmaf(v1, v1, vv); vv = __builtin_fmaf(v2, v2, vv); vv = __builtin_fmaf(v3, v3, vv);
-            }
+            up = __builtin_fmaf(p0.x, v0.x, up); up = __builtin_fmaf(p0.y, v0.y, up); up = __builtin_fmaf(p0.z, v0.z, up); up = __builtin_fmaf(p0.w, v0.w, up);
+            up = __builtin_fmaf(p1.x, v1.x, up); up = __builtin_fmaf(p1.y, v1.y, up); up = __builtin_fmaf(p1.z, v1.z, up); up = __builtin_fmaf(p1.w, v1.w, up);
+            vvp = __builtin_fmaf(v0.x, v0.x, vvp); vvp = __builtin_fmaf(v0.y, v0.y, vvp); vvp = __builtin_fmaf(v0.z, v0.z, vvp); vvp = __builtin_fmaf(v0.w, v0.w, vvp);
+            vvp = __builtin_fmaf(v1.x, v1.x, vvp); vvp = __builtin_fmaf(v1.y, v1.y, vvp); vvp = __builtin_fmaf(v1.z, v1.z, vvp); vvp = __builtin_fmaf(v1.w, v1.w, vvp);
         }
-        float r2 = 0.0f, t2 = u1 * u1;
-        int ci = 0;
-        if (lane < static_cast<uint32_t>(DC)) {
-            const float b = a.pca_bias[lane];
-            float c = __builtin_rintf((u0 - b) / a.pca_step);
-            c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
-            if (!(c == c)) c = 0.0f;
-            ci = static_cast<int>(c);
-            const float r = u0 - (b + a.pca_step * c);
+        float u = up + __shfl_xor(up, 32);     // coordinate ci (both halves of the wave hold it)
+        float vv = vvp + __shfl_xor(vvp, 32);  // ||v||^2
+        if constexpr (METRIC == M_COS) {
+            // cosine records hold UNIT vectors: work with the unit query q / ||q|| (two more roundings per coordinate, in `urel`)
+            const float sc = 1.0f / __builtin_sqrtf(vv);
+            u *= sc;
+            vv = vv > 0.0f ? 1.0f : vv; // a zero query gives NaN coordinates: the bound never fires
+        }
+        const bool owner = lane < static_cast<uint32_t>(DC);
+        float r2 = 0.0f, un2 = 0.0f;
+        int cint = 0;
+        if (owner) {
+            float c, uh;
+            if constexpr (METRIC == M_L2) {
+                const float b = a.pca_bias[lane];
+                c = __builtin_rintf((u - b) / a.pca_step);
+                c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
+                if (!(c == c)) c = 0.0f;
+                uh = b + a.pca_step * c;
+            } else {
+                c = __builtin_rintf(u / a.pca_step);
+                c = c < -127.0f ? -127.0f : (c > 127.0f ? 127.0f : c);
+                if (!(c == c)) c = 0.0f;
+                uh = a.pca_step * c;
+            }
+            cint = static_cast<int>(c);
+            const float r = u - uh;
             r2 = r * r;
-        } else {
-            t2 = __builtin_fmaf(u0, u0, t2);
+            un2 = u * u;
         }
-        int qq = ci * ci;
+        int qq = cint * cint;
         for (int off = 32; off >= 1; off >>= 1) {
             r2 += __shfl_xor(r2, off);
-            t2 += __shfl_xor(t2, off);
+            un2 += __shfl_xor(un2, off);
             qq += __shfl_xor(qq, off);
         }
         uint8_t* cb = reinterpret_cast<uint8_t*>(compact);
-        if (lane < 32u) cb[lane] = static_cast<uint8_t>(ci); // lanes 28..31 write 0
+        if (lane < 32u) cb[lane] = static_cast<uint8_t>(cint & 0xFF); // lanes DC..31 write 0
         lds_order();
 #pragma unroll
         for (int w = 0; w < 7; ++w) fq[w] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(compact[w])));
         lds_order();
-        fat_qq = __builtin_amdgcn_readfirstlane(qq);
         const float vn = __builtin_sqrtf(vv) * 1.00001f;
-        const float urel = static_cast<float>(d + 2) * 5.9604645e-8f * 1.01f; // (d + 2) 2^-24
-        float eq = __builtin_sqrtf(r2) * 1.0001f + 5.2915f * urel * vn + a.pca_eq_abs;            // sqrt(28) = 5.2915
-        const float tq = __builtin_sqrtf(t2);
-        float et0 = __builtin_sqrtf(static_cast<float>(d > DC ? d - DC : 1)) * urel * vn + tq * 1.0e-5f + a.pca_tail_unit * 6.0e-8f;
-        if (!(eq < 3.0e38f) || !(et0 < 3.0e38f)) { // non-finite query: the bound never fires
+        const float urel = (static_cast<float>(d + 3 + (METRIC == M_COS ? d / 2 + 6 : 0)) * 5.9604645e-8f) * 1.01f + a.pca_delta; // cosine: + rounding of ||q|| and of the scaling
+        const float erot = __builtin_sqrtf(static_cast<float>(DC)) * urel * vn;
+        const float nu = __builtin_sqrtf(un2);
+        float eq = __builtin_sqrtf(r2) * 1.0001f + erot + a.pca_eq_abs;
+        // remainder norm tq = sqrt(||v||^2 - ||u||^2): a difference of float32 sums, bracketed from both sides
+        const float drel = static_cast<float>(d + 4) * 5.9604645e-8f * 1.01f;
+        const float alo = nu * 0.99999f - erot, ahi = nu * 1.00001f + erot;
+        const float alo2 = alo > 0.0f ? alo * alo : 0.0f;
+        const float thi2 = vv * (1.0f + drel) - alo2, tlo2 = vv * (1.0f - drel) - ahi * ahi;
+        float tq_hi = __builtin_sqrtf(thi2 > 0.0f ? thi2 : 0.0f) * 1.00001f;
+        const float tq_lo = __builtin_sqrtf(tlo2 > 0.0f ? tlo2 : 0.0f) * 0.99999f;
+        if (!(eq < 3.0e38f) || !(tq_hi < 3.0e38f)) { // non-finite query: the bound never fires
             eq = __builtin_inff();
-            et0 = __builtin_inff();
+            tq_hi = __builtin_inff();
         }
-        fat_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, eq)));
-        fat_tq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tq)));
-        fat_et0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, et0)));
-        fat_s2m = a.pca_step * a.pca_step * 0.99999f;
+        auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+        fat_qq = __builtin_amdgcn_readfirstlane(qq);
+        fat_eq = uni(eq);
+        fat_tq_hi = uni(tq_hi);
+        fat_tq_lo = uni(tq_lo);
+        fat_s2m = a.pca_step * a.pca_step * (METRIC == M_L2 ? 0.99999f : 1.0f);
+        fat_nuh = uni(a.pca_step * __builtin_sqrtf(static_cast<float>(qq)) * 1.00001f); // ||uhat|| (signed codes)
+        fat_nq = uni(vn);
     }
 
     // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
@@ -315,7 +338,12 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             buf.size = it_meta[0];
             buf.best_unvisited = it_meta[1];
             const uint2* src = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
-            for (uint32_t i = lane; i < buf.size; i += 64) buf.e[i] = src[i];
+            for (uint32_t i = lane; i < buf.size; i += 64) {
+                const uint2 en = src[i];
+                buf.e[i] = en;
+                nan_seen = nan_seen || __uint_as_float(en.x) != __uint_as_float(en.x);
+            }
+            nan_seen = __ballot(nan_seen) != 0ull; // a NaN left in the buffer by an earlier call
             lds_order();
             wave_std_sort<GREATER>(buf, sort_stack, lane, true);
         } else if (append_then_sort) {
@@ -367,36 +395,67 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 // remembered -- the same table then covers the whole query almost without evictions.  A hit = this id went
                 // through the exact path earlier in this query, re-inserting it would be a no-op.
                 const uint32_t fh = nid & fmask, ftag = nid >> fshift; // 16-bit tags only (the host never asks for 8-bit tags with inline records)
-                if (a.filter_entries != 0u && keep) keep = static_cast<uint32_t>(filt[fh]) != ftag;
+                const bool use_filter = a.filter_entries != 0u && !nan_seen; // with a NaN in the buffer a repeated insert is no longer a no-op
+                if (use_filter && keep) keep = static_cast<uint32_t>(filt[fh]) != ftag;
                 if (full) {
-                    // lower bound of every candidate of this chunk, lane-parallel.  With A = max(0, s sqrt(I) - e), e = eq + ex, and
-                    // B = max(0, | ||u_T|| - ||y_T|| | - slack):  (1 + eps) dist >= A^2 + B^2.  Reject iff A^2 + B^2 > W' := worst (1 + eps) 1.0001,
-                    // which is implied by  s^2 I > W' - B^2 + e (2 sqrt(W') + e)   (sqrt(W' - B^2) <= sqrt(W'): one square root per expansion).
-                    // `worst` can only improve while this expansion's survivors are inserted, so the bound stays valid.
-                    const float wp = worst * (1.0f + a.pca_eps) * 1.0001f;
-                    const float r2 = 2.0f * __builtin_amdgcn_sqrtf(wp) * 1.00001f;
-                    uint32_t dqx = 0u, dxx = 0u;
-                    dqx = __builtin_amdgcn_udot4(rec0.x, fq[0], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.x, rec0.x, dxx, false);
-                    dqx = __builtin_amdgcn_udot4(rec0.y, fq[1], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.y, rec0.y, dxx, false);
-                    dqx = __builtin_amdgcn_udot4(rec0.z, fq[2], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.z, rec0.z, dxx, false);
-                    dqx = __builtin_amdgcn_udot4(rec0.w, fq[3], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.w, rec0.w, dxx, false);
-                    dqx = __builtin_amdgcn_udot4(rec1.x, fq[4], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.x, rec1.x, dxx, false);
-                    dqx = __builtin_amdgcn_udot4(rec1.y, fq[5], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.y, rec1.y, dxx, false);
-                    dqx = __builtin_amdgcn_udot4(rec1.z, fq[6], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.z, rec1.z, dxx, false);
-                    const float fi = static_cast<float>(fat_qq + static_cast<int>(dxx) - 2 * static_cast<int>(dqx)); // sum (cq - cx)^2 < 2^24: exact
-                    const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w & 0xFFFFu))) * a.pca_step;
-                    const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w >> 16))) * a.pca_tail_unit;
-                    const float e = fat_eq + ex;
-                    const float t = __builtin_fabsf(fat_tq - tx) - (fat_et0 + tx * 4.94e-4f); // tx is a nearest float16: 2^-11 relative
-                    const float bb = (t > 0.0f ? t : 0.0f) * 0.99999f;
-                    const float rhs = wp - bb * bb + e * (r2 + e) * 1.00001f;
-                    const bool rej = fi * fat_s2m > rhs; // false for NaN / inf thresholds
+                    // bound of every candidate of this chunk, lane-parallel (svsx_codes.hip has the geometry).  `worst` can only
+                    // improve while this expansion's survivors are inserted, so a bound taken against it stays valid.
+                    bool rej;
+                    if constexpr (METRIC == M_L2) {
+                        // A = max(0, s sqrt(I) - e), e = eq + ex;  B = max(0, |tq - tx| - slack):  dist >= A^2 + B^2.  Reject iff
+                        // A^2 + B^2 > W' := worst * 1.0001, implied by  s^2 I > W' - B^2 + e (2 sqrt(W') + e)  (one square root per hop)
+                        const float wp = worst * 1.0001f;
+                        const float r2 = 2.0f * __builtin_amdgcn_sqrtf(wp) * 1.00001f;
+                        uint32_t dqx = 0u, dxx = 0u;
+                        dqx = __builtin_amdgcn_udot4(rec0.x, fq[0], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.x, rec0.x, dxx, false);
+                        dqx = __builtin_amdgcn_udot4(rec0.y, fq[1], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.y, rec0.y, dxx, false);
+                        dqx = __builtin_amdgcn_udot4(rec0.z, fq[2], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.z, rec0.z, dxx, false);
+                        dqx = __builtin_amdgcn_udot4(rec0.w, fq[3], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.w, rec0.w, dxx, false);
+                        dqx = __builtin_amdgcn_udot4(rec1.x, fq[4], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.x, rec1.x, dxx, false);
+                        dqx = __builtin_amdgcn_udot4(rec1.y, fq[5], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.y, rec1.y, dxx, false);
+                        dqx = __builtin_amdgcn_udot4(rec1.z, fq[6], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.z, rec1.z, dxx, false);
+                        const float fi = static_cast<float>(fat_qq + static_cast<int>(dxx) - 2 * static_cast<int>(dqx)); // sum (cq - cx)^2 < 2^24: exact
+                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w & 0xFFFFu))) * a.pca_step;
+                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w >> 16))) * a.pca_tail_unit;
+                        const float e = fat_eq + ex;
+                        const float txe = tx * 4.94e-4f + a.pca_tail_unit * 6.0e-8f; // tx is a nearest float16: 2^-11 relative
+                        const float t1 = fat_tq_lo - (tx + txe), t2 = (tx - txe) - fat_tq_hi;
+                        const float t = t1 > t2 ? t1 : t2;
+                        const float bb = (t > 0.0f ? t : 0.0f) * 0.99999f;
+                        const float rhs = wp - bb * bb + e * (r2 + e) * 1.00001f;
+                        rej = fi * fat_s2m > rhs; // false for NaN / inf thresholds
+                    } else {
+                        // q . z <= s^2 I + ||uhat|| ex + eq (ny + ex) + tq tx,  I = sum cq cx (exact);  all record fields are upper bounds
+                        int dot = 0;
+                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.x), static_cast<int>(fq[0]), dot, false);
+                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.y), static_cast<int>(fq[1]), dot, false);
+                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.z), static_cast<int>(fq[2]), dot, false);
+                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.w), static_cast<int>(fq[3]), dot, false);
+                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec1.x), static_cast<int>(fq[4]), dot, false);
+                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec1.y), static_cast<int>(fq[5]), dot, false);
+                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec1.z), static_cast<int>(fq[6]), dot, false); // bytes 2, 3 of fq[6] are 0: the f16 above the codes drops out
+                        const float main = fat_s2m * static_cast<float>(dot);
+                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.z >> 16))) * a.pca_step;
+                        const float ny = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w & 0xFFFFu))) * a.pca_step;
+                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w >> 16))) * a.pca_tail_unit;
+                        const float pos = fat_nuh * ex + fat_eq * (ny + ex) + fat_tq_hi * tx;
+                        float ub = main + pos + (__builtin_fabsf(main) + pos) * 4.0e-6f;
+                        if constexpr (METRIC == M_COS) {
+                            // records hold the UNIT vector and the query was scaled to unit norm: `ub` bounds the real cosine; the
+                            // reference's float32 result is within (d + 8) 2^-24 of it (|cos| <= 1)
+                            ub += static_cast<float>(d + 8) * 6.3e-8f + 1.0e-7f;
+                        } else {
+                            // the reference's own float32 accumulation: |computed - real| <= (d + 2) 2^-24 ||q|| ||z||
+                            ub += static_cast<float>(d + 2) * 6.1e-8f * fat_nq * (ny + ex + tx + a.pca_ref_extra);
+                        }
+                        rej = ub < worst; // false whenever anything is NaN / inf
+                    }
                     const uint32_t nrej = __popcll(__ballot(keep && rej));
                     n_code_rej += nrej;
                     n_eval += nrej;
                     keep = keep && !rej;
                 }
-                if (a.filter_entries != 0u && keep) filt[fh] = static_cast<uint16_t>(ftag);
+                if (use_filter && keep) filt[fh] = static_cast<uint16_t>(ftag);
                 const unsigned long long km = __ballot(keep);
                 cnt = __popcll(km);
                 const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
@@ -405,7 +464,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 lds_order();
                 nid = lane < cnt ? compact[lane] : kInvalidId;
                 lds_order();
-            } else if (a.filter_entries != 0u) {
+            } else if (a.filter_entries != 0u && !nan_seen) { // with a NaN in the buffer a repeated insert is no longer a no-op: filter off
                 // emplace_visited (greedy_search.h:191-193): drop ids already evaluated, keep adjacency order
                 bool keep = nid != kInvalidId;
                 if (keep) {
@@ -526,7 +585,8 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                     const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
                     if (full && cmpf<GREATER>(worst, dd)) continue; // worst may have improved within this pass
                     const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
-                    if (wave_insert<GREATER>(buf, dd, id, lane)) {
+                    nan_seen = nan_seen || dd != dd;
+                    if (wave_insert<GREATER>(buf, dd, id, lane, nan_seen)) {
                         ++n_ins;
                         full = buf.size == buf.capacity;
                         if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
@@ -643,10 +703,16 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
     if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
-    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && METRIC == M_L2) {
+    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         if (a.fat != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 2>(a, stream);
         if (a.fat != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 2>(a, stream);
         if (a.fat != nullptr) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+    }
+    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && (DT == DT_I8 || DT == DT_U8)) {
+        if (a.fat != nullptr && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 2>(a, stream);
+        if (a.fat != nullptr) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+    }
+    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && METRIC == M_L2) {
         if (a.codes != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 1>(a, stream);
         if (a.codes != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 1>(a, stream);
     }

@@ -146,13 +146,24 @@ def test_bound_codes_equidistant_candidates(svs, oracle, mode):
 @pytest.mark.parametrize("mode", MODES)
 def test_bound_codes_scope(svs, oracle, small_world, mode):
     sw = small_world
-    idx = svs.VamanaIndex(sw["graph"], sw["x"].astype(np.float16), svs.DistanceCosineSimilarity(), sw["entry"])
-    with pytest.raises(svs.SvsxError) as e:
-        idx.build_bound_codes(mode)
-    assert e.value.code == 3  # NOT_IMPLEMENTED
-    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceIP(), sw["entry"])
-    with pytest.raises(svs.SvsxError):
-        idx.build_bound_codes(mode)
+    if mode == 1:  # 128-byte rows: L2 only
+        idx = svs.VamanaIndex(sw["graph"], sw["x"].astype(np.float16), svs.DistanceCosineSimilarity(), sw["entry"])
+        with pytest.raises(svs.SvsxError) as e:
+            idx.build_bound_codes(mode)
+        assert e.value.code == 3  # NOT_IMPLEMENTED
+        idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceIP(), sw["entry"])
+        with pytest.raises(svs.SvsxError):
+            idx.build_bound_codes(mode)
+    else:          # inline records: not for raw int8 rows, nor for the compressed L2 distance
+        raw = np.clip(np.round(sw["x"] * 400), -128, 127).astype(np.int8)
+        idx = svs.VamanaIndex(sw["graph"], raw, svs.DistanceIP(), sw["entry"])
+        with pytest.raises(svs.SvsxError) as e:
+            idx.build_bound_codes(mode)
+        assert e.value.code == 3
+        codes, sc, bias = oracle.sq_compress(sw["x"], 2)
+        idx = svs.VamanaIndex(sw["graph"], codes, svs.DistanceL2(), sw["entry"], sq=(sc, bias))
+        with pytest.raises(svs.SvsxError):
+            idx.build_bound_codes(mode)
     bad = sw["x"].copy()
     bad[3, 5] = np.inf
     idx = svs.VamanaIndex(sw["graph"], bad, svs.DistanceL2(), sw["entry"])
@@ -181,13 +192,15 @@ def _u64(ids):
     return out
 
 
-def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24):
+def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24, inline=False):
     codes, sc, bias = oracle.sq_compress(x, code_dtype)
     g, e = oracle.build_vamana(metric, x, R=R, L=40)
     fn = svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
     idx = svs.VamanaIndex(g, codes, fn, e, sq=(sc, bias))
     with pytest.raises(svs.SvsxError):
-        idx.build_bound_codes()  # NOT_IMPLEMENTED: measured to buy nothing on these rows
+        idx.build_bound_codes(1)  # 128-byte rows are an L2 / float-row scheme
+    if inline:
+        idx.build_bound_codes(2)  # graph-inline records: upper bound of the similarity from 26 signed codes
     rej = 0
     for w, c, k, vis in configs:
         res, st = idx.search(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
@@ -195,23 +208,83 @@ def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24):
         assert (res.indices == _u64(ids)).all(), (metric, code_dtype, w, c, k, vis)
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, code_dtype, w, c, k, vis)
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
+        if inline:
+            assert "codes=2" in idx.last_kernel_info(), idx.last_kernel_info()
+        rej += int(st[:, 5].sum())
+    return rej
+
+
+@pytest.mark.parametrize("inline", [False, True])
+@pytest.mark.parametrize("metric", [IP, COS])
+@pytest.mark.parametrize("code_dtype", [I8, U8])
+def test_sq_parity_d768_and_ragged(svs, oracle, metric, code_dtype, inline):
+    x = deep_like(1500, 768, 32, seed=61, normalize=False)
+    q = deep_like(24, 768, 32, seed=62, normalize=False)
+    rej = _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS, inline=inline)
+    assert (rej > 1000) == inline
+    x = deep_like(1200, 100, 16, seed=63, normalize=False)  # runtime dimension, ragged tail
+    q = deep_like(24, 100, 16, seed=64, normalize=False)
+    _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS, inline=inline)
+
+
+def _check_float(svs, oracle, metric, x, q, graph, entry, configs, nan_rows=False):
+    """nan_rows: the data holds zero vectors under cosine, i.e. SOME candidates have NaN distances.  A NaN in the buffer breaks its
+    order, and from then on the reference's own answer depends on its visited-set flag (a repeated insert is no longer a no-op);
+    the HIP path then drops its filter and reproduces the flag-off traversal."""
+    fn = svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
+    idx = svs.VamanaIndex(graph, x, fn, entry)
+    idx.build_bound_codes(2)
+    rej = 0
+    for w, c, k, vis in configs:
+        res, st = idx.search(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
+        ids, dists, ost = oracle.search(metric, x, graph, entry, q, k, w, c, visited_set=bool(vis) and not nan_rows, stats=True)
+        assert (res.indices == _u64(ids)).all(), (metric, x.dtype, w, c, k, vis)
+        assert (_bits(res.distances) == _bits(dists)).all(), (metric, x.dtype, w, c, k, vis)
+        assert (st[:, :2] == ost[:, :2]).all()
+        assert "codes=2" in idx.last_kernel_info()
         rej += int(st[:, 5].sum())
     return rej
 
 
 @pytest.mark.parametrize("metric", [IP, COS])
-@pytest.mark.parametrize("code_dtype", [I8, U8])
-def test_sq_parity_d768_and_ragged(svs, oracle, metric, code_dtype):
-    x = deep_like(1500, 768, 32, seed=61, normalize=False)
-    q = deep_like(24, 768, 32, seed=62, normalize=False)
-    _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS)
-    x = deep_like(1200, 100, 16, seed=63, normalize=False)  # runtime dimension, ragged tail
-    q = deep_like(24, 100, 16, seed=64, normalize=False)
-    _check_sq(svs, oracle, metric, x, q, code_dtype, CONFIGS)
+@pytest.mark.parametrize("xdt,qdt", [(np.float32, np.float32), (np.float16, np.float32), (np.float16, np.float16)])
+@pytest.mark.parametrize("d", [96, 128, 100, 40])
+def test_inline_records_inner_product_and_cosine(svs, oracle, metric, xdt, qdt, d):
+    """mode 2 under the similarity metrics: upper bound from signed codes; static (96, 128) and runtime (100, 40) dimensions"""
+    x = deep_like(1500, d, 16, seed=d + metric, normalize=False).astype(xdt)
+    q = deep_like(32, d, 16, seed=d + 7, normalize=False).astype(qdt)
+    g, e = oracle.build_vamana(metric, x, R=24, L=40)
+    rej = _check_float(svs, oracle, metric, x, q, g, e, CONFIGS)
+    assert rej > 500
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_sq_parity_fuzz(svs, oracle, seed):
+def test_inline_records_similarity_fuzz(svs, oracle, seed):
+    """scales from 1e-3 to 1e3, offsets (a dominant mean direction), zero and tiny queries (NaN / unstable cosines), a query
+    opposite to a database point, zero database rows (NaN cosine for that row only)"""
+    rng = np.random.default_rng(300 + seed)
+    d = int(rng.choice([48, 96, 128, 200]))
+    n = int(rng.integers(400, 1400))
+    x = deep_like(n, d, int(rng.integers(4, 40)), seed=seed + 90, normalize=bool(seed & 1))
+    x = (x * np.float32(10.0 ** rng.uniform(-3, 3)) + np.float32(rng.uniform(-1, 1) * (10.0 ** rng.uniform(-2, 1)))).astype(np.float32)
+    if seed % 3 == 0:
+        x[rng.integers(0, n, 6)] = 0.0        # zero rows
+        x[rng.integers(0, n, 4)] *= np.float32(40.0)  # outliers stretch the code range
+    q = x[rng.integers(0, n, 20)] + rng.standard_normal((20, d)).astype(np.float32) * np.float32(np.abs(x).mean() * 0.3)
+    q[0] = 0.0
+    q[1] = rng.standard_normal(d).astype(np.float32) * np.float32(1e-6)
+    q[2] = -x[5]
+    q[3] *= np.float32(1e4)
+    metric = IP if seed % 2 == 0 else COS
+    if seed >= 3:
+        x = x.astype(np.float16)
+    g, e = oracle.build_vamana(metric, x, R=int(rng.integers(8, 40)), L=48)
+    _check_float(svs, oracle, metric, x, q, g, e, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], nan_rows=(seed % 3 == 0 and metric == COS))
+
+
+@pytest.mark.parametrize("inline", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_sq_parity_fuzz(svs, oracle, seed, inline):
     """offsets that make the bias term dominate, tiny and huge scales, queries (nearly) orthogonal to everything, and a zero
     query: cosine then is NaN for every row, which exercises the NaN behaviour of SearchBuffer::insert_inner (ids-only
     duplicate scan, search_buffer.h:377-389)"""
@@ -227,4 +300,4 @@ def test_sq_parity_fuzz(svs, oracle, seed):
     q[3:6] -= q[3:6].mean(axis=1, keepdims=True)  # sum(q) = 0: the bias term vanishes, q.c is all there is
     metric = IP if seed % 2 == 0 else COS
     code_dtype = I8 if seed % 3 else U8
-    _check_sq(svs, oracle, metric, x, q, code_dtype, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)])
+    _check_sq(svs, oracle, metric, x, q, code_dtype, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], inline=inline)

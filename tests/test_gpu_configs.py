@@ -115,6 +115,32 @@ def test_static768_sq_instantiations(svs, oracle, metric, code):
     assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all()
 
 
+def test_inline_record_instantiations_for_configs_3_and_4(svs, oracle, sift_like):
+    """config 3 (f16 IP d=128) and config 4 (SQ-int8 cosine d=768) with graph-inline records: the static instantiations with
+    codes=2 serve the call, answers stay bit-identical to the oracle"""
+    s_ = sift_like
+    idx = svs.VamanaIndex(s_["graph"], s_["x"], svs.DistanceIP(), s_["entry"])
+    idx.build_bound_codes(2)
+    for qdt in (np.float32, np.float16):
+        q = s_["q"].astype(qdt)
+        res, st = idx.search(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(128), 1), stats=True)
+        assert idx.last_kernel_info() == "search_kernel<dt=1,metric=1,qmode=0,ds=128,general=0,codes=2>"
+        ids, dists, ost = oracle.search(IP, s_["x"], s_["graph"], s_["entry"], q, 10, 128, visited_set=True, stats=True)
+        assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all()
+        assert (st[:, :2] == ost[:, :2]).all() and st[:, 5].sum() > 0.5 * st[:, 2].sum()
+    x = deep_like(1200, 768, 32, seed=61, normalize=False)
+    q = deep_like(24, 768, 32, seed=62, normalize=False)
+    for metric in (IP, COS):
+        codes, sc, bias = oracle.sq_compress(x, I8)
+        g, e = oracle.build_vamana(metric, x, R=24, L=40)
+        idx = svs.VamanaIndex(g, codes, _fn(svs, metric), e, sq=(sc, bias))
+        idx.build_bound_codes(2)
+        res, st = idx.search(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(64), 1), stats=True)
+        assert idx.last_kernel_info() == f"search_kernel<dt=2,metric={metric},qmode={2 if metric == IP else 3},ds=768,general=0,codes=2>"
+        ids, dists, ost = oracle.search(metric, codes, g, e, q, 10, 64, visited_set=True, sq=(sc, bias), stats=True)
+        assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all()
+
+
 def test_bound_code_instantiations_are_reported(svs, small_world, world128):
     for w, d in ((small_world, 96), (world128, 128)):
         for ddt, conv in ((F32, lambda a: a), (F16, lambda a: a.astype(np.float16))):

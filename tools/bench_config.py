@@ -77,7 +77,7 @@ def main():
     t_build = time.time() - t0
     idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), a.n, a.d, np_dt, sq=sq)
     if a.bound_codes:
-        idx.build_bound_codes()
+        idx.build_bound_codes(a.bound_codes)
     k = 10
     ids = torch.empty((a.nq, k), dtype=torch.int64, device=dev); dists = torch.empty((a.nq, k), device=dev)
     stats = torch.zeros((a.nq, 6), dtype=torch.int32, device=dev)
@@ -98,14 +98,14 @@ def main():
     if a.bound_codes:  # same index without the bound, for the A/B in one process
         ids_b = ids.clone()
         stats_b = stats.clone()
-        idx.build_bound_codes(False)
+        idx.build_bound_codes(0)
         for _ in range(2): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
         e0.record()
         for _ in range(a.steps): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
         e1.record(); torch.cuda.synchronize()
         ms_plain = e0.elapsed_time(e1) / a.steps
         assert bool((ids == ids_b).all()), "bound codes changed the result"
-        idx.build_bound_codes()
+        idx.build_bound_codes(a.bound_codes)
     out = dict(config=vars(a), build_s=t_build, mean_degree=float((graph[:, :a.degree] >= 0).sum(1).float().mean()), recall_at_10=rec, ms_per_batch=ms,
                qps=a.nq / ms * 1e3, ms_per_batch_without_bound=ms_plain, bound_rejects_per_query=float(stats[:, 5].sum()) / a.nq, evals_per_query=float(stats[:, 2].sum()) / a.nq, expansions=exp / a.nq, slots=slots / a.nq, alg_GB=alg / 1e9, achieved_GBs=alg / ms / 1e6, frac_of_8TBs=alg / ms / 1e6 / 8000)
     if a.cpu:
