@@ -48,6 +48,7 @@ struct svsx_index {
     // graph-inline records (svsx_index_build_bound_codes mode 2; svsx_codes.hip)
     void* d_fat = nullptr;
     size_t fat_stride = 0;
+    uint32_t fat_rb = 32;
     float* d_pca = nullptr;      // [32][dpad] leading directions (float32, row-major, zero padded) | [dpad] mean | [32] bias
     float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_delta = 0.0f, pca_eq_abs = 0.0f, pca_ref_extra = 0.0f;
 };
@@ -335,7 +336,7 @@ float half_bits_to_float(uint16_t h) {
     return f;
 }
 
-constexpr uint32_t kPcaRows = 32;   // rows of the float32 device copy of the directions (rows >= dc are zero)
+constexpr uint32_t kPcaRows = 128;  // rows of the float32 device copy of the directions (rows >= dc are zero)
 
 // modified Gram-Schmidt on the m columns of V (d x m, column j at V[i * m + j]); twice for orthogonality to rounding
 void orthonormalize_columns(std::vector<double>& V, uint32_t d, uint32_t m) {
@@ -362,7 +363,7 @@ int build_fat_rows(svsx_index* ix) {
     const uint32_t d = static_cast<uint32_t>(ix->d), n = static_cast<uint32_t>(ix->n);
     const size_t es = dtype_size(ix->data_dtype);
     const bool l2 = ix->metric == M_L2, cosine = ix->metric == M_COS;
-    const uint32_t dc = l2 ? 28u : 26u;
+    const uint32_t meta = l2 ? 4u : 6u; // bytes of float16 fields at the end of a record
     // 1. sample (evenly strided) -> host, the vector the metric sees (decompressed / normalised), f64
     const size_t want = d <= 128 ? 65536 : (d <= 256 ? 32768 : 8192);
     const size_t ns = n < want ? n : want;
@@ -420,7 +421,11 @@ int build_fat_rows(svsx_index* ix) {
         }
     // 3. leading directions by subspace iteration + Rayleigh-Ritz (ANY orthonormal set is valid for the bound; a good one
     //    makes it tight).  m >= dc columns for convergence margin.
-    const uint32_t m = d < 40u ? d : 40u;
+    // candidate record sizes: a record larger than a sixth of the row it protects cannot pay for itself
+    uint32_t rb_max = 32;
+    if (ix->row_bytes >= 6 * 64) rb_max = 64;
+    if (ix->row_bytes >= 6 * 128) rb_max = 128;
+    const uint32_t m = d < rb_max - meta + 12u ? d : rb_max - meta + 12u;
     std::vector<double> V(static_cast<size_t>(d) * m), W(static_cast<size_t>(d) * m);
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     for (auto& v : V) {
@@ -465,7 +470,22 @@ int build_fat_rows(svsx_index* ix) {
     std::vector<uint32_t> order(m);
     for (uint32_t i = 0; i < m; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return T[static_cast<size_t>(x) * m + x] > T[static_cast<size_t>(y) * m + y]; });
-    const uint32_t dcu = dc < m ? dc : m; // directions really used (d < dc cannot happen: d >= 32)
+    // smallest record whose directions carry >= 95 % of the sample's second moment (the remainder only enters the bound through
+    // the product of remainder norms, which is loose); 32 bytes when nothing larger is allowed
+    double trace = 0.0;
+    for (uint32_t i = 0; i < d; ++i) trace += cov[static_cast<size_t>(i) * d + i];
+    uint32_t rb = 32;
+    for (; rb < rb_max; rb *= 2) {
+        double got = 0.0;
+        for (uint32_t c = 0; c < rb - meta && c < m; ++c) got += std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0);
+        if (got >= 0.95 * trace) break;
+    }
+    if (const char* force = getenv("SVSX_RECORD_BYTES")) { // experiments: 32 / 64 / 128
+        const uint32_t f = static_cast<uint32_t>(atoi(force));
+        if ((f == 32 || f == 64 || f == 128) && f <= rb_max) rb = f;
+    }
+    const uint32_t dc = rb - meta;
+    const uint32_t dcu = dc < m ? dc : m; // directions really used (d < dc cannot happen: d >= 32 and m >= dc unless d is smaller)
     std::vector<double> Q(static_cast<size_t>(d) * dcu), sigma(dcu);
     for (uint32_t c = 0; c < dcu; ++c) {
         for (uint32_t i = 0; i < d; ++i) {
@@ -477,7 +497,7 @@ int build_fat_rows(svsx_index* ix) {
     }
     orthonormalize_columns(Q, d, dcu);
     // device copies: float32 rows for the query side (+ delta = how far they are from the f64 directions), f64 rows for the data side
-    std::vector<float> host(static_cast<size_t>(kPcaRows) * pd + pd + 32, 0.0f); // P | mean | bias
+    std::vector<float> host(static_cast<size_t>(kPcaRows) * pd + pd + 128, 0.0f); // P | mean | bias
     std::vector<double> q64(static_cast<size_t>(dcu) * d);
     double delta = 0.0;
     for (uint32_t c = 0; c < dcu; ++c) {
@@ -500,25 +520,25 @@ int build_fat_rows(svsx_index* ix) {
     HIP_TRY(hipMemcpy(dq.p, q64.data(), q64.size() * sizeof(double), hipMemcpyHostToDevice));
     // 4. per-coordinate range of y over ALL vectors (device), clipped to +-8 sigma; step, biases, tail unit
     DeviceBuffer st;
-    HIP_TRY(st.alloc((2 * 32 + 2) * 4));
-    std::vector<uint32_t> init(2 * 32 + 2, 0u);
-    for (uint32_t i = 0; i < 32; ++i) init[i] = 0xFFFFFFFFu;
+    HIP_TRY(st.alloc((2 * 128 + 2) * 4));
+    std::vector<uint32_t> init(2 * 128 + 2, 0u);
+    for (uint32_t i = 0; i < 128; ++i) init[i] = 0xFFFFFFFFu;
     HIP_TRY(hipMemcpy(st.p, init.data(), init.size() * 4, hipMemcpyHostToDevice));
     PcaArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.dc = dcu;
+    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.dc = dcu; pa.rb = rb;
     pa.decomp = ix->sq_enabled; pa.sq_scale = ix->sq_scale; pa.sq_bias = ix->sq_bias; pa.normalize = cosine ? 1 : 0; pa.signed_codes = l2 ? 0 : 1;
     pa.q64 = static_cast<const double*>(dq.p);
     pa.mean = ix->d_pca + static_cast<size_t>(kPcaRows) * pd; pa.bias = pa.mean + pd;
-    pa.stat_min = static_cast<uint32_t*>(st.p); pa.stat_max = pa.stat_min + 32; pa.stat_tail = pa.stat_max + 32; pa.stat_bad = pa.stat_tail + 1;
+    pa.stat_min = static_cast<uint32_t*>(st.p); pa.stat_max = pa.stat_min + 128; pa.stat_tail = pa.stat_max + 128; pa.stat_bad = pa.stat_tail + 1;
     HIP_TRY(launch_pca_stats(pa, nullptr));
-    std::vector<uint32_t> stats(2 * 32 + 2);
+    std::vector<uint32_t> stats(2 * 128 + 2);
     HIP_TRY(hipMemcpy(stats.data(), st.p, stats.size() * 4, hipMemcpyDeviceToHost));
-    if (stats[2 * 32 + 1] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
+    if (stats[2 * 128 + 1] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
     double range = 0.0, bmax = 0.0;
-    std::vector<float> bias(32, 0.0f);
+    std::vector<float> bias(128, 0.0f);
     for (uint32_t i = 0; i < dcu; ++i) {
-        double lo = pca_key_to_float(stats[i]), hi = pca_key_to_float(stats[32 + i]);
+        double lo = pca_key_to_float(stats[i]), hi = pca_key_to_float(stats[128 + i]);
         if (sigma[i] > 0.0) { // outliers beyond 8 sigma clamp (their coding error is in their own ex)
             lo = std::max(lo, -8.0 * sigma[i]);
             hi = std::min(hi, 8.0 * sigma[i]);
@@ -534,20 +554,20 @@ int build_fat_rows(svsx_index* ix) {
     }
     float stepf = static_cast<float>(range / (l2 ? 255.0 : 127.0));
     if (!(stepf > 0.0f) || !(stepf < 3.0e38f)) stepf = 1.0f;
-    float tail_max = pca_key_to_float(stats[2 * 32]);
+    float tail_max = pca_key_to_float(stats[2 * 128]);
     if (!(tail_max > 0.0f) || !(tail_max < 3.0e38f)) tail_max = 1.0f;
     const float tail_unit = tail_max / 60000.0f;
-    HIP_TRY(hipMemcpy(ix->d_pca + static_cast<size_t>(kPcaRows) * pd + pd, bias.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->d_pca + static_cast<size_t>(kPcaRows) * pd + pd, bias.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
     // 5. records, then node rows
     DeviceBuffer rec;
-    HIP_TRY(rec.alloc(static_cast<size_t>(n) * 32 + 32));
+    HIP_TRY(rec.alloc(static_cast<size_t>(n) * rb + 128));
     pa.step = stepf; pa.tail_unit = tail_unit; pa.records = static_cast<uint32_t*>(rec.p);
     HIP_TRY(launch_pca_encode(pa, nullptr));
-    const size_t fat_stride = (ix->gstride * 36 + 127) & ~size_t(127);
+    const size_t fat_stride = (ix->gstride * (4 + rb) + 127) & ~size_t(127);
     void* fat = nullptr;
     if (hipMalloc(&fat, static_cast<size_t>(n) * fat_stride + 128) != hipSuccess)
         return fail(SVSX_RUNTIME_ERROR, "hipMalloc(%zu) for the graph-inline records failed", static_cast<size_t>(n) * fat_stride);
-    hipError_t e = launch_fat_build(ix->d_graph, static_cast<uint32_t>(ix->gstride), n, rec.p, fat, fat_stride, nullptr);
+    hipError_t e = launch_fat_build(ix->d_graph, static_cast<uint32_t>(ix->gstride), n, rec.p, rb, fat, fat_stride, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipFree(fat);
@@ -555,6 +575,7 @@ int build_fat_rows(svsx_index* ix) {
     }
     ix->d_fat = fat;
     ix->fat_stride = fat_stride;
+    ix->fat_rb = rb;
     ix->pca_step = stepf;
     ix->pca_tail_unit = tail_unit;
     ix->pca_delta = static_cast<float>(delta * 1.01 + 1e-9);
@@ -643,6 +664,7 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     if (ix->d_fat && !a.general) { // graph-inline records: same guarantee, one contiguous block per expansion
         a.fat = static_cast<const unsigned char*>(ix->d_fat);
         a.fat_stride = ix->fat_stride;
+        a.fat_rb = ix->fat_rb;
         a.pca_pd = static_cast<uint32_t>((ix->d + 15) & ~size_t(15));
         a.pca_t = ix->d_pca;
         a.pca_mean = ix->d_pca + static_cast<size_t>(kPcaRows) * a.pca_pd;

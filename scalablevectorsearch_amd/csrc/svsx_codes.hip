@@ -13,9 +13,10 @@
 // For a query with coordinates u and remainder norm tq:
 //     L2      ||q - x||^2  =  ||u - y||^2 + ||r_q - r_x||^2  >=  ||u - y||^2 + (tq - tx)^2
 //     IP/cos  q . z        =  u . y + r_q . r_x             <=  u . y + tq tx
-// Record (32 B), everything rounded in the SAFE direction:
-//     L2      28 x u8 codes c_i = clamp(rint((y_i - b_i) / s), 0, 255) | f16 ex (up) | f16 tx (nearest)
-//     IP/cos  26 x i8 codes c_i = clamp(rint(y_i / s), -127, 127)      | f16 ex (up) | f16 ny (up) | f16 tx (up)
+// Record (RB = 32, 64 or 128 bytes -- the host picks the smallest whose directions carry the sample's energy, svsx_api.hip),
+// everything rounded in the SAFE direction:
+//     L2      (RB - 4) x u8 codes c_i = clamp(rint((y_i - b_i) / s), 0, 255) | f16 ex (up) | f16 tx (nearest)
+//     IP/cos  (RB - 6) x i8 codes c_i = clamp(rint(y_i / s), -127, 127)      | f16 ex (up) | f16 ny (up) | f16 tx (up)
 // ex >= ||y - yhat|| (coding error incl. clamping, in units of s), ny >= ||yhat|| (units of s), tx = ||r|| (units of
 // `tail_unit`).  The kernel (svsx_search.hip, CODES == 2) adds explicit slack for every float rounding on the query side and
 // rejects a candidate only if the bound proves SearchBuffer::can_skip (search_buffer.h:338-340) would drop it anyway.
@@ -26,7 +27,8 @@ namespace svsx {
 
 namespace {
 
-constexpr int kMaxDc = 28;
+constexpr int kMaxDc = 124;  // 128-byte records
+constexpr int kChunk = 31;   // coordinates accumulated per sweep over the vector (registers: 31 doubles per lane)
 
 __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -62,10 +64,10 @@ template <int DT> __device__ __forceinline__ double load_elem(const PcaArgs& a, 
     return static_cast<double>(f);
 }
 
-// Coordinates of one vector: z into LDS (`vs`, d doubles), then y_i = Q_i . z for i < dc (every lane returns all of them in
-// y[]), n2 = ||z||^2.  Lane l owns the elements j = l, l + 64, ...: coalesced reads of the f64 basis rows.
+// Coordinates of one vector: z into LDS (`vs`, d doubles), then y_i = Q_i . z for i < dc into LDS (`ys`), n2 = ||z||^2.
+// Lane l owns the elements j = l, l + 64, ...: coalesced reads of the f64 basis rows; kChunk coordinates per sweep.
 template <int DT>
-__device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned char* row, double* vs, uint32_t lane, double (&y)[kMaxDc], double& n2) {
+__device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned char* row, double* vs, double* ys, uint32_t lane, double& n2) {
     double part = 0.0;
     for (uint32_t j = lane; j < a.d; j += 64) {
         const double z = load_elem<DT>(a, row, j) - static_cast<double>(a.mean[j]);
@@ -76,16 +78,22 @@ __device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned cha
     double scale = 1.0;
     if (a.normalize) scale = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0; // cosine: the unit vector (a zero vector gets ex = inf below)
     __syncthreads();
+    for (uint32_t c0 = 0; c0 < a.dc; c0 += kChunk) {
+        double y[kChunk];
 #pragma unroll
-    for (int i = 0; i < kMaxDc; ++i) y[i] = 0.0;
-    for (uint32_t j = lane; j < a.d; j += 64) {
-        const double z = vs[j] * scale;
+        for (int i = 0; i < kChunk; ++i) y[i] = 0.0;
+        for (uint32_t j = lane; j < a.d; j += 64) {
+            const double z = vs[j] * scale;
 #pragma unroll
-        for (int i = 0; i < kMaxDc; ++i)
-            if (static_cast<uint32_t>(i) < a.dc) y[i] = __builtin_fma(a.q64[static_cast<size_t>(i) * a.d + j], z, y[i]);
+            for (int i = 0; i < kChunk; ++i)
+                if (c0 + static_cast<uint32_t>(i) < a.dc) y[i] = __builtin_fma(a.q64[static_cast<size_t>(c0 + i) * a.d + j], z, y[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const double t = wave_sum(y[i]);
+            if (lane == 0 && c0 + static_cast<uint32_t>(i) < a.dc) ys[c0 + i] = t;
+        }
     }
-#pragma unroll
-    for (int i = 0; i < kMaxDc; ++i) y[i] = wave_sum(y[i]);
     if (a.normalize) n2 = n2 > 0.0 ? 1.0 : 0.0;
     __syncthreads();
 }
@@ -95,33 +103,40 @@ __device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned cha
 // pass 1: per-coordinate min / max of y (order keys), max remainder norm, count of non-finite vectors
 template <int DT> __global__ __launch_bounds__(64) void pca_stats_kernel(const PcaArgs a) {
     extern __shared__ double vs[];
+    double* ys = vs + a.d;
     const uint32_t lane = threadIdx.x;
-    float lo = __builtin_inff(), hi = -__builtin_inff();
+    float lo[2] = {__builtin_inff(), __builtin_inff()}, hi[2] = {-__builtin_inff(), -__builtin_inff()};
     double tmax = 0.0;
     uint32_t bad = 0;
     for (uint32_t r = blockIdx.x; r < a.n; r += gridDim.x) {
-        double y[kMaxDc], n2;
-        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, lane, y, n2);
+        double n2;
+        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, ys, lane, n2);
         double ny2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < kMaxDc; ++i) {
-            if (static_cast<uint32_t>(i) < a.dc) {
-                ny2 += y[i] * y[i];
-                if (lane == static_cast<uint32_t>(i)) {
-                    const float f = static_cast<float>(y[i]);
-                    lo = f < lo ? f : lo;
-                    hi = f > hi ? f : hi;
-                }
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t i = lane + 64u * t;
+            if (i < a.dc) {
+                const double yv = ys[i];
+                ny2 += yv * yv;
+                const float f = static_cast<float>(yv);
+                lo[t] = f < lo[t] ? f : lo[t];
+                hi[t] = f > hi[t] ? f : hi[t];
             }
         }
+        ny2 = wave_sum(ny2);
         if (!(n2 - n2 == 0.0)) bad = 1;
         const double t2 = n2 - ny2;
         const double tn = t2 > 0.0 ? sqrt(t2) : 0.0;
         tmax = tn > tmax ? tn : tmax;
+        __syncthreads();
     }
-    if (lane < a.dc && lo <= hi) {
-        atomicMin(&a.stat_min[lane], f32_order_key(lo));
-        atomicMax(&a.stat_max[lane], f32_order_key(hi));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t i = lane + 64u * t;
+        if (i < a.dc && lo[t] <= hi[t]) {
+            atomicMin(&a.stat_min[i], f32_order_key(lo[t]));
+            atomicMax(&a.stat_max[i], f32_order_key(hi[t]));
+        }
     }
     if (lane == 0) {
         atomicMax(a.stat_tail, f32_order_key(static_cast<float>(tmax) * 1.0000002f));
@@ -129,82 +144,90 @@ template <int DT> __global__ __launch_bounds__(64) void pca_stats_kernel(const P
     }
 }
 
-// pass 2: the 32-byte record of every vector
+// pass 2: the record of every vector (a.rb bytes: codes, then the float16 fields in its last 4 / 6 bytes)
 template <int DT> __global__ __launch_bounds__(64) void pca_encode_kernel(const PcaArgs a) {
     extern __shared__ double vs[];
+    double* ys = vs + a.d;
+    __shared__ uint32_t recw[32];
+    unsigned char* recb = reinterpret_cast<unsigned char*>(recw);
     const uint32_t lane = threadIdx.x;
     const double s = static_cast<double>(a.step), inv = 1.0 / s;
     for (uint32_t r = blockIdx.x; r < a.n; r += gridDim.x) {
-        double y[kMaxDc], n2;
-        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, lane, y, n2);
+        double n2;
+        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, ys, lane, n2);
+        if (lane < 32u) recw[lane] = 0u;
+        __syncthreads();
         double e2 = 0.0, ny2 = 0.0, nh2 = 0.0;
-        uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < kMaxDc; ++i) {
-            if (static_cast<uint32_t>(i) < a.dc) {
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t i = lane + 64u * t;
+            if (i < a.dc) {
+                const double yv = ys[i];
                 double c, yh;
                 if (a.signed_codes) {
-                    c = rint(y[i] * inv);
+                    c = rint(yv * inv);
                     c = c < -127.0 ? -127.0 : (c > 127.0 ? 127.0 : c);
                     if (!(c == c)) c = 0.0;
                     yh = s * c;
                 } else {
                     const double b = static_cast<double>(a.bias[i]);
-                    c = rint((y[i] - b) * inv);
+                    c = rint((yv - b) * inv);
                     c = c < 0.0 ? 0.0 : (c > 255.0 ? 255.0 : c);
                     if (!(c == c)) c = 0.0;
                     yh = b + s * c;
                 }
-                const double rr = y[i] - yh;
+                const double rr = yv - yh;
                 e2 += rr * rr;
-                ny2 += y[i] * y[i];
+                ny2 += yv * yv;
                 nh2 += yh * yh;
-                w[i >> 2] |= (static_cast<uint32_t>(static_cast<int>(c)) & 0xFFu) << (8 * (i & 3));
+                recb[i] = static_cast<unsigned char>(static_cast<int>(c) & 0xFF);
             }
         }
+        e2 = wave_sum(e2);
+        ny2 = wave_sum(ny2);
+        nh2 = wave_sum(nh2);
+        __syncthreads();
         const double t2 = n2 - ny2;
         const double tail = t2 > 0.0 ? sqrt(t2) : 0.0;
         uint16_t exh = half_round_up(sqrt(e2) * inv * (1.0 + 1e-12));
         if (a.normalize && n2 == 0.0) exh = 0x7C00u; // zero vector under cosine: the reference's distance is NaN, never bound it
-        if (a.signed_codes) { // 26 codes | ex | ny | tx, all upper bounds
-            const uint16_t nyh = half_round_up(sqrt(nh2) * inv * (1.0 + 1e-12));
-            const uint16_t txh = half_round_up(tail / static_cast<double>(a.tail_unit) * (1.0 + 1e-12));
-            w[6] = (w[6] & 0xFFFFu) | (static_cast<uint32_t>(exh) << 16);
-            w[7] = static_cast<uint32_t>(nyh) | (static_cast<uint32_t>(txh) << 16);
-        } else {              // 28 codes | ex (up) | tx (nearest)
-            const _Float16 txn = static_cast<_Float16>(static_cast<float>(tail / static_cast<double>(a.tail_unit)));
-            w[7] = static_cast<uint32_t>(exh) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, txn)) << 16);
+        const uint32_t nw = a.rb / 4u;
+        if (lane == 0) {
+            if (a.signed_codes) { // codes | ex | ny | tx, all upper bounds
+                const uint16_t nyh = half_round_up(sqrt(nh2) * inv * (1.0 + 1e-12));
+                const uint16_t txh = half_round_up(tail / static_cast<double>(a.tail_unit) * (1.0 + 1e-12));
+                recw[nw - 2] = (recw[nw - 2] & 0xFFFFu) | (static_cast<uint32_t>(exh) << 16);
+                recw[nw - 1] = static_cast<uint32_t>(nyh) | (static_cast<uint32_t>(txh) << 16);
+            } else {              // codes | ex (up) | tx (nearest)
+                const _Float16 txn = static_cast<_Float16>(static_cast<float>(tail / static_cast<double>(a.tail_unit)));
+                recw[nw - 1] = static_cast<uint32_t>(exh) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, txn)) << 16);
+            }
         }
-        if (lane < 8) {
-            uint32_t mine = 0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) mine = lane == static_cast<uint32_t>(t) ? w[t] : mine;
-            a.records[static_cast<size_t>(r) * 8 + lane] = mine;
-        }
+        __syncthreads();
+        if (lane < nw) a.records[static_cast<size_t>(r) * nw + lane] = recw[lane];
+        __syncthreads();
     }
 }
 
-// pass 3: node v -> [ids of chunk | plane 0 (first 16 B of each neighbour's record) | plane 1] per chunk of <= 64 slots
+// pass 3: node v -> per chunk of <= 64 slots [ids | plane 0 | ... | plane RW-1]; plane p = bytes [16p, 16p + 16) of each
+// neighbour's record, so that one load instruction of the search kernel reads one contiguous plane
 __global__ __launch_bounds__(64) void fat_build_kernel(const uint32_t* __restrict__ graph, uint32_t gstride, uint32_t n, const uint4* __restrict__ records,
-                                                       unsigned char* __restrict__ fat, size_t fat_stride) {
+                                                       uint32_t rw, unsigned char* __restrict__ fat, size_t fat_stride) {
     const uint32_t lane = threadIdx.x;
     for (uint32_t v = blockIdx.x; v < n; v += gridDim.x) {
         unsigned char* out = fat + static_cast<size_t>(v) * fat_stride;
         for (uint32_t gbase = 0; gbase < gstride; gbase += 64) {
             const uint32_t cs = (gstride - gbase) < 64u ? (gstride - gbase) : 64u;
-            uint32_t* ids = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(gbase) * 36u);
-            uint4* p0 = reinterpret_cast<uint4*>(ids + cs);
-            uint4* p1 = p0 + cs;
+            uint32_t* ids = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(gbase) * (4u + 16u * rw));
+            uint4* planes = reinterpret_cast<uint4*>(ids + cs);
             if (lane < cs) {
                 const uint32_t nb = graph[static_cast<size_t>(v) * gstride + gbase + lane];
-                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
-                if (nb != kInvalidId) {
-                    r0 = records[static_cast<size_t>(nb) * 2];
-                    r1 = records[static_cast<size_t>(nb) * 2 + 1];
-                }
                 ids[lane] = nb;
-                p0[lane] = r0;
-                p1[lane] = r1;
+                for (uint32_t p = 0; p < rw; ++p) {
+                    uint4 r = make_uint4(0, 0, 0, 0);
+                    if (nb != kInvalidId) r = records[static_cast<size_t>(nb) * rw + p];
+                    planes[static_cast<size_t>(p) * cs + lane] = r;
+                }
             }
         }
     }
@@ -227,8 +250,8 @@ float pca_key_to_float(uint32_t k) {
 static uint32_t grid_for(uint32_t n) { return n < 32768u ? (n ? n : 1u) : 32768u; }
 
 template <int DT> static hipError_t launch_both(const PcaArgs& a, bool encode, hipStream_t stream) {
-    const size_t lds = static_cast<size_t>(a.d) * sizeof(double);
-    if (lds > 64 * 1024 || a.dc > static_cast<uint32_t>(kMaxDc)) return hipErrorInvalidValue;
+    const size_t lds = (static_cast<size_t>(a.d) + 128) * sizeof(double);
+    if (lds > 60 * 1024 || a.dc > static_cast<uint32_t>(kMaxDc) || (a.rb != 32 && a.rb != 64 && a.rb != 128)) return hipErrorInvalidValue;
     if (encode) hipLaunchKernelGGL(pca_encode_kernel<DT>, dim3(grid_for(a.n)), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL(pca_stats_kernel<DT>, dim3(grid_for(a.n)), dim3(64), lds, stream, a);
     return hipGetLastError();
@@ -247,8 +270,9 @@ static hipError_t launch_by_dtype(const PcaArgs& a, bool encode, hipStream_t str
 hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream) { return launch_by_dtype(a, false, stream); }
 hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream) { return launch_by_dtype(a, true, stream); }
 
-hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, void* d_fat, size_t fat_stride, hipStream_t stream) {
-    hipLaunchKernelGGL(fat_build_kernel, dim3(grid_for(n)), dim3(64), 0, stream, d_graph, gstride, n, static_cast<const uint4*>(d_records),
+hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, uint32_t record_bytes, void* d_fat, size_t fat_stride,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(fat_build_kernel, dim3(grid_for(n)), dim3(64), 0, stream, d_graph, gstride, n, static_cast<const uint4*>(d_records), record_bytes / 16u,
                        static_cast<unsigned char*>(d_fat), fat_stride);
     return hipGetLastError();
 }

@@ -43,9 +43,10 @@ struct SearchArgs {
     // graph-inline records (svsx_codes.hip; CODES == 2): node rows [ids | plane 0 | plane 1] per chunk of <= 64 slots
     const unsigned char* fat;
     size_t fat_stride;        // bytes per node
-    const float* pca_t;       // [32][pca_pd] leading directions, row-major float32 (rows >= dc are zero), pca_pd = d rounded up to 16
+    uint32_t fat_rb;          // record bytes: 32 / 64 / 128
+    const float* pca_t;       // [128][pca_pd] leading directions, row-major float32 (rows >= dc are zero), pca_pd = d rounded up to 16
     const float* pca_mean;    // [pca_pd] (zeros unless L2)
-    const float* pca_bias;    // [32] per-coordinate code bias (L2)
+    const float* pca_bias;    // [128] per-coordinate code bias (L2)
     uint32_t pca_pd;
     float pca_step;           // s
     float pca_tail_unit;      // tx = half(tx16) * tail_unit
@@ -172,7 +173,7 @@ struct PcaArgs {
     const void* data;
     size_t row_bytes;
     int dtype;
-    uint32_t n, d, dc;      // dc = coded coordinates (28 unsigned / 26 signed)
+    uint32_t n, d, dc, rb;  // rb = record bytes (32 / 64 / 128); dc = coded coordinates = rb - 4 (unsigned codes) / rb - 6 (signed)
     int decomp;             // rows are scalar-quantized codes: decompress scale * c + bias in float32 first
     float sq_scale, sq_bias;
     int normalize;          // cosine: code the unit vector
@@ -185,11 +186,12 @@ struct PcaArgs {
     uint32_t* stat_max;     // [dc] order keys (stats; init 0)
     uint32_t* stat_tail;    // max remainder norm key (init 0)
     uint32_t* stat_bad;     // vectors with a non-finite component (init 0)
-    uint32_t* records;      // [n][8]          (encode)
+    uint32_t* records;      // [n][rb / 4]     (encode)
 };
 hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream);
 hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream);
-hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, void* d_fat, size_t fat_stride, hipStream_t stream);
+hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, uint32_t record_bytes, void* d_fat, size_t fat_stride,
+                            hipStream_t stream);
 float pca_key_to_float(uint32_t key);
 hipError_t launch_set_word(int* d_word, int value, hipStream_t stream); // one agent-scope store (cancellation)
 // name of the search_kernel instantiation launch_search picked last on this thread (tests assert which one ran)

@@ -39,6 +39,10 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
 __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
+    // CODES: 0 none, 1 128-byte code rows (svsx_distance.hip), 2 / 3 / 4 graph-inline records of 32 / 64 / 128 bytes (svsx_codes.hip)
+    constexpr bool FAT = CODES >= 2;
+    constexpr int RW = FAT ? (2 << (CODES - 2)) : 2;              // 16-byte planes per record
+    constexpr int FDC = RW * 16 - (METRIC == M_L2 ? 4 : 6);       // coded coordinates per record
     constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     constexpr bool B8 = !INTPATH && use_block_cyclic<DT>();  // 8-bit rows on the float path: block-cyclic mapping
     constexpr int G = (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     const bool tag8 = a.filter_tag8 != 0u;
     const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES != 0) ? 256u : 0u)); // GENERAL only
+    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + 256u); // FAT: the query's own record codes (128 B)
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES != 0) ? 256u : 0u) + (FAT ? 128u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -164,70 +169,74 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     uint32_t fq[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
     [[maybe_unused]] int fat_qq = 0;
     [[maybe_unused]] float fat_eq = 0.0f, fat_tq_hi = 0.0f, fat_tq_lo = 0.0f, fat_s2m = 0.0f, fat_nuh = 0.0f, fat_nq = 0.0f;
-    if constexpr (CODES == 2) {
-        constexpr int DC = METRIC == M_L2 ? 28 : 26;
-        const uint32_t ci = lane & 31u, half = lane >> 5; // lane -> coordinate ci, half of the element range
+    if constexpr (FAT) {
+        constexpr int DC = FDC;
+        const uint32_t ci = lane & 31u, half = lane >> 5; // lane -> coordinate ci (+ 32 per group), half of the element range
         const int hlen = dpad >> 1;                       // dpad is a multiple of 16 -> 8-float steps
-        const float4* prow = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(ci) * a.pca_pd + half * hlen);
         const float* qh = qf + half * hlen;
         const float* mh = a.pca_mean + half * hlen;
-        float up = 0.0f, vvp = 0.0f;
+        float r2 = 0.0f, un2 = 0.0f, vv = 0.0f;
+        int qq = 0;
+        if (lane < 32u) qcodes[lane] = 0u;
+        lds_order();
 #pragma unroll 1
-        for (int j0 = 0; j0 < hlen; j0 += 8) { // rolled: the projection must not raise the kernel's register peak
-            const float4 p0 = prow[j0 >> 2], p1 = prow[(j0 >> 2) + 1];
-            float4 v0 = *reinterpret_cast<const float4*>(qh + j0), v1 = *reinterpret_cast<const float4*>(qh + j0 + 4);
-            if constexpr (METRIC == M_L2) {
-                const float4 m0 = *reinterpret_cast<const float4*>(mh + j0), m1 = *reinterpret_cast<const float4*>(mh + j0 + 4);
-                v0.x -= m0.x; v0.y -= m0.y; v0.z -= m0.z; v0.w -= m0.w;
-                v1.x -= m1.x; v1.y -= m1.y; v1.z -= m1.z; v1.w -= m1.w;
+        for (int g = 0; g * 32 < DC; ++g) { // 32 coordinates per sweep over the query
+            const float4* prow = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(ci + 32u * g) * a.pca_pd + half * hlen);
+            float up = 0.0f, vvp = 0.0f;
+#pragma unroll 1
+            for (int j0 = 0; j0 < hlen; j0 += 8) { // rolled: the projection must not raise the kernel's register peak
+                const float4 p0 = prow[j0 >> 2], p1 = prow[(j0 >> 2) + 1];
+                float4 v0 = *reinterpret_cast<const float4*>(qh + j0), v1 = *reinterpret_cast<const float4*>(qh + j0 + 4);
+                if constexpr (METRIC == M_L2) {
+                    const float4 m0 = *reinterpret_cast<const float4*>(mh + j0), m1 = *reinterpret_cast<const float4*>(mh + j0 + 4);
+                    v0.x -= m0.x; v0.y -= m0.y; v0.z -= m0.z; v0.w -= m0.w;
+                    v1.x -= m1.x; v1.y -= m1.y; v1.z -= m1.z; v1.w -= m1.w;
+                }
+                up = __builtin_fmaf(p0.x, v0.x, up); up = __builtin_fmaf(p0.y, v0.y, up); up = __builtin_fmaf(p0.z, v0.z, up); up = __builtin_fmaf(p0.w, v0.w, up);
+                up = __builtin_fmaf(p1.x, v1.x, up); up = __builtin_fmaf(p1.y, v1.y, up); up = __builtin_fmaf(p1.z, v1.z, up); up = __builtin_fmaf(p1.w, v1.w, up);
+                vvp = __builtin_fmaf(v0.x, v0.x, vvp); vvp = __builtin_fmaf(v0.y, v0.y, vvp); vvp = __builtin_fmaf(v0.z, v0.z, vvp); vvp = __builtin_fmaf(v0.w, v0.w, vvp);
+                vvp = __builtin_fmaf(v1.x, v1.x, vvp); vvp = __builtin_fmaf(v1.y, v1.y, vvp); vvp = __builtin_fmaf(v1.z, v1.z, vvp); vvp = __builtin_fmaf(v1.w, v1.w, vvp);
             }
-            up = __builtin_fmaf(p0.x, v0.x, up); up = __builtin_fmaf(p0.y, v0.y, up); up = __builtin_fmaf(p0.z, v0.z, up); up = __builtin_fmaf(p0.w, v0.w, up);
-            up = __builtin_fmaf(p1.x, v1.x, up); up = __builtin_fmaf(p1.y, v1.y, up); up = __builtin_fmaf(p1.z, v1.z, up); up = __builtin_fmaf(p1.w, v1.w, up);
-            vvp = __builtin_fmaf(v0.x, v0.x, vvp); vvp = __builtin_fmaf(v0.y, v0.y, vvp); vvp = __builtin_fmaf(v0.z, v0.z, vvp); vvp = __builtin_fmaf(v0.w, v0.w, vvp);
-            vvp = __builtin_fmaf(v1.x, v1.x, vvp); vvp = __builtin_fmaf(v1.y, v1.y, vvp); vvp = __builtin_fmaf(v1.z, v1.z, vvp); vvp = __builtin_fmaf(v1.w, v1.w, vvp);
-        }
-        float u = up + __shfl_xor(up, 32);     // coordinate ci (both halves of the wave hold it)
-        float vv = vvp + __shfl_xor(vvp, 32);  // ||v||^2
-        if constexpr (METRIC == M_COS) {
-            // cosine records hold UNIT vectors: work with the unit query q / ||q|| (two more roundings per coordinate, in `urel`)
-            const float sc = 1.0f / __builtin_sqrtf(vv);
-            u *= sc;
-            vv = vv > 0.0f ? 1.0f : vv; // a zero query gives NaN coordinates: the bound never fires
-        }
-        const bool owner = lane < static_cast<uint32_t>(DC);
-        float r2 = 0.0f, un2 = 0.0f;
-        int cint = 0;
-        if (owner) {
-            float c, uh;
-            if constexpr (METRIC == M_L2) {
-                const float b = a.pca_bias[lane];
-                c = __builtin_rintf((u - b) / a.pca_step);
-                c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
-                if (!(c == c)) c = 0.0f;
-                uh = b + a.pca_step * c;
-            } else {
-                c = __builtin_rintf(u / a.pca_step);
-                c = c < -127.0f ? -127.0f : (c > 127.0f ? 127.0f : c);
-                if (!(c == c)) c = 0.0f;
-                uh = a.pca_step * c;
+            float u = up + __shfl_xor(up, 32);     // coordinate ci + 32 g (both halves of the wave hold it)
+            vv = vvp + __shfl_xor(vvp, 32);        // ||v||^2 (the same in every sweep)
+            if constexpr (METRIC == M_COS) {
+                // cosine records hold UNIT vectors: work with the unit query q / ||q|| (two more roundings per coordinate, in `urel`)
+                u *= 1.0f / __builtin_sqrtf(vv);
             }
-            cint = static_cast<int>(c);
-            const float r = u - uh;
-            r2 = r * r;
-            un2 = u * u;
+            const uint32_t coord = ci + 32u * static_cast<uint32_t>(g);
+            if (half == 0u && coord < static_cast<uint32_t>(DC)) {
+                float c, uh;
+                if constexpr (METRIC == M_L2) {
+                    const float b = a.pca_bias[coord];
+                    c = __builtin_rintf((u - b) / a.pca_step);
+                    c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
+                    if (!(c == c)) c = 0.0f;
+                    uh = b + a.pca_step * c;
+                } else {
+                    c = __builtin_rintf(u / a.pca_step);
+                    c = c < -127.0f ? -127.0f : (c > 127.0f ? 127.0f : c);
+                    if (!(c == c)) c = 0.0f;
+                    uh = a.pca_step * c;
+                }
+                const int cint = static_cast<int>(c);
+                const float r = u - uh;
+                r2 = __builtin_fmaf(r, r, r2);
+                un2 = __builtin_fmaf(u, u, un2);
+                qq += cint * cint;
+                reinterpret_cast<uint8_t*>(qcodes)[coord] = static_cast<uint8_t>(cint & 0xFF);
+            }
         }
-        int qq = cint * cint;
+        if constexpr (METRIC == M_COS) vv = vv > 0.0f ? 1.0f : vv; // a zero query gives NaN coordinates: the bound never fires
         for (int off = 32; off >= 1; off >>= 1) {
             r2 += __shfl_xor(r2, off);
             un2 += __shfl_xor(un2, off);
             qq += __shfl_xor(qq, off);
         }
-        uint8_t* cb = reinterpret_cast<uint8_t*>(compact);
-        if (lane < 32u) cb[lane] = static_cast<uint8_t>(cint & 0xFF); // lanes DC..31 write 0
         lds_order();
+        if constexpr (RW == 2) { // 32-byte records: the query's code words live in SGPRs
 #pragma unroll
-        for (int w = 0; w < 7; ++w) fq[w] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(compact[w])));
-        lds_order();
+            for (int w = 0; w < 7; ++w) fq[w] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(qcodes[w])));
+        }
         const float vn = __builtin_sqrtf(vv) * 1.00001f;
         const float urel = (static_cast<float>(d + 3 + (METRIC == M_COS ? d / 2 + 6 : 0)) * 5.9604645e-8f) * 1.01f + a.pca_delta; // cosine: + rounding of ||q|| and of the scaling
         const float erot = __builtin_sqrtf(static_cast<float>(DC)) * urel * vn;
@@ -371,16 +380,18 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
         const uint32_t* grow = a.graph + static_cast<size_t>(node) * a.gstride;
         for (uint32_t gbase = 0; gbase < a.gstride; gbase += 64) {
             uint32_t nid = kInvalidId;
-            [[maybe_unused]] uint4 rec0 = make_uint4(0u, 0u, 0u, 0u), rec1 = make_uint4(0u, 0u, 0u, 0u);
-            if constexpr (CODES == 2) {
-                // one contiguous block per chunk: [ids | plane 0 | plane 1]; lane c owns neighbour c and its 32-byte record
+            [[maybe_unused]] uint4 rec[RW];
+#pragma unroll
+            for (int p = 0; p < RW; ++p) rec[p] = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (FAT) {
+                // one contiguous block per chunk: [ids | plane 0 | ... | plane RW-1]; lane c owns neighbour c and its record
                 const uint32_t cs = (a.gstride - gbase) < 64u ? (a.gstride - gbase) : 64u;
-                const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(gbase) * 36u);
-                const uint4* p0 = reinterpret_cast<const uint4*>(fids + cs);
+                const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(gbase) * (4u + 16u * RW));
+                const uint4* planes = reinterpret_cast<const uint4*>(fids + cs);
                 if (lane < cs) {
                     nid = fids[lane];
-                    rec0 = p0[lane];
-                    rec1 = p0[cs + lane];
+#pragma unroll
+                    for (int p = 0; p < RW; ++p) rec[p] = planes[static_cast<uint32_t>(p) * cs + lane];
                 }
             } else {
                 if (gbase + lane < a.gstride) nid = grow[gbase + lane];
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             const uint32_t deg_here = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
             n_slots += deg_here;
             uint32_t cnt = deg_here;
-            if constexpr (CODES == 2) {
+            if constexpr (FAT) {
                 bool keep = nid != kInvalidId;
                 // visited filter (greedy_search.h:191-193), here holding only the ids whose rows were really fetched: a candidate the
                 // bound rejected is rejected again by the bound (worst only improves) at no memory cost, so it need not be
@@ -401,22 +412,38 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                     // bound of every candidate of this chunk, lane-parallel (svsx_codes.hip has the geometry).  `worst` can only
                     // improve while this expansion's survivors are inserted, so a bound taken against it stays valid.
                     bool rej;
+                    constexpr int NW = RW * 4;  // words per record; the last one holds float16 fields
+                    auto recw = [&](int w) -> uint32_t {
+                        const uint4& r = rec[w >> 2];
+                        return (w & 3) == 0 ? r.x : (w & 3) == 1 ? r.y : (w & 3) == 2 ? r.z : r.w;
+                    };
+                    uint32_t qw[NW];
+                    if constexpr (RW == 2) {
+#pragma unroll
+                        for (int w = 0; w < 7; ++w) qw[w] = fq[w];
+                        qw[7] = 0u;
+                    } else { // larger records: the query's code words come from LDS (broadcast reads)
+#pragma unroll
+                        for (int p = 0; p < RW; ++p) {
+                            const uint4 q4 = reinterpret_cast<const uint4*>(qcodes)[p];
+                            qw[4 * p] = q4.x; qw[4 * p + 1] = q4.y; qw[4 * p + 2] = q4.z; qw[4 * p + 3] = q4.w;
+                        }
+                    }
+                    const uint32_t last = recw(NW - 1), prev = recw(NW - 2);
                     if constexpr (METRIC == M_L2) {
                         // A = max(0, s sqrt(I) - e), e = eq + ex;  B = max(0, |tq - tx| - slack):  dist >= A^2 + B^2.  Reject iff
                         // A^2 + B^2 > W' := worst * 1.0001, implied by  s^2 I > W' - B^2 + e (2 sqrt(W') + e)  (one square root per hop)
                         const float wp = worst * 1.0001f;
                         const float r2 = 2.0f * __builtin_amdgcn_sqrtf(wp) * 1.00001f;
                         uint32_t dqx = 0u, dxx = 0u;
-                        dqx = __builtin_amdgcn_udot4(rec0.x, fq[0], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.x, rec0.x, dxx, false);
-                        dqx = __builtin_amdgcn_udot4(rec0.y, fq[1], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.y, rec0.y, dxx, false);
-                        dqx = __builtin_amdgcn_udot4(rec0.z, fq[2], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.z, rec0.z, dxx, false);
-                        dqx = __builtin_amdgcn_udot4(rec0.w, fq[3], dqx, false); dxx = __builtin_amdgcn_udot4(rec0.w, rec0.w, dxx, false);
-                        dqx = __builtin_amdgcn_udot4(rec1.x, fq[4], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.x, rec1.x, dxx, false);
-                        dqx = __builtin_amdgcn_udot4(rec1.y, fq[5], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.y, rec1.y, dxx, false);
-                        dqx = __builtin_amdgcn_udot4(rec1.z, fq[6], dqx, false); dxx = __builtin_amdgcn_udot4(rec1.z, rec1.z, dxx, false);
+#pragma unroll
+                        for (int w = 0; w < NW - 1; ++w) {
+                            dqx = __builtin_amdgcn_udot4(recw(w), qw[w], dqx, false);
+                            dxx = __builtin_amdgcn_udot4(recw(w), recw(w), dxx, false);
+                        }
                         const float fi = static_cast<float>(fat_qq + static_cast<int>(dxx) - 2 * static_cast<int>(dqx)); // sum (cq - cx)^2 < 2^24: exact
-                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w & 0xFFFFu))) * a.pca_step;
-                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w >> 16))) * a.pca_tail_unit;
+                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last & 0xFFFFu))) * a.pca_step;
+                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last >> 16))) * a.pca_tail_unit;
                         const float e = fat_eq + ex;
                         const float txe = tx * 4.94e-4f + a.pca_tail_unit * 6.0e-8f; // tx is a nearest float16: 2^-11 relative
                         const float t1 = fat_tq_lo - (tx + txe), t2 = (tx - txe) - fat_tq_hi;
@@ -427,17 +454,13 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                     } else {
                         // q . z <= s^2 I + ||uhat|| ex + eq (ny + ex) + tq tx,  I = sum cq cx (exact);  all record fields are upper bounds
                         int dot = 0;
-                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.x), static_cast<int>(fq[0]), dot, false);
-                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.y), static_cast<int>(fq[1]), dot, false);
-                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.z), static_cast<int>(fq[2]), dot, false);
-                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec0.w), static_cast<int>(fq[3]), dot, false);
-                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec1.x), static_cast<int>(fq[4]), dot, false);
-                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec1.y), static_cast<int>(fq[5]), dot, false);
-                        dot = __builtin_amdgcn_sdot4(static_cast<int>(rec1.z), static_cast<int>(fq[6]), dot, false); // bytes 2, 3 of fq[6] are 0: the f16 above the codes drops out
+#pragma unroll
+                        for (int w = 0; w < NW - 1; ++w) // word NW-2: codes in its low half, a float16 above -- the query's bytes there are 0
+                            dot = __builtin_amdgcn_sdot4(static_cast<int>(recw(w)), static_cast<int>(qw[w]), dot, false);
                         const float main = fat_s2m * static_cast<float>(dot);
-                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.z >> 16))) * a.pca_step;
-                        const float ny = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w & 0xFFFFu))) * a.pca_step;
-                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(rec1.w >> 16))) * a.pca_tail_unit;
+                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(prev >> 16))) * a.pca_step;
+                        const float ny = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last & 0xFFFFu))) * a.pca_step;
+                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last >> 16))) * a.pca_tail_unit;
                         const float pos = fat_nuh * ex + fat_eq * (ny + ex) + fat_tq_hi * tx;
                         float ub = main + pos + (__builtin_fabsf(main) + pos) * 4.0e-6f;
                         if constexpr (METRIC == M_COS) {
@@ -690,7 +713,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (GENERAL ? 64 * 8 : 0);
+                       ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (CODES >= 2 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES>;
     if (lds > 48 * 1024) {
@@ -704,13 +727,19 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
     if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
-        if (a.fat != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 2>(a, stream);
-        if (a.fat != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 2>(a, stream);
-        if (a.fat != nullptr) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 32 && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 32 && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 32) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 64) return launch_one<DT, METRIC, QMODE, 0, false, 3>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
     }
     if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && (DT == DT_I8 || DT == DT_U8)) {
-        if (a.fat != nullptr && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 2>(a, stream);
-        if (a.fat != nullptr) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 32 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 32) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 64 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 3>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 64) return launch_one<DT, METRIC, QMODE, 0, false, 3>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 128 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 4>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
     }
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && METRIC == M_L2) {
         if (a.codes != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 1>(a, stream);

@@ -1,5 +1,7 @@
 """Bound codes (svsx_index_build_bound_codes): lower-bound rejection must be result-neutral -- ids, distance bits and the
 traversal (expansions, candidates evaluated) identical to the oracle, on benign and on adversarial inputs."""
+import re
+
 import numpy as np
 import pytest
 
@@ -37,7 +39,7 @@ def _check(svs, oracle, x, graph, entry, q, configs, expect_rejects=True, mode=1
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
         if not vis:
             assert (st[:, 2] == ost[:, 2]).all()  # every candidate is still accounted for
-        assert f"codes={mode}" in idx.last_kernel_info(), idx.last_kernel_info()
+        assert re.search(r"codes=[234]>" if mode == 2 else r"codes=1>", idx.last_kernel_info()), idx.last_kernel_info()
         rej += int(st[:, 5].sum())
     if expect_rejects:
         assert rej > 0
@@ -209,7 +211,7 @@ def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24, inline=False
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, code_dtype, w, c, k, vis)
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
         if inline:
-            assert "codes=2" in idx.last_kernel_info(), idx.last_kernel_info()
+            assert re.search(r"codes=[234]>", idx.last_kernel_info()), idx.last_kernel_info()  # 32- / 64- / 128-byte records
         rej += int(st[:, 5].sum())
     return rej
 
@@ -241,7 +243,7 @@ def _check_float(svs, oracle, metric, x, q, graph, entry, configs, nan_rows=Fals
         assert (res.indices == _u64(ids)).all(), (metric, x.dtype, w, c, k, vis)
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, x.dtype, w, c, k, vis)
         assert (st[:, :2] == ost[:, :2]).all()
-        assert "codes=2" in idx.last_kernel_info()
+        assert re.search(r"codes=[234]>", idx.last_kernel_info())
         rej += int(st[:, 5].sum())
     return rej
 
