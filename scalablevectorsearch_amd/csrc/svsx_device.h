@@ -831,28 +831,33 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
 // equal distance keep adjacency order, whatever ends at position >= capacity is dropped (a candidate that loses against a
 // `worst` that improved inside the pass would have been dropped, or pushed out, anyway), and best_unvisited = min(old, position
 // of the best new entry), which is the smallest position any of the sequential inserts reports.
-// Preconditions: capacity <= 128 (two entries per lane), no NaN distance in the buffer, candidate distances finite (empty slots
+// Preconditions: capacity <= 64 EPL (EPL entries per lane), no NaN distance in the buffer, candidate distances finite (empty slots
 // are modelled as +-inf sentinels; comparisons must be a strict weak order).  Returns false -- with LDS untouched -- if a candidate duplicates a buffer entry (same id at equal
 // distance, search_buffer.h:377-389); the caller then takes the sequential path for this pass.
-template <bool GREATER>
+template <bool GREATER, int EPL>
 __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted) {
-    // Written to stay off the scalar unit (one SALU issue slot per CU per cycle is the scarce resource of this kernel): no
-    // boolean mask algebra -- validity is folded into sentinel values, counters advance with carry-in adds, the tie rule of
-    // the candidate ranks is one 64-bit compare of (order key, lane).
-    const uint32_t i0 = lane, i1 = lane + 64u;
-    const bool v0 = i0 < b.size, v1 = i1 < b.size;
+    // EPL buffer entries per lane (capacity <= 64 EPL).  Written to stay off the scalar unit (one SALU issue slot per CU per
+    // cycle is the scarce resource of this kernel): no boolean mask algebra -- validity is folded into sentinel values, counters
+    // advance with carry-in adds, the tie rule of the candidate ranks is one 64-bit compare of (order key, lane).
     constexpr float kPast = GREATER ? -__builtin_inff() : __builtin_inff(); // no candidate compares better than an empty slot
-    uint2 e0 = make_uint2(__float_as_uint(kPast), kInvalidId), e1 = e0;
-    if (v0) e0 = b.e[i0];
-    if (v1) e1 = b.e[i1];
-    const float d0 = __uint_as_float(e0.x), d1 = __uint_as_float(e1.x);
-    const uint32_t id0 = e0.y & kIdMask, id1 = e1.y & kIdMask; // kInvalidId & kIdMask is no valid id either (ids < 2^31 - 1)
+    uint2 e[EPL];
+    float dv[EPL];
+    uint32_t idv[EPL], c[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const uint32_t i = lane + 64u * t;
+        e[t] = make_uint2(__float_as_uint(kPast), kInvalidId);
+        if (i < b.size) e[t] = b.e[i];
+        dv[t] = __uint_as_float(e[t].x);
+        idv[t] = e[t].y & kIdMask; // kInvalidId & kIdMask is no valid id either (ids < 2^31 - 1)
+        c[t] = 0u;
+    }
     // total-order key of my own distance (+0.0 first: -0 and +0 compare equal as floats), ascending = better first
     const uint32_t fb = __float_as_uint(dist + 0.0f);
     uint32_t key = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
     if (GREATER) key = ~key;
     const unsigned long long mykey = (static_cast<unsigned long long>(key) << 32) | lane;
-    uint32_t c0 = 0, c1 = 0, rank = 0, oldle = 0, minpos = 0xFFFFFFFFu, dupacc = 0xFFFFFFFFu;
+    uint32_t rank = 0, oldle = 0, minpos = 0xFFFFFFFFu, dupacc = 0xFFFFFFFFu;
     unsigned long long m = __ballot(cand);
     const uint32_t ncand = static_cast<uint32_t>(__popcll(m));
     while (m != 0ull) {
@@ -861,15 +866,16 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
         const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
         const uint32_t idj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id), bl));
         const uint32_t kj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), bl));
-        const bool lt0 = cmpf<GREATER>(dj, d0), lt1 = cmpf<GREATER>(dj, d1); // candidate j goes before these old entries (a suffix: sorted)
-        const unsigned long long b0 = __ballot(lt0), b1 = __ballot(lt1);
-        c0 += lt0 ? 1u : 0u;
-        c1 += lt1 ? 1u : 0u;
-        // old entries that stay before j; empty slots always count as "after", so they are subtracted again
-        const uint32_t le = 128u - static_cast<uint32_t>(__popcll(b0) + __popcll(b1));
-        const uint32_t x0 = id0 ^ idj, x1 = id1 ^ idj;
-        dupacc = x0 < dupacc ? x0 : dupacc;
-        dupacc = x1 < dupacc ? x1 : dupacc;
+        uint32_t after = 0; // old entries (and empty slots) candidate j goes before: a suffix of the sorted buffer
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const bool lt = cmpf<GREATER>(dj, dv[t]);
+            c[t] += lt ? 1u : 0u;
+            after += static_cast<uint32_t>(__popcll(__ballot(lt)));
+            const uint32_t x = idv[t] ^ idj;
+            dupacc = x < dupacc ? x : dupacc;
+        }
+        const uint32_t le = 64u * EPL - after; // old entries that stay before j (empty slots always count as "after")
         const unsigned long long kjl = (static_cast<unsigned long long>(kj) << 32) | static_cast<uint32_t>(bl);
         rank += kjl < mykey ? 1u : 0u; // new entries before mine: better, or equal and earlier in adjacency order
         oldle = lane == static_cast<uint32_t>(bl) ? le : oldle;
@@ -877,9 +883,12 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     }
     if (__ballot(dupacc == 0u) != 0ull) return false;
     lds_order();
-    const uint32_t p0 = i0 + c0, p1 = i1 + c1, pn = oldle + rank;
-    if (v0 && c0 != 0u && p0 < b.capacity) b.e[p0] = e0;
-    if (v1 && c1 != 0u && p1 < b.capacity) b.e[p1] = e1;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const uint32_t i = lane + 64u * t, p = i + c[t];
+        if (i < b.size && c[t] != 0u && p < b.capacity) b.e[p] = e[t];
+    }
+    const uint32_t pn = oldle + rank;
     const bool placed = cand && pn < b.capacity;
     if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
     lds_order();

@@ -35,7 +35,9 @@ namespace svsx {
 #define SVSX_KERNEL_ATTR
 #endif
 
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0>
+// BIG: search buffers of 129 .. 512 entries get their own instantiation, so that the 4- / 8-entries-per-lane merge does not raise the
+// register count (= lower the occupancy) of the common window <= 128 kernels
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, bool BIG = false>
 __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
@@ -592,10 +594,19 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 if constexpr (!GENERAL) {
                     // all accepted candidates of the pass in ONE merge (wave_merge_insert); NaN distances and duplicates of buffer
                     // entries (possible when the visited filter is off or evicted) take the one-by-one path below
-                    if (m != 0ull && buf.capacity <= 128u) {
+                    if (m != 0ull && buf.capacity <= (BIG ? 512u : 128u)) {
                         nan_seen = nan_seen || (__ballot(cand && dist != dist) != 0ull);
                         const bool finite = __ballot(cand && !(__builtin_fabsf(dist) < __builtin_inff())) == 0ull;
-                        if (!nan_seen && finite && wave_merge_insert<GREATER>(buf, cand, dist, cid, lane, n_ins)) {
+                        bool merged = false;
+                        if (!nan_seen && finite) {
+                            if constexpr (BIG) {
+                                if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, cand, dist, cid, lane, n_ins);
+                                else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins);
+                            } else {
+                                merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins);
+                            }
+                        }
+                        if (merged) {
                             m = 0ull;
                             full = buf.size == buf.capacity;
                             if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
@@ -705,7 +716,10 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
 static thread_local char g_last_inst[96] = "";
 const char* last_search_instantiation() { return g_last_inst; }
 
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, bool BIG = false> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+    if constexpr (!GENERAL && !BIG) {
+        if (a.capacity > 128u && a.capacity <= 512u) return launch_one<DT, METRIC, QMODE, DS, GENERAL, CODES, true>(a, stream);
+    }
     snprintf(g_last_inst, sizeof(g_last_inst), "search_kernel<dt=%d,metric=%d,qmode=%d,ds=%d,general=%d,codes=%d>", DT, METRIC, QMODE, DS, GENERAL ? 1 : 0, CODES);
     const int d = static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
@@ -715,7 +729,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
                        ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (CODES >= 2 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES>;
+    auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
