@@ -225,6 +225,18 @@ int svsx_iterator_next_device(
  * [6] flags: 1 = next search restarts from the entry points, 2 = exhausted; done() (:230) = [4] == n || flags & 2. */
 int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
 
+/* Batch search with an id filter: the runtime's VamanaIndex::search(n, x, k, distances, labels, params, IDFilter* filter)
+ * (bindings/cpp/include/svs/runtime/vamana_index.h:75-83; algorithm bindings/cpp/src/vamana_index_impl.h:140-218 with
+ * filter_estimate_batch = false).  id_bitmap: bit i of the (n + 63) / 64 words = IDFilter::is_member(i), local ids.
+ * filter_stop: give up on a query (all-padding row) once its observed hit rate falls below it; 0 = never
+ * (SearchParams::filter_stop, api_defs.h).  Per query the answer equals the reference's iterator loop: adaptive batches from
+ * a BatchIterator until k members are found or the iterator is exhausted.  Host pointers, synchronous.
+ * One iterator's search buffer is limited to 16 000 entries (one wave's LDS); a query that needs more keeps what it found. */
+int svsx_search_filtered(
+    const svsx_index* index, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    const uint64_t* id_bitmap, float filter_stop, uint64_t* ids64, float* dists
+);
+
 /* Bound codes (no reference counterpart; result-neutral).  The search kernel turns them into a rigorous LOWER BOUND of
  * the L2 distance and drops candidates that can_skip (search_buffer.h:338-340) would drop anyway before their full row
  * is fetched -- ids and distances returned are unchanged, only the number of 128-byte lines requested per hop falls.

@@ -62,7 +62,7 @@ EXPORTS = [
     "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
     "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
     "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
-    "svsx_last_kernel_info",
+    "svsx_last_kernel_info", "svsx_search_filtered",
 ]
 
 _lib = None
@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
         L.svsx_iterator_next_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_iterator_state.argtypes = [C.c_void_p, C.c_void_p]
         L.svsx_index_build_bound_codes.argtypes = [C.c_void_p, C.c_int]
+        L.svsx_search_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

@@ -1280,3 +1280,93 @@ int svsx_iterator_next(
     HIP_TRY(hipStreamSynchronize(cs.s));
     return SVSX_SUCCESS;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batch search with an id filter: the runtime's VamanaIndex::search(n, x, k, distances, labels, params, IDFilter*)
+// (bindings/cpp/include/svs/runtime/vamana_index.h:75-83; algorithm bindings/cpp/src/vamana_index_impl.h:140-218 with
+// filter_estimate_batch = false, helpers svs_runtime_utils.h:411-434).  Per query: pull adaptive batches from its
+// BatchIterator until k members of the filter are found, the iterator is done, or the observed hit rate falls below
+// filter_stop.  All queries advance together, one kernel launch per round (per-query batch sizes, finished queries skipped).
+extern "C" int svsx_search_filtered(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    const uint64_t* id_bitmap, float filter_stop, uint64_t* ids64, float* dists
+) {
+    if (int rc = check_search_args(ix, queries, q_dtype, nq, k)) return rc;
+    if (!id_bitmap || !ids64 || !dists) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    if (nq == 0) return SVSX_SUCCESS;
+    for (size_t i = 0; i < nq * k; ++i) { // Unspecify<size_t>() / Unspecify<float>() padding (vamana_index_impl.h:205-209)
+        ids64[i] = ~0ull;
+        dists[i] = __builtin_inff();
+    }
+    const size_t sws = params ? params->search_window_size : 0;
+    const size_t max_batch = ix->n;
+    svsx_batch_iterator* it = nullptr;
+    if (int rc = svsx_iterator_create(ix, queries, q_dtype, nq, ~size_t(0), &it)) return rc;
+    std::vector<size_t> found(nq, 0), checked(nq, 0), batch(nq, std::max(k, sws));
+    std::vector<char> active(nq, 1);
+    std::vector<uint32_t> per_query(nq), counts(nq), meta(nq * 8);
+    std::vector<uint64_t> b_ids;
+    std::vector<float> b_dists;
+    auto predict = [](size_t processed, size_t hits, size_t goal, size_t hint, size_t max_value) -> size_t { // svs_runtime_utils.h:411-419
+        if (hits == 0 || hits >= goal) return std::min(hint, max_value);
+        const float bs = static_cast<float>(goal - hits) * processed / hits;
+        return std::min(std::max(static_cast<size_t>(bs), size_t(1)), max_value);
+    };
+    int rc = SVSX_SUCCESS;
+    size_t n_active = nq;
+    while (n_active > 0 && rc == SVSX_SUCCESS) {
+        size_t round_max = 0;
+        for (size_t i = 0; i < nq; ++i) {
+            if (!active[i]) { per_query[i] = 0xFFFFFFFFu; continue; }
+            batch[i] = predict(checked[i], found[i], k, batch[i], max_batch);
+            // the per-wave LDS budget bounds how far ONE iterator can grow; a batch that no longer fits is cut to what does
+            per_query[i] = static_cast<uint32_t>(std::min<size_t>(batch[i], 0xFFFFFFFEu));
+            round_max = std::max(round_max, batch[i]);
+        }
+        const size_t room = it->max_capacity < 16000 ? 16000 - it->max_capacity : 0;
+        if (room == 0) break; // buffers cannot grow any further: what was found so far stands (rows stay padded)
+        if (round_max > room) {
+            round_max = room;
+            for (size_t i = 0; i < nq; ++i)
+                if (active[i] && per_query[i] > room) per_query[i] = static_cast<uint32_t>(room);
+        }
+        b_ids.resize(nq * round_max);
+        b_dists.resize(nq * round_max);
+        rc = svsx_iterator_next(it, round_max, per_query.data(), b_ids.data(), b_dists.data(), counts.data());
+        if (rc != SVSX_SUCCESS) break;
+        rc = svsx_iterator_state(it, meta.data());
+        if (rc != SVSX_SUCCESS) break;
+        for (size_t i = 0; i < nq; ++i) {
+            if (!active[i]) continue;
+            const size_t c = counts[i];
+            checked[i] += c;
+            for (size_t j = 0; j < c && found[i] < k; ++j) {
+                const uint64_t id = b_ids[i * round_max + j];
+                const uint64_t local = id - ix->id_offset;
+                if (local < ix->n && ((id_bitmap[local >> 6] >> (local & 63)) & 1ull)) {
+                    ids64[i * k + found[i]] = id;
+                    dists[i * k + found[i]] = b_dists[i * round_max + j];
+                    ++found[i];
+                }
+            }
+            bool stop = false; // should_stop_filtered_search (svs_runtime_utils.h:424-434)
+            if (filter_stop > 0.0f && checked[i] != 0)
+                stop = found[i] == 0 || static_cast<float>(found[i]) / checked[i] < filter_stop;
+            const bool done = meta[i * 8 + 4] == ix->n || (meta[i * 8 + 6] & 2u) != 0u;
+            if (stop) {
+                for (size_t j = 0; j < k; ++j) {
+                    ids64[i * k + j] = ~0ull;
+                    dists[i * k + j] = __builtin_inff();
+                }
+                found[i] = 0;
+            }
+            if (stop || found[i] >= k || done) {
+                active[i] = 0;
+                --n_active;
+            }
+        }
+    }
+    svsx_iterator_destroy(it);
+    return rc;
+}

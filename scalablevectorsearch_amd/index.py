@@ -200,6 +200,24 @@ class VamanaIndex:
         res = QueryResult(ids, dists)
         return (res, st) if stats else res
 
+    def search_filtered(self, queries, num_neighbors: int, is_member, search_parameters: VamanaSearchParameters | None = None, filter_stop: float = 0.0):
+        """Runtime VamanaIndex::search with an IDFilter (svsx_search_filtered; vamana_index_impl.h:140-218): `is_member` = boolean
+        array over the ids.  Unfilled slots: id all-ones, distance +inf."""
+        queries = np.ascontiguousarray(np.atleast_2d(queries))
+        member = np.asarray(is_member, dtype=bool)
+        if member.shape != (self.n,):
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "is_member must have one entry per vector")
+        bits = np.zeros((self.n + 63) // 64 * 64, np.uint8)
+        bits[: self.n] = member
+        bitmap = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy()
+        nq = queries.shape[0]
+        ids = np.empty((nq, num_neighbors), np.uint64)
+        dists = np.empty((nq, num_neighbors), np.float32)
+        sp = (search_parameters or self._params)._c()
+        _lib.check(_lib.lib().svsx_search_filtered(self._h, queries.ctypes.data, dtype_code(queries), nq, num_neighbors, C.byref(sp),
+                                                   bitmap.ctypes.data, float(filter_stop), ids.ctypes.data, dists.ctypes.data))
+        return QueryResult(ids, dists)
+
     def build_bound_codes(self, mode: int | bool = 1) -> None:
         """svsx_index_build_bound_codes: result-neutral lower-bound rejection for float32 / float16 L2 indexes.
         mode 1 (True): 128-byte code row per vector (d = 96 / 128); mode 2: graph-inline 32-byte records per neighbour

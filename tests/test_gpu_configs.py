@@ -293,3 +293,22 @@ def test_flat_search_k_limit(svs):
     with pytest.raises(svs.SvsxError) as e:
         f.search(x[:4], 97)
     assert e.value.code == 2 and "k <= 96" in e.value.message
+
+
+# ---- SURVEY 7 step 4 gate: graphs of the GPU builder are as good as the oracle builder's --------------------------------------------------
+@pytest.mark.parametrize("metric,n,d,latent,normalize,alpha", [(L2, 4000, 96, 24, True, 1.2), (IP, 3000, 128, 32, False, 0.95), (COS, 3000, 128, 32, False, 0.95)])
+def test_gpu_built_graph_matches_oracle_graph_quality(svs, oracle, metric, n, d, latent, normalize, alpha):
+    """Same data, same build parameters (R = 32, L = 64, prune_to = 28, two passes), one graph from the C oracle's sequential
+    builder (vamana_build.h semantics), one from this repo's GPU builder.  The graphs differ (the reference's own builder is
+    thread-schedule dependent too), the recall-vs-window curves must not: within 1.5 % absolute at every window, searched by
+    the oracle on both graphs, ground truth exhaustive."""
+    x = deep_like(n, d, latent, seed=1, normalize=normalize)
+    q = deep_like(200, d, latent, seed=2, normalize=normalize)
+    g_o, e_o = oracle.build_vamana(metric, x, R=32, L=64, prune_to=28, alpha=alpha)
+    g_g, e_g = _gpu_graph(svs, x, metric, R=32, L=64, alpha=alpha)
+    assert abs(g_o[:, 0].mean() - g_g[:, 0].mean()) < 0.15 * g_o[:, 0].mean()  # comparable density
+    gt, _ = oracle.flat_search(metric, x, q, 10)
+    for w in (10, 16, 24, 40, 64):
+        r_o = oracle.recall(gt, oracle.search(metric, x, g_o, e_o, q, 10, w)[0], 10, 10)
+        r_g = oracle.recall(gt, oracle.search(metric, x, g_g, e_g, q, 10, w)[0], 10, 10)
+        assert abs(r_o - r_g) < 0.015, (metric, w, r_o, r_g)

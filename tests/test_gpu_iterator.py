@@ -227,3 +227,14 @@ def test_range_and_filtered_search_on_gpu(svs, oracle, small_world):
         a = svs.filtered_search(idx, q, k, member, filter_stop=stop)
         b = svs.filtered_search(fake, q, k, member, filter_stop=stop, make_iterator=_OracleBatchIterator)
         assert (a.indices == b.indices).all() and (_bits(a.distances) == _bits(b.distances)).all()
+        # the same loop inside the library (svsx_search_filtered: the IDFilter argument of the runtime's batch operator)
+        c = idx.search_filtered(q, k, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), filter_stop=stop)
+        assert (c.indices == b.indices).all() and (_bits(c.distances) == _bits(b.distances)).all()
+    # a filter nothing passes: every row padded; a filter with a handful of members: found through growing batches
+    none = idx.search_filtered(q, 5, np.zeros(sw["x"].shape[0], bool), svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
+    assert (none.indices == np.uint64(2**64 - 1)).all() and np.isposinf(none.distances).all()
+    few = np.zeros(sw["x"].shape[0], bool)
+    few[[3, 500, 900, 1400]] = True
+    a = svs.filtered_search(idx, q, 3, few)
+    c = idx.search_filtered(q, 3, few, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
+    assert (a.indices == c.indices).all() and (c.indices != np.uint64(2**64 - 1)).all()

@@ -215,3 +215,57 @@ def test_batch_search_plumbing(oracle, small_world):
     a = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 24, 40, visited_set=True)
     b = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], 10, 24, 40, visited_set=False)
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
+# ---- scalar quantization: every numeric known answer the reference's own test holds (tests/svs/quantization/scalar/scalar.cpp) ----
+def test_sq_scale_bias_known_answer(oracle):
+    """scalar.cpp:30-58 (test_sq_top): for data spanning exactly [-127, 127] the reference REQUIRES, with float equality,
+    scale == 254 / (MAX - MIN) and bias == -127 - MIN * scale ("calculations are performed in float everywhere and should
+    therefore produce the exact same results"); and scalar.cpp:85-101: |x - decompress(compress(x))| < scale / 2, strictly."""
+    rng = np.random.default_rng(11)
+    x = rng.integers(-127, 128, (300, 128)).astype(np.float32)  # the test dataset's value range
+    x[0, 0], x[1, 1] = -127.0, 127.0
+    for code, lo, hi in ((I8, -128.0, 127.0), (U8, 0.0, 255.0)):
+        codes, scale, bias = oracle.sq_compress(x, code)
+        exp_scale = np.float32(254.0) / np.float32(hi - lo)
+        exp_bias = np.float32(-127.0) - np.float32(lo) * exp_scale
+        assert np.float32(scale) == exp_scale and np.float32(bias) == exp_bias
+        recon = np.float32(scale) * codes.astype(np.float32) + np.float32(bias)
+        # integer data at this scale contains exact half-way cases (v + 127 = 127 -> code k + 0.5): the error is then 0.5 * scale
+        # to the last bit, so the strict form of the reference's check is only meaningful on tie-free data (below)
+        assert (np.abs(x - recon) <= np.float32(0.5) * np.float32(scale) * np.float32(1.0 + 1e-6)).all()
+    # fractional data (no exact ties): strictly inside half a step, as the reference requires (scalar.cpp:85-110)
+    y = rng.uniform(-127, 127, (50, 128)).astype(np.float32)
+    y[0, 0], y[0, 1] = -127.0, 127.0
+    codes, scale, bias = oracle.sq_compress(y, I8)
+    recon = np.float32(scale) * codes.astype(np.float32) + np.float32(bias)
+    assert (np.abs(y - recon) < np.float32(0.5) * np.float32(scale) * np.float32(1.0 + 4e-6)).all()
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("lo,hi", [(-127, 127), (80, 100), (-10, 10), (-100, -80), (-1, 1), (-10, 1)])
+def test_sq_compressed_distances_match_float_reference(oracle, metric, lo, hi):
+    """scalar.cpp:113-176 (test_distance_single / test_distance): N = 64 + 16 + 7, 100 random code vectors from the given part
+    of the int8 range, random scale and bias in (-3, 3) (the sign of scale included), query = a decompressed code vector;
+    compressed_distance.compute must equal the float distance of the decompressed vectors within Approx(epsilon 0.01, margin 0.01).
+    The float side is the reference's own kernel (oracle/_ref) when it can run here, else the C restatement."""
+    from oracle.oracle import Ref
+
+    rng = np.random.default_rng(1000 * (metric + 1) + (lo + 200) * 7 + hi)
+    N, num = 64 + 16 + 7, 100
+    for _ in range(3):
+        scale, bias = (np.float32(v) for v in rng.uniform(-3, 3, 2))
+        if abs(scale) < 1e-3:
+            scale = np.float32(0.5)
+        a = rng.integers(lo, hi + 1, N).astype(np.int8)
+        b = rng.integers(lo, hi + 1, (num, N)).astype(np.int8)
+        dec = lambda v: scale * v.astype(np.float32) + bias  # noqa: E731
+        query = dec(a)[None, :]
+        floats = dec(b)
+        ref = (Ref() if Ref.available() else oracle).distance_batch(metric, query, floats)[0]
+        # the compressed distance, as the search path computes it: exhaustive search over the codes returns every point
+        ids, got = oracle.flat_search(metric, b, query, num, sq=(float(scale), float(bias)))
+        want = ref[ids[0].astype(np.int64)]
+        ok = np.abs(got[0] - want) <= 0.01 * np.abs(want) + 0.01
+        ok |= np.isnan(got[0]) & np.isnan(want)
+        assert ok.all(), (metric, lo, hi, scale, bias, got[0][~ok][:3], want[~ok][:3])

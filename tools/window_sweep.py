@@ -34,9 +34,12 @@ t0 = time.time()
 L = a.build_window or 2 * a.degree
 graph, entry = build_vamana_device(x, a.n, a.d, fn, VamanaBuildParameters(alpha=alpha, graph_max_degree=a.degree, window_size=L, prune_to=a.degree - 4), data_dtype=np_dt, sq=sq)
 t_build = time.time() - t0
-idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), a.n, a.d, np_dt, sq=sq)
 k = 10
 gt = exact_topk(xf, qf, k, a.metric)
+if a.dtype != "f32":
+    del xf  # the float copy is only needed for the ground truth: give the memory back before the inline records are built
+torch.cuda.empty_cache()
+idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), a.n, a.d, np_dt, sq=sq)
 ids = torch.empty((a.nq, k), dtype=torch.int64, device=dev); dists = torch.empty((a.nq, k), device=dev); stats = torch.zeros((a.nq, 6), dtype=torch.int32, device=dev)
 base = None
 for mode in [int(m) for m in a.modes.split(",")]:
