@@ -35,9 +35,9 @@ namespace svsx {
 #define SVSX_KERNEL_ATTR
 #endif
 
-// BIG: search buffers of 129 .. 512 entries get their own instantiation, so that the 4- / 8-entries-per-lane merge does not raise the
-// register count (= lower the occupancy) of the common window <= 128 kernels
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, bool BIG = false>
+// BIG: search buffers of 129 .. 512 (BIG = 1) and 513 .. 1024 entries (BIG = 2) get their own instantiations, so that the 4- / 8- /
+// 16-entries-per-lane merge does not raise the register count (= lower the occupancy) of the common window <= 128 kernels
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0>
 __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool GREATER = METRIC != M_L2;
@@ -76,8 +76,9 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     const bool tag8 = a.filter_tag8 != 0u;
     const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
-    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + 256u); // FAT: the query's own record codes (128 B)
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES != 0) ? 256u : 0u) + (FAT ? 128u : 0u)); // GENERAL only
+    // FAT: the query's own record codes; 32-byte records keep them in SGPRs afterwards, so the 128 bytes alias the compaction scratch
+    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + (CODES >= 3 ? 256u : 0u));
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES != 0) ? 256u : 0u) + (CODES >= 3 ? 128u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -594,12 +595,14 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 if constexpr (!GENERAL) {
                     // all accepted candidates of the pass in ONE merge (wave_merge_insert); NaN distances and duplicates of buffer
                     // entries (possible when the visited filter is off or evicted) take the one-by-one path below
-                    if (m != 0ull && buf.capacity <= (BIG ? 512u : 128u)) {
+                    if (m != 0ull && buf.capacity <= (BIG == 2 ? 1024u : BIG == 1 ? 512u : 128u)) {
                         nan_seen = nan_seen || (__ballot(cand && dist != dist) != 0ull);
                         const bool finite = __ballot(cand && !(__builtin_fabsf(dist) < __builtin_inff())) == 0ull;
                         bool merged = false;
                         if (!nan_seen && finite) {
-                            if constexpr (BIG) {
+                            if constexpr (BIG == 2) {
+                                merged = wave_merge_insert<GREATER, 16>(buf, cand, dist, cid, lane, n_ins);
+                            } else if constexpr (BIG == 1) {
                                 if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, cand, dist, cid, lane, n_ins);
                                 else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins);
                             } else {
@@ -716,9 +719,10 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
 static thread_local char g_last_inst[96] = "";
 const char* last_search_instantiation() { return g_last_inst; }
 
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, bool BIG = false> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
-    if constexpr (!GENERAL && !BIG) {
-        if (a.capacity > 128u && a.capacity <= 512u) return launch_one<DT, METRIC, QMODE, DS, GENERAL, CODES, true>(a, stream);
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
+    if constexpr (!GENERAL && BIG == 0) {
+        if (a.capacity > 128u && a.capacity <= 512u) return launch_one<DT, METRIC, QMODE, DS, GENERAL, CODES, 1>(a, stream);
+        if (a.capacity > 512u && a.capacity <= 1024u) return launch_one<DT, METRIC, QMODE, DS, GENERAL, CODES, 2>(a, stream);
     }
     snprintf(g_last_inst, sizeof(g_last_inst), "search_kernel<dt=%d,metric=%d,qmode=%d,ds=%d,general=%d,codes=%d>", DT, METRIC, QMODE, DS, GENERAL ? 1 : 0, CODES);
     const int d = static_cast<int>(a.d);
@@ -727,7 +731,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (CODES >= 2 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
+                       ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (CODES >= 3 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>;
     if (lds > 48 * 1024) {

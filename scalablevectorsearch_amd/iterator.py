@@ -18,6 +18,7 @@ from . import _lib
 from .index import QueryResult, VamanaSearchParameters, dtype_code
 
 SKIP = 0xFFFFFFFF  # per-query batch size meaning "leave this query untouched"
+LDS_BUFFER_ENTRIES = 16000  # capacity limit of one iterator's search buffer (one wave's LDS)
 UNSIGNED_INTEGER_PLACEHOLDER = (1 << 64) - 1  # lib/preprocessor.h:177
 
 
@@ -37,6 +38,8 @@ class BatchIterator:
         self._ids = np.zeros((self.nq, 0), np.uint64)
         self._dists = np.zeros((self.nq, 0), np.float32)
         self._counts = np.zeros(self.nq, np.uint32)
+        self._extra = 100 if extra_search_buffer_capacity is None else int(extra_search_buffer_capacity)  # ITERATOR_EXTRA_BUFFER_CAPACITY_DEFAULT
+        self._cap_bound = self._extra
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -64,6 +67,7 @@ class BatchIterator:
         _lib.check(_lib.lib().svsx_iterator_next(self._h, batch_size, None if bs is None else bs.ctypes.data, ids.ctypes.data,
                                                  dists.ctypes.data, counts.ctypes.data))
         self._ids, self._dists, self._counts = ids, dists, counts
+        self._cap_bound += batch_size
         return ids, dists, counts
 
     def next_device(self, batch_size: int, d_ids64, d_dists, d_counts, d_batch_sizes=None, stream=None):
@@ -105,6 +109,7 @@ class BatchIterator:
             raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Incompatible dimensions. Query has {queries.shape[1]} while the index expects {self.index.d}.")
         _lib.check(_lib.lib().svsx_iterator_update(self._h, queries.ctypes.data))
         self._counts[:] = 0
+        self._cap_bound = self._extra
 
 
 def predict_further_processing(processed, hits, goal, hint, max_value):
@@ -145,8 +150,15 @@ def filtered_search(index, queries, k: int, is_member, search_parameters: Vamana
     while active.any():
         for i in np.flatnonzero(active):
             batch[i] = predict_further_processing(checked[i], found[i], k, batch[i], max_batch)
-        per_query = np.where(active, batch, SKIP).astype(np.uint32)
-        b_ids, b_dists, counts = it.next(int(batch[active].max()), per_query)
+        # one iterator's search buffer lives in one wave's LDS (16 000 entries, include/svsx.h): a predicted batch that no
+        # longer fits is cut to what does; once nothing fits, the queries still active keep what they found (same rule as
+        # svsx_search_filtered)
+        room = LDS_BUFFER_ENTRIES - getattr(it, "_cap_bound", LDS_BUFFER_ENTRIES - max_batch)  # the library's own bound: extra + sum of round sizes
+        if room <= 0:
+            break
+        step = np.minimum(batch, room)
+        per_query = np.where(active, step, SKIP).astype(np.uint32)
+        b_ids, b_dists, counts = it.next(int(step[active].max()), per_query)
         done = it.done()
         for i in np.flatnonzero(active):
             c = int(counts[i])

@@ -63,7 +63,8 @@ def _search_both(svs, oracle, metric, fn, x, graph, entry, q, k, w, c, sq=None):
     return res, st, ids, dists, ost
 
 
-@pytest.mark.parametrize("w,c,k", [(10, 10, 10), (32, 32, 10), (20, 40, 10), (128, 128, 10), (5, 5, 10), (64, 64, 64), (1, 1, 1)])
+@pytest.mark.parametrize("w,c,k", [(10, 10, 10), (32, 32, 10), (20, 40, 10), (128, 128, 10), (5, 5, 10), (64, 64, 64), (1, 1, 1),
+                                   (129, 129, 10), (200, 256, 20), (300, 300, 10), (512, 512, 50), (513, 600, 10), (1000, 1024, 100), (1025, 1100, 10)])
 def test_search_f32_l2_bit_exact(svs, oracle, small_world, w, c, k):
     sw = small_world
     res, st, ids, dists, ost = _search_both(svs, oracle, L2, svs.DistanceL2(), sw["x"], sw["graph"], sw["entry"], sw["q"], k, w, c)
@@ -90,7 +91,7 @@ def test_search_all_type_pairs(svs, oracle, small_world, metric, qdt, ddt):
 
     x = conv(sw["x"], ddt)
     q = conv(sw["q"], qdt)
-    for (w, c) in [(16, 16), (12, 30)]:
+    for (w, c) in [(16, 16), (12, 30), (260, 260), (700, 700)]:  # the last two: 4- / 8- and 16-entries-per-lane merge instantiations
         res, st, ids, dists, ost = _search_both(svs, oracle, metric, fn, x, sw["graph"], sw["entry"], q, 10, w, c)
         assert (res.indices == ids.astype(np.uint64)).all(), (metric, qdt, ddt)
         assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
