@@ -1,819 +1,25 @@
-// svsx_search.hip -- batched Vamana greedy search, one wavefront per query (gfx950 / CDNA4).
-//
-// Restates, wave-parallel but order-exact, the reference's per-thread loop:
-//   VamanaIndex::search batch        index/vamana/index.h:564-611
-//   per_thread_batch_search          index/vamana/extensions.h:555-592
-//   greedy_search                    index/vamana/greedy_search.h:124-203
-//   EntryPointInitializer            index/vamana/greedy_search.h:62-94
-//   SearchBuffer                     index/vamana/search_buffer.h:104-497
-//
-// Mapping to the machine:
-//   * grid = nq single-wave workgroups; the hardware dispatcher is the work queue (a CU holds up to 32 waves,
-//     each wave hides its own gather latency behind the others').
-//   * query (f32 or bytes) and the sorted candidate buffer live in the wave's LDS slice.
-//   * per expansion: one coalesced load of the padded adjacency row (lane c <- neighbour c), then passes of
-//     64/G candidate rows: G adjacent lanes stream one row with 16-B loads (row = 384 B at d=96 f32), reduce
-//     with DPP quad exchanges in the reference's exact summation tree, and the surviving candidates
-//     (ballot against the current worst) are inserted in adjacency order -> identical buffer contents to the
-//     sequential CPU loop.
+// svsx_search.hip -- dispatch of the batched greedy search to the per-row-type translation units (svsx_search_kernel.h holds the
+// kernel; svsx_search_{f32,f16,i8,u8}.hip its instantiations).
 #include "svsx_device.h"
 #include "svsx_kernels.h"
 
-#include <cstdio>
-
-#ifndef SVSX_CODE_BATCH
-// bound-code passes (16 candidates each) whose loads are issued together.  Measured on the bench workload: 1 -> 4.90,
-// 2 -> 5.17, 3 -> 5.13, 4 -> 4.55 M QPS (4 needs 105 VGPRs = 4 waves/SIMD); profiles/r01_notes.md
-#define SVSX_CODE_BATCH 2
-#endif
-
 namespace svsx {
 
-#ifdef SVSX_WAVES_PER_EU
-#define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(SVSX_WAVES_PER_EU)))
-#else
-#define SVSX_KERNEL_ATTR
-#endif
-
-// BIG: search buffers of 129 .. 512 (BIG = 1) and 513 .. 1024 entries (BIG = 2) get their own instantiations, so that the 4- / 8- /
-// 16-entries-per-lane merge does not raise the register count (= lower the occupancy) of the common window <= 128 kernels
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0>
-__global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const SearchArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr bool GREATER = METRIC != M_L2;
-    // CODES: 0 none, 1 128-byte code rows (svsx_distance.hip), 2 / 3 / 4 graph-inline records of 32 / 64 / 128 bytes (svsx_codes.hip)
-    constexpr bool FAT = CODES >= 2;
-    constexpr int RW = FAT ? (2 << (CODES - 2)) : 2;              // 16-byte planes per record
-    constexpr int FDC = RW * 16 - (METRIC == M_L2 ? 4 : 6);       // coded coordinates per record
-    constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
-    constexpr bool B8 = !INTPATH && use_block_cyclic<DT>();  // 8-bit rows on the float path: block-cyclic mapping
-    constexpr int G = (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
-    constexpr int RPP = 64 / G;                        // rows per pass
-
-    const uint32_t lane = threadIdx.x;
-    const uint32_t qi = blockIdx.x;
-    const int d = DS > 0 ? DS : static_cast<int>(a.d);
-    const int dpad = (d + 15) & ~15;
-
-    WaveBuffer buf;
-    buf.e = reinterpret_cast<uint2*>(smem);
-    buf.size = 0;
-    buf.best_unvisited = 0;
-    buf.window = a.window;
-    buf.capacity = a.capacity;
-    const uint32_t buf_bytes = ((a.capacity + 1) * 8u + 15u) & ~15u;
-    float* qf = reinterpret_cast<float*>(smem + buf_bytes);          // float path: dpad f32
-    uint32_t* qw = reinterpret_cast<uint32_t*>(smem + buf_bytes);    // int path: dpad bytes
-    const uint32_t q_bytes = INTPATH ? static_cast<uint32_t>(dpad) : static_cast<uint32_t>(dpad) * 4u;
-    // VisitedFilter (index/vamana/filter.h:49-130, search_buffer.h:461-463) with the reference's own encoding: slot =
-    // low bits of the id, 16-bit tag = the remaining high bits, 0xFFFF = empty.  The host only enables it when
-    // (n >> log2(entries)) < 0xFFFF, so slot+tag identify the id exactly: no false positives -- a hit means the id was
-    // evaluated earlier in this query and re-inserting it would be a no-op (duplicate, or not better than the worst,
-    // which only improves).  Result-neutral by construction; it only removes vector re-fetches.
-    // When (n >> log2 entries) < 255 the tag fits 8 bits (0xFF = empty) and the same LDS holds twice the entries.
-    uint16_t* filt = reinterpret_cast<uint16_t*>(smem + buf_bytes + q_bytes);
-    uint8_t* filt8 = reinterpret_cast<uint8_t*>(filt);
-    const bool tag8 = a.filter_tag8 != 0u;
-    const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
-    uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
-    // FAT: the query's own record codes; 32-byte records keep them in SGPRs afterwards, so the 128 bytes alias the compaction scratch
-    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + (CODES >= 3 ? 256u : 0u));
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES != 0) ? 256u : 0u) + (CODES >= 3 ? 128u : 0u)); // GENERAL only
-
-    // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
-    uint32_t* it_meta = nullptr;
-    uint32_t it_bs = 0;
-    bool resume = false;
-    if constexpr (GENERAL) {
-        if (a.it_meta != nullptr) {
-            it_meta = a.it_meta + static_cast<size_t>(qi) * 8;
-            it_bs = a.it_batch_sizes != nullptr ? a.it_batch_sizes[qi] : a.it_batch;
-            const bool skip = it_bs == 0xFFFFFFFFu;
-            const bool done = it_meta[4] == a.n || (it_meta[6] & 2u) != 0u;
-            if (skip || done) { // results_.clear() (:253-256); an untouched query reports nothing either
-                for (uint32_t j = lane; j < a.it_batch; j += 64) {
-                    a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + j] = ~0ull;
-                    a.it_out_dists[static_cast<size_t>(qi) * a.it_batch + j] = __builtin_inff();
-                }
-                if (lane == 0) a.it_counts[qi] = 0;
-                return;
-            }
-            if (it_bs > a.it_batch) it_bs = a.it_batch;
-            buf.window = it_meta[2] + it_bs;      // SearchBufferConfig::increment (search_buffer.h:70-73)
-            buf.capacity = it_meta[3] + it_bs;
-            resume = (it_meta[6] & 1u) == 0u;
-        }
-    }
-    if constexpr (!GENERAL) {
-        if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return; // extensions.h:575-578
-    }
-    const uint32_t fmask = a.filter_entries - 1u;
-    const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));
-    for (uint32_t i = lane; i < filt_bytes / 4u; i += 64) reinterpret_cast<uint32_t*>(filt)[i] = 0xFFFFFFFFu;
-
-    // ---- load + fix the query (maybe_fix_argument, greedy_search.h:140) -------------------------------------
-    const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
-    const QueryFix fx = prepare_query<DT, METRIC, QMODE>(qptr, a.q_dtype, d, dpad, qf, qw, a.sq_scale, a.sq_bias, lane);
-
-    const unsigned char* data = static_cast<const unsigned char*>(a.data);
-    const int sub = static_cast<int>(lane) & (G - 1);
-    const uint32_t grp = lane / G;
-
-    // ---- bound codes (svsx_index_build_bound_codes): the query's own codes, kept in registers -----------------------
-    // Row r has codes cx (u8) of its first DC components under the global (scale, bias): xhat_j = bias + scale * cx_j, and
-    // the stored ex >= ||x_C - xhat||.  With the query coded the same way (error eq, computed here),
-    //     sqrt(distance_L2) >= ||q_C - x_C|| >= ||qhat - xhat|| - eq - ex = scale * sqrt(sum (cq - cx)^2) - eq - ex,
-    // and the integer sum is exact (v_dot4).  A candidate whose bound already exceeds the worst buffer entry would be
-    // skipped by can_skip (search_buffer.h:338-340) whatever its exact distance -> its 384-B row is never fetched.
-    // Margins (0.99998 on the code distance, 1.001 on eq, 1.0001 on the threshold) cover every float rounding involved.
-    uint32_t qc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    int code_qq = 0;
-    float code_eq = 0.0f;
-    uint32_t n_code_rej = 0;
-    if constexpr (CODES == 1) {
-        static_assert(G == 4 && DS > 0, "bound codes: f32 rows of static dimension");
-        constexpr int DC = DS < 120 ? DS : 120;
-        const float inv = 1.0f / a.code_scale;
-        float e2 = 0.0f;
-        int qq = 0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int j = sub * 32 + w * 4 + t;
-                if (j < DC) {
-                    const float v = qf[j];
-                    float c = __builtin_rintf((v - a.code_bias) * inv);
-                    c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
-                    const int ci = static_cast<int>(c);
-                    const float r = v - (a.code_bias + a.code_scale * c);
-                    e2 += r * r;
-                    qq += ci * ci;
-                    packed |= static_cast<uint32_t>(ci) << (8 * t);
-                }
-            }
-            qc[w] = packed;
-        }
-        e2 += xor1f(e2);
-        e2 += xor2f(e2);
-        qq += xor1i(qq);
-        qq += xor2i(qq);
-        code_qq = __builtin_amdgcn_readfirstlane(qq); // wave-uniform values live in SGPRs
-        code_eq = __builtin_sqrtf(e2) * 1.001f + 1.0e-7f;
-        if (!(code_eq < 3.0e38f)) code_eq = __builtin_inff(); // non-finite query: the bound never fires
-        code_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, code_eq)));
-    }
-
-    // ---- graph-inline records (svsx_codes.hip; CODES == 2): coordinates, codes and remainder norm of the query, once --------
-    //   v = q - mean (mean = 0 unless L2);  u_i = P_i . v  for the DC leading directions (P = float32 copy of the orthonormal
-    //   f64 directions Q the records were built with):  |u_i - Q_i . v*| <= ((d + 2) 2^-24 + delta + 2^-24) ||v||  (fma chain,
-    //   rounding of P, rounding of q - mean).  Everything below carries that slack explicitly.
-    uint32_t fq[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    [[maybe_unused]] int fat_qq = 0;
-    [[maybe_unused]] float fat_eq = 0.0f, fat_tq_hi = 0.0f, fat_tq_lo = 0.0f, fat_s2m = 0.0f, fat_nuh = 0.0f, fat_nq = 0.0f;
-    if constexpr (FAT) {
-        constexpr int DC = FDC;
-        const uint32_t ci = lane & 31u, half = lane >> 5; // lane -> coordinate ci (+ 32 per group), half of the element range
-        const int hlen = dpad >> 1;                       // dpad is a multiple of 16 -> 8-float steps
-        const float* qh = qf + half * hlen;
-        const float* mh = a.pca_mean + half * hlen;
-        float r2 = 0.0f, un2 = 0.0f, vv = 0.0f;
-        int qq = 0;
-        if (lane < 32u) qcodes[lane] = 0u;
-        lds_order();
-#pragma unroll 1
-        for (int g = 0; g * 32 < DC; ++g) { // 32 coordinates per sweep over the query
-            const float4* prow = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(ci + 32u * g) * a.pca_pd + half * hlen);
-            float up = 0.0f, vvp = 0.0f;
-#pragma unroll 1
-            for (int j0 = 0; j0 < hlen; j0 += 8) { // rolled: the projection must not raise the kernel's register peak
-                const float4 p0 = prow[j0 >> 2], p1 = prow[(j0 >> 2) + 1];
-                float4 v0 = *reinterpret_cast<const float4*>(qh + j0), v1 = *reinterpret_cast<const float4*>(qh + j0 + 4);
-                if constexpr (METRIC == M_L2) {
-                    const float4 m0 = *reinterpret_cast<const float4*>(mh + j0), m1 = *reinterpret_cast<const float4*>(mh + j0 + 4);
-                    v0.x -= m0.x; v0.y -= m0.y; v0.z -= m0.z; v0.w -= m0.w;
-                    v1.x -= m1.x; v1.y -= m1.y; v1.z -= m1.z; v1.w -= m1.w;
-                }
-                up = __builtin_fmaf(p0.x, v0.x, up); up = __builtin_fmaf(p0.y, v0.y, up); up = __builtin_fmaf(p0.z, v0.z, up); up = __builtin_fmaf(p0.w, v0.w, up);
-                up = __builtin_fmaf(p1.x, v1.x, up); up = __builtin_fmaf(p1.y, v1.y, up); up = __builtin_fmaf(p1.z, v1.z, up); up = __builtin_fmaf(p1.w, v1.w, up);
-                vvp = __builtin_fmaf(v0.x, v0.x, vvp); vvp = __builtin_fmaf(v0.y, v0.y, vvp); vvp = __builtin_fmaf(v0.z, v0.z, vvp); vvp = __builtin_fmaf(v0.w, v0.w, vvp);
-                vvp = __builtin_fmaf(v1.x, v1.x, vvp); vvp = __builtin_fmaf(v1.y, v1.y, vvp); vvp = __builtin_fmaf(v1.z, v1.z, vvp); vvp = __builtin_fmaf(v1.w, v1.w, vvp);
-            }
-            float u = up + __shfl_xor(up, 32);     // coordinate ci + 32 g (both halves of the wave hold it)
-            vv = vvp + __shfl_xor(vvp, 32);        // ||v||^2 (the same in every sweep)
-            if constexpr (METRIC == M_COS) {
-                // cosine records hold UNIT vectors: work with the unit query q / ||q|| (two more roundings per coordinate, in `urel`)
-                u *= 1.0f / __builtin_sqrtf(vv);
-            }
-            const uint32_t coord = ci + 32u * static_cast<uint32_t>(g);
-            if (half == 0u && coord < static_cast<uint32_t>(DC)) {
-                float c, uh;
-                if constexpr (METRIC == M_L2) {
-                    const float b = a.pca_bias[coord];
-                    c = __builtin_rintf((u - b) / a.pca_step);
-                    c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
-                    if (!(c == c)) c = 0.0f;
-                    uh = b + a.pca_step * c;
-                } else {
-                    c = __builtin_rintf(u / a.pca_step);
-                    c = c < -127.0f ? -127.0f : (c > 127.0f ? 127.0f : c);
-                    if (!(c == c)) c = 0.0f;
-                    uh = a.pca_step * c;
-                }
-                const int cint = static_cast<int>(c);
-                const float r = u - uh;
-                r2 = __builtin_fmaf(r, r, r2);
-                un2 = __builtin_fmaf(u, u, un2);
-                qq += cint * cint;
-                reinterpret_cast<uint8_t*>(qcodes)[coord] = static_cast<uint8_t>(cint & 0xFF);
-            }
-        }
-        if constexpr (METRIC == M_COS) vv = vv > 0.0f ? 1.0f : vv; // a zero query gives NaN coordinates: the bound never fires
-        for (int off = 32; off >= 1; off >>= 1) {
-            r2 += __shfl_xor(r2, off);
-            un2 += __shfl_xor(un2, off);
-            qq += __shfl_xor(qq, off);
-        }
-        lds_order();
-        if constexpr (RW == 2) { // 32-byte records: the query's code words live in SGPRs
-#pragma unroll
-            for (int w = 0; w < 7; ++w) fq[w] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(qcodes[w])));
-        }
-        const float vn = __builtin_sqrtf(vv) * 1.00001f;
-        const float urel = (static_cast<float>(d + 3 + (METRIC == M_COS ? d / 2 + 6 : 0)) * 5.9604645e-8f) * 1.01f + a.pca_delta; // cosine: + rounding of ||q|| and of the scaling
-        const float erot = __builtin_sqrtf(static_cast<float>(DC)) * urel * vn;
-        const float nu = __builtin_sqrtf(un2);
-        float eq = __builtin_sqrtf(r2) * 1.0001f + erot + a.pca_eq_abs;
-        // remainder norm tq = sqrt(||v||^2 - ||u||^2): a difference of float32 sums, bracketed from both sides
-        const float drel = static_cast<float>(d + 4) * 5.9604645e-8f * 1.01f;
-        const float alo = nu * 0.99999f - erot, ahi = nu * 1.00001f + erot;
-        const float alo2 = alo > 0.0f ? alo * alo : 0.0f;
-        const float thi2 = vv * (1.0f + drel) - alo2, tlo2 = vv * (1.0f - drel) - ahi * ahi;
-        float tq_hi = __builtin_sqrtf(thi2 > 0.0f ? thi2 : 0.0f) * 1.00001f;
-        const float tq_lo = __builtin_sqrtf(tlo2 > 0.0f ? tlo2 : 0.0f) * 0.99999f;
-        if (!(eq < 3.0e38f) || !(tq_hi < 3.0e38f)) { // non-finite query: the bound never fires
-            eq = __builtin_inff();
-            tq_hi = __builtin_inff();
-        }
-        auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
-        fat_qq = __builtin_amdgcn_readfirstlane(qq);
-        fat_eq = uni(eq);
-        fat_tq_hi = uni(tq_hi);
-        fat_tq_lo = uni(tq_lo);
-        fat_s2m = a.pca_step * a.pca_step * (METRIC == M_L2 ? 0.99999f : 1.0f);
-        fat_nuh = uni(a.pca_step * __builtin_sqrtf(static_cast<float>(qq)) * 1.00001f); // ||uhat|| (signed codes)
-        fat_nq = uni(vn);
-    }
-
-    // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
-    // candidate out (l2_row_distance_two_phase); result-neutral, removes the third line of most rows at d = 96
-    constexpr bool TWO_PHASE = QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && DS > 64 && DS <= 128;
-    uint32_t n_early = 0;
-    // distance of the candidate whose id each lane-group holds; every lane of the wave participates.
-    // `thr`: +inf while the buffer is not full, else worst * (1 + 4e-5).
-    auto group_distance = [&](uint32_t cid, bool active, float thr) -> float {
-        const unsigned char* row = data + static_cast<size_t>(active ? cid : 0u) * a.row_bytes;
-        float fmain = 0.0f, fnrm = 0.0f;
-        int ab = 0, bb = 0;
-        if constexpr (TWO_PHASE && CODES == 0) { // survivors of the bound codes are close to the worst entry: fetch whole rows
-            bool rejected = false;
-            const float dd = l2_row_distance_two_phase<DT, (DS > 64 && DS <= 128) ? DS : 96>(row, active, qf, sub, thr, rejected);
-            n_early += __popcll(__ballot(active && rejected && sub == 0));
-            return dd;
-        } else if constexpr (QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && DS == 0) {
-            // runtime dimension: progressive partial-distance rejection after every 64-element block
-            bool rejected = false;
-            float_row_distance<DT, METRIC, 0, false, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm, thr, &rejected);
-            n_early += __popcll(__ballot(active && rejected && sub == 0));
-            return fmain;
-        } else if constexpr (INTPATH) {
-            int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
-        } else if constexpr (B8) {
-            float_row_distance_bc<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
-        } else {
-            float_row_distance<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
-        }
-        return finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
-    };
-
-    uint32_t n_exp = 0, n_slots = 0, n_eval = 0, n_ins = 0;
-    [[maybe_unused]] bool nan_seen = false; // a NaN distance reached the buffer: comparisons stop being an order, inserts go one by one
-
-    // ---- EntryPointInitializer: distances to the entry points, push_back, sort --------------------------------
-    // (push_back + sort == ordered insert for <= 16 entry points, where std::sort is a stable insertion sort; the
-    //  GENERAL variant appends and runs the std::sort restatement, exact for any number of entry points)
-    const bool append_then_sort = GENERAL && a.n_entry > 16u;
-    if (!resume) {
-        for (uint32_t base = 0; base < a.n_entry; base += RPP) {
-            const uint32_t ci = base + grp;
-            const bool act = ci < a.n_entry;
-            const uint32_t cid = act ? a.entry[ci] : 0u;
-            const float dist = group_distance(cid, act, __builtin_inff());
-            unsigned long long m = __ballot(act && sub == 0);
-            while (m != 0ull) {
-                const int bl = __builtin_ctzll(m);
-                m &= m - 1ull;
-                const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
-                const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
-                ++n_eval;
-                nan_seen = nan_seen || dd != dd;
-                if (buf.size < buf.capacity) {
-                    // EntryPointInitializer never touches the visited set (greedy_search.h:69-90); marking an entry point that was
-                    // really pushed is result-neutral (re-encountering it would be a duplicate), one that push_back dropped is not
-                    if (a.filter_entries != 0u && lane == 0) {
-                        if (tag8) filt8[id & fmask] = static_cast<uint8_t>(id >> fshift);
-                        else filt[id & fmask] = static_cast<uint16_t>(id >> fshift);
-                    }
-                    // push_back + (stable) sort == ordered insert without the duplicate check
-                    uint32_t pos = append_then_sort ? buf.size : 0u;
-                    for (uint32_t i0 = 0; !append_then_sort && i0 < buf.size; i0 += 64) {
-                        const uint32_t i = i0 + lane;
-                        bool before = false;
-                        if (i < buf.size) before = !cmpf<GREATER>(dd, __uint_as_float(buf.e[i].x));
-                        pos += __popcll(__ballot(before));
-                    }
-                    lds_order();
-                    for (int i = static_cast<int>(buf.size) - 1; i >= static_cast<int>(pos); --i) {
-                        if (lane == 0) buf.e[i + 1] = buf.e[i];
-                    }
-                    if (lane == 0) buf.e[pos] = make_uint2(__float_as_uint(dd), id);
-                    lds_order();
-                    buf.size++;
-                }
-            }
-        }
-    }
-
-    if constexpr (GENERAL) {
-        if (resume) { // RestartInitializer (iterator.h:36-63): keep the previous contents, sort()
-            buf.size = it_meta[0];
-            buf.best_unvisited = it_meta[1];
-            const uint2* src = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
-            for (uint32_t i = lane; i < buf.size; i += 64) {
-                const uint2 en = src[i];
-                buf.e[i] = en;
-                nan_seen = nan_seen || __uint_as_float(en.x) != __uint_as_float(en.x);
-            }
-            nan_seen = __ballot(nan_seen) != 0ull; // a NaN left in the buffer by an earlier call
-            lds_order();
-            wave_std_sort<GREATER>(buf, sort_stack, lane, true);
-        } else if (append_then_sort) {
-            wave_std_sort<GREATER>(buf, sort_stack, lane, false);
-        }
-    }
-
-    bool full = buf.size == buf.capacity;
-    float worst = (full && buf.capacity > 0u) ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
-
-    // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
-    int cancel_seen = 0;
-    while (!wave_done(buf)) {
-        if (a.cancel != nullptr) { // greedy_search.h:155: `if (cancel()) return;` -- the word read here is consumed one expansion later
-            if (cancel_seen != 0) break;
-            cancel_seen = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        float node_dist;
-        const uint32_t node = wave_next(buf, lane, node_dist);
-        if (a.history_ids != nullptr && lane == 0 && n_exp < a.history_cap) {
-            a.history_ids[static_cast<size_t>(qi) * a.history_cap + n_exp] = node;
-            if (a.history_dists != nullptr) a.history_dists[static_cast<size_t>(qi) * a.history_cap + n_exp] = node_dist;
-        }
-        ++n_exp;
-        const uint32_t* grow = a.graph + static_cast<size_t>(node) * a.gstride;
-        for (uint32_t gbase = 0; gbase < a.gstride; gbase += 64) {
-            uint32_t nid = kInvalidId;
-            [[maybe_unused]] uint4 rec[RW];
-#pragma unroll
-            for (int p = 0; p < RW; ++p) rec[p] = make_uint4(0u, 0u, 0u, 0u);
-            if constexpr (FAT) {
-                // one contiguous block per chunk: [ids | plane 0 | ... | plane RW-1]; lane c owns neighbour c and its record
-                const uint32_t cs = (a.gstride - gbase) < 64u ? (a.gstride - gbase) : 64u;
-                const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(gbase) * (4u + 16u * RW));
-                const uint4* planes = reinterpret_cast<const uint4*>(fids + cs);
-                if (lane < cs) {
-                    nid = fids[lane];
-#pragma unroll
-                    for (int p = 0; p < RW; ++p) rec[p] = planes[static_cast<uint32_t>(p) * cs + lane];
-                }
-            } else {
-                if (gbase + lane < a.gstride) nid = grow[gbase + lane];
-            }
-            const uint32_t deg_here = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
-            n_slots += deg_here;
-            uint32_t cnt = deg_here;
-            if constexpr (FAT) {
-                bool keep = nid != kInvalidId;
-                // visited filter (greedy_search.h:191-193), here holding only the ids whose rows were really fetched: a candidate the
-                // bound rejected is rejected again by the bound (worst only improves) at no memory cost, so it need not be
-                // remembered -- the same table then covers the whole query almost without evictions.  A hit = this id went
-                // through the exact path earlier in this query, re-inserting it would be a no-op.
-                const uint32_t fh = nid & fmask, ftag = nid >> fshift; // 16-bit tags only (the host never asks for 8-bit tags with inline records)
-                const bool use_filter = a.filter_entries != 0u && !nan_seen; // with a NaN in the buffer a repeated insert is no longer a no-op
-                if (use_filter && keep) keep = static_cast<uint32_t>(filt[fh]) != ftag;
-                if (full) {
-                    // bound of every candidate of this chunk, lane-parallel (svsx_codes.hip has the geometry).  `worst` can only
-                    // improve while this expansion's survivors are inserted, so a bound taken against it stays valid.
-                    bool rej;
-                    constexpr int NW = RW * 4;  // words per record; the last one holds float16 fields
-                    auto recw = [&](int w) -> uint32_t {
-                        const uint4& r = rec[w >> 2];
-                        return (w & 3) == 0 ? r.x : (w & 3) == 1 ? r.y : (w & 3) == 2 ? r.z : r.w;
-                    };
-                    uint32_t qw[NW];
-                    if constexpr (RW == 2) {
-#pragma unroll
-                        for (int w = 0; w < 7; ++w) qw[w] = fq[w];
-                        qw[7] = 0u;
-                    } else { // larger records: the query's code words come from LDS (broadcast reads)
-#pragma unroll
-                        for (int p = 0; p < RW; ++p) {
-                            const uint4 q4 = reinterpret_cast<const uint4*>(qcodes)[p];
-                            qw[4 * p] = q4.x; qw[4 * p + 1] = q4.y; qw[4 * p + 2] = q4.z; qw[4 * p + 3] = q4.w;
-                        }
-                    }
-                    const uint32_t last = recw(NW - 1), prev = recw(NW - 2);
-                    if constexpr (METRIC == M_L2) {
-                        // A = max(0, s sqrt(I) - e), e = eq + ex;  B = max(0, |tq - tx| - slack):  dist >= A^2 + B^2.  Reject iff
-                        // A^2 + B^2 > W' := worst * 1.0001, implied by  s^2 I > W' - B^2 + e (2 sqrt(W') + e)  (one square root per hop)
-                        const float wp = worst * 1.0001f;
-                        const float r2 = 2.0f * __builtin_amdgcn_sqrtf(wp) * 1.00001f;
-                        uint32_t dqx = 0u, dxx = 0u;
-#pragma unroll
-                        for (int w = 0; w < NW - 1; ++w) {
-                            dqx = __builtin_amdgcn_udot4(recw(w), qw[w], dqx, false);
-                            dxx = __builtin_amdgcn_udot4(recw(w), recw(w), dxx, false);
-                        }
-                        const float fi = static_cast<float>(fat_qq + static_cast<int>(dxx) - 2 * static_cast<int>(dqx)); // sum (cq - cx)^2 < 2^24: exact
-                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last & 0xFFFFu))) * a.pca_step;
-                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last >> 16))) * a.pca_tail_unit;
-                        const float e = fat_eq + ex;
-                        const float txe = tx * 4.94e-4f + a.pca_tail_unit * 6.0e-8f; // tx is a nearest float16: 2^-11 relative
-                        const float t1 = fat_tq_lo - (tx + txe), t2 = (tx - txe) - fat_tq_hi;
-                        const float t = t1 > t2 ? t1 : t2;
-                        const float bb = (t > 0.0f ? t : 0.0f) * 0.99999f;
-                        const float rhs = wp - bb * bb + e * (r2 + e) * 1.00001f;
-                        rej = fi * fat_s2m > rhs; // false for NaN / inf thresholds
-                    } else {
-                        // q . z <= s^2 I + ||uhat|| ex + eq (ny + ex) + tq tx,  I = sum cq cx (exact);  all record fields are upper bounds
-                        int dot = 0;
-#pragma unroll
-                        for (int w = 0; w < NW - 1; ++w) // word NW-2: codes in its low half, a float16 above -- the query's bytes there are 0
-                            dot = __builtin_amdgcn_sdot4(static_cast<int>(recw(w)), static_cast<int>(qw[w]), dot, false);
-                        const float main = fat_s2m * static_cast<float>(dot);
-                        const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(prev >> 16))) * a.pca_step;
-                        const float ny = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last & 0xFFFFu))) * a.pca_step;
-                        const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last >> 16))) * a.pca_tail_unit;
-                        const float pos = fat_nuh * ex + fat_eq * (ny + ex) + fat_tq_hi * tx;
-                        float ub = main + pos + (__builtin_fabsf(main) + pos) * 4.0e-6f;
-                        if constexpr (METRIC == M_COS) {
-                            // records hold the UNIT vector and the query was scaled to unit norm: `ub` bounds the real cosine; the
-                            // reference's float32 result is within (d + 8) 2^-24 of it (|cos| <= 1)
-                            ub += static_cast<float>(d + 8) * 6.3e-8f + 1.0e-7f;
-                        } else {
-                            // the reference's own float32 accumulation: |computed - real| <= (d + 2) 2^-24 ||q|| ||z||
-                            ub += static_cast<float>(d + 2) * 6.1e-8f * fat_nq * (ny + ex + tx + a.pca_ref_extra);
-                        }
-                        rej = ub < worst; // false whenever anything is NaN / inf
-                    }
-                    const uint32_t nrej = __popcll(__ballot(keep && rej));
-                    n_code_rej += nrej;
-                    n_eval += nrej;
-                    keep = keep && !rej;
-                }
-                if (use_filter && keep) filt[fh] = static_cast<uint16_t>(ftag);
-                const unsigned long long km = __ballot(keep);
-                cnt = __popcll(km);
-                const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
-                lds_order();
-                if (keep) compact[rank] = nid;
-                lds_order();
-                nid = lane < cnt ? compact[lane] : kInvalidId;
-                lds_order();
-            } else if (a.filter_entries != 0u && !nan_seen) { // with a NaN in the buffer a repeated insert is no longer a no-op: filter off
-                // emplace_visited (greedy_search.h:191-193): drop ids already evaluated, keep adjacency order
-                bool keep = nid != kInvalidId;
-                if (keep) {
-                    const uint32_t h = nid & fmask;
-                    const uint32_t tag = nid >> fshift;
-                    if (tag8) {
-                        keep = static_cast<uint32_t>(filt8[h]) != tag;
-                        filt8[h] = static_cast<uint8_t>(tag);
-                    } else {
-                        keep = static_cast<uint32_t>(filt[h]) != tag;
-                        filt[h] = static_cast<uint16_t>(tag);
-                    }
-                }
-                const unsigned long long km = __ballot(keep);
-                cnt = __popcll(km);
-                const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
-                lds_order();
-                if (keep) compact[rank] = nid;
-                lds_order();
-                nid = lane < cnt ? compact[lane] : kInvalidId;
-                lds_order();
-            }
-            if constexpr (CODES == 1) {
-                if (full && cnt > 0u) {
-                    // bound pass over all candidates of this expansion; survivors keep their adjacency order.  `worst` can
-                    // only improve while they are inserted, so a bound taken against the current worst stays valid.
-                    // reject iff  scale * sqrt(I) * 0.99998 - eq - ex > sqrt(worst * 1.0001),  I = sum (cq - cx)^2; with
-                    // T = (sqrt(worst * 1.0001) * 1.00001 + eq + ex) / (0.99998 * scale) this is implied by I > T^2 * 1.00001
-                    // (one square root per expansion instead of one per candidate)
-                    const float sthr = __builtin_sqrtf(worst * 1.0001f) * 1.00001f + code_eq;
-                    const float tscale = 1.00002f / a.code_scale * 1.000001f;
-                    uint32_t nsurv = 0;
-                    // the code rows of CB passes (16 candidates each) are requested together before the first is used:
-                    // fewer dependent memory round trips per expansion
-                    constexpr int CB = SVSX_CODE_BATCH;
-                    for (int pg = 0; pg < 4 && static_cast<uint32_t>(pg) * RPP < cnt; pg += CB) {
-                    uint4 c0[CB], c1[CB];
-                    uint32_t pcid[CB];
-#pragma unroll
-                    for (int pp = 0; pp < CB; ++pp) {
-                        const int p = pp;
-                        const uint32_t ci = static_cast<uint32_t>(pg + pp) * RPP + grp;
-                        pcid[p] = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
-                        if (static_cast<uint32_t>(pg + pp) * RPP < cnt) {
-                            const uint4* crow = reinterpret_cast<const uint4*>(a.codes + static_cast<size_t>(ci < cnt ? pcid[p] : 0u) * 128u) + sub * 2;
-                            c0[p] = crow[0];
-                            c1[p] = crow[1];
-                        }
-                    }
-#pragma unroll
-                    for (int pp = 0; pp < CB; ++pp) {
-                        const int p = pp;
-                        if (static_cast<uint32_t>(pg + pp) * RPP >= cnt) break;
-                        const uint32_t ci = static_cast<uint32_t>(pg + pp) * RPP + grp;
-                        const uint32_t cid = pcid[p];
-                        const bool act = ci < cnt;
-                        uint32_t dot = 0;
-                        dot = __builtin_amdgcn_udot4(c0[p].x, qc[0], dot, false);
-                        dot = __builtin_amdgcn_udot4(c0[p].y, qc[1], dot, false);
-                        dot = __builtin_amdgcn_udot4(c0[p].z, qc[2], dot, false);
-                        dot = __builtin_amdgcn_udot4(c0[p].w, qc[3], dot, false);
-                        dot = __builtin_amdgcn_udot4(c1[p].x, qc[4], dot, false);
-                        dot = __builtin_amdgcn_udot4(c1[p].y, qc[5], dot, false);
-                        dot = __builtin_amdgcn_udot4(c1[p].z, qc[6], dot, false); // qc[6], qc[7] are 0 in the lane that holds the row tail
-                        dot = __builtin_amdgcn_udot4(c1[p].w, qc[7], dot, false);
-                        int part = -2 * static_cast<int>(dot);
-                        float ex = 0.0f;
-                        if (sub == 3) {
-                            ex = __uint_as_float(c1[p].z);
-                            part += static_cast<int>(c1[p].w);
-                        }
-                        part += xor1i(part);
-                        part += xor2i(part);
-                        ex += xor1f(ex);
-                        ex += xor2f(ex);
-                        const float isum = static_cast<float>(code_qq + part); // sum (cq - cx)^2 < 2^24: exact
-                        const float t = (sthr + ex) * tscale;
-                        const bool rej = isum > t * t * 1.00001f; // false for NaN / inf thresholds
-                        const bool surv = act && !rej && sub == 0;
-                        const unsigned long long sm = __ballot(surv);
-                        if (surv) compact[nsurv + __popcll(sm & ((1ull << lane) - 1ull))] = cid;
-                        nsurv += __popcll(sm);
-                    }
-                    }
-                    lds_order();
-                    nid = lane < nsurv ? compact[lane] : kInvalidId;
-                    lds_order();
-                    n_code_rej += cnt - nsurv;
-                    n_eval += cnt - nsurv;
-                    cnt = nsurv;
-                }
-            }
-            for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
-                const uint32_t ci = p0 + grp;
-                const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
-                const bool act = ci < cnt;
-                const float dist = group_distance(cid, act, full ? worst * 1.00004f : __builtin_inff());
-                const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
-                const bool cand = act && sub == 0 && !skip;
-                unsigned long long m = __ballot(cand);
-                n_eval += (cnt - p0) < static_cast<uint32_t>(RPP) ? (cnt - p0) : static_cast<uint32_t>(RPP);
-                if constexpr (!GENERAL) {
-                    // all accepted candidates of the pass in ONE merge (wave_merge_insert); NaN distances and duplicates of buffer
-                    // entries (possible when the visited filter is off or evicted) take the one-by-one path below
-                    if (m != 0ull && buf.capacity <= (BIG == 2 ? 1024u : BIG == 1 ? 512u : 128u)) {
-                        nan_seen = nan_seen || (__ballot(cand && dist != dist) != 0ull);
-                        const bool finite = __ballot(cand && !(__builtin_fabsf(dist) < __builtin_inff())) == 0ull;
-                        bool merged = false;
-                        if (!nan_seen && finite) {
-                            if constexpr (BIG == 2) {
-                                merged = wave_merge_insert<GREATER, 16>(buf, cand, dist, cid, lane, n_ins);
-                            } else if constexpr (BIG == 1) {
-                                if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, cand, dist, cid, lane, n_ins);
-                                else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins);
-                            } else {
-                                merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins);
-                            }
-                        }
-                        if (merged) {
-                            m = 0ull;
-                            full = buf.size == buf.capacity;
-                            if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
-                        }
-                    }
-                }
-                while (m != 0ull) {
-                    const int bl = __builtin_ctzll(m);
-                    m &= m - 1ull;
-                    const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
-                    if (full && cmpf<GREATER>(worst, dd)) continue; // worst may have improved within this pass
-                    const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
-                    nan_seen = nan_seen || dd != dd;
-                    if (wave_insert<GREATER>(buf, dd, id, lane, nan_seen)) {
-                        ++n_ins;
-                        full = buf.size == buf.capacity;
-                        if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
-                    }
-                }
-            }
-            if (deg_here < 64u) break;
-        }
-    }
-
-    if constexpr (GENERAL) {
-        if (it_meta != nullptr) {
-            // ---- save the buffer for the next call; copy_from_scratch (iterator.h:104-124): the best entries not yet
-            // handed out, in buffer order, at most batch_size of them -------------------------------------------------------
-            uint2* dst = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
-            for (uint32_t i = lane; i < buf.size; i += 64) dst[i] = buf.e[i];
-            const uint32_t n_old = it_meta[4];
-            uint32_t* yl = a.it_yielded + static_cast<size_t>(qi) * a.it_ystride;
-            uint32_t got = 0;
-            for (uint32_t base = 0; base < buf.size && got < it_bs; base += 64) {
-                const uint32_t i = base + lane;
-                const bool valid = i < buf.size;
-                uint2 en = make_uint2(0u, kInvalidId);
-                if (valid) en = buf.e[i];
-                const uint32_t id = valid ? (en.y & kIdMask) : kInvalidId;
-                bool fresh = valid;
-                for (uint32_t y0 = 0; y0 < n_old; y0 += 64) {
-                    if (__ballot(fresh) == 0ull) break;
-                    uint32_t yv = kInvalidId;
-                    if (y0 + lane < n_old) yv = yl[y0 + lane];
-                    for (int t = 0; t < 64; ++t) {
-                        const uint32_t v = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(yv), t));
-                        fresh = fresh && (v != id);
-                    }
-                }
-                const unsigned long long fm = __ballot(fresh);
-                const uint32_t rank = got + __popcll(fm & ((1ull << lane) - 1ull));
-                if (fresh && rank < it_bs) {
-                    a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + rank] = static_cast<uint64_t>(id) + a.id_offset;
-                    a.it_out_dists[static_cast<size_t>(qi) * a.it_batch + rank] = __uint_as_float(en.x);
-                    yl[n_old + rank] = id;
-                }
-                const uint32_t add = __popcll(fm);
-                got = (got + add < it_bs) ? got + add : it_bs;
-            }
-            for (uint32_t j = got + lane; j < a.it_batch; j += 64) {
-                a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + j] = ~0ull;
-                a.it_out_dists[static_cast<size_t>(qi) * a.it_batch + j] = __builtin_inff();
-            }
-            if (lane == 0) {
-                a.it_counts[qi] = got;
-                it_meta[0] = buf.size;
-                it_meta[1] = buf.best_unvisited;
-                it_meta[2] = buf.window;
-                it_meta[3] = buf.capacity;
-                it_meta[4] = n_old + got;
-                it_meta[5] = it_meta[5] + 1u;
-                it_meta[6] = (got == 0u && it_bs > 0u) ? 2u : 0u; // restart_search_ = false; is_exhausted_ (:311-316)
-            }
-        }
-    }
-
-    // ---- copy-back (extensions.h:588-590), padded like vamana_index_impl.h:205-209 -----------------------------
-    for (uint32_t j = lane; j < a.k; j += 64) {
-        uint32_t id = kInvalidId;
-        float dist = __builtin_inff();
-        const bool have = j < buf.size;
-        if (have) {
-            const uint2 en = buf.e[j];
-            id = en.y & kIdMask;
-            dist = __uint_as_float(en.x);
-        }
-        const size_t o = static_cast<size_t>(qi) * a.k + j;
-        if (a.ids64 != nullptr) a.ids64[o] = have ? (static_cast<uint64_t>(id) + a.id_offset) : ~0ull;
-        if (a.ids32 != nullptr) a.ids32[o] = have ? static_cast<uint32_t>(id + static_cast<uint32_t>(a.id_offset)) : kInvalidId;
-        if (a.dists != nullptr) a.dists[o] = dist;
-    }
-    if (lane == 0) {
-        if (a.stats != nullptr) {
-            uint32_t* st = a.stats + static_cast<size_t>(qi) * 6;
-            st[0] = n_exp;
-            st[1] = n_slots;
-            st[2] = n_eval;
-            st[3] = n_ins;
-            st[4] = n_early;
-            st[5] = n_code_rej;
-        }
-        if (a.history_len != nullptr) a.history_len[qi] = n_exp;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 static thread_local char g_last_inst[96] = "";
 const char* last_search_instantiation() { return g_last_inst; }
+char* last_search_instantiation_buffer() { return g_last_inst; }
 
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
-    if constexpr (!GENERAL && BIG == 0) {
-        if (a.capacity > 128u && a.capacity <= 512u) return launch_one<DT, METRIC, QMODE, DS, GENERAL, CODES, 1>(a, stream);
-        if (a.capacity > 512u && a.capacity <= 1024u) return launch_one<DT, METRIC, QMODE, DS, GENERAL, CODES, 2>(a, stream);
-    }
-    snprintf(g_last_inst, sizeof(g_last_inst), "search_kernel<dt=%d,metric=%d,qmode=%d,ds=%d,general=%d,codes=%d>", DT, METRIC, QMODE, DS, GENERAL ? 1 : 0, CODES);
-    const int d = static_cast<int>(a.d);
-    const int dpad = (d + 15) & ~15;
-    const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
-    const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
-    const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
-                       (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (CODES >= 3 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = search_kernel<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), lds, stream, a);
-    return hipGetLastError();
-}
-
-template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
-    if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
-    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
-        if (a.fat != nullptr && a.fat_rb == 32 && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 2>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 32 && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 2>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 32) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 64) return launch_one<DT, METRIC, QMODE, 0, false, 3>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
-    }
-    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && (DT == DT_I8 || DT == DT_U8)) {
-        if (a.fat != nullptr && a.fat_rb == 32 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 2>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 32) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 64 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 3>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 64) return launch_one<DT, METRIC, QMODE, 0, false, 3>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 128 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 4>(a, stream);
-        if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
-    }
-    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && METRIC == M_L2) {
-        if (a.codes != nullptr && a.d == 96) return launch_one<DT, METRIC, QMODE, 96, false, 1>(a, stream);
-        if (a.codes != nullptr && a.d == 128) return launch_one<DT, METRIC, QMODE, 128, false, 1>(a, stream);
-    }
-    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
-        if (a.d == 96) return launch_one<DT, METRIC, QMODE, 96>(a, stream);
-        if (a.d == 128) return launch_one<DT, METRIC, QMODE, 128>(a, stream);
-    }
-    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && (DT == DT_I8 || DT == DT_U8)) {
-        if (a.d == 768) return launch_one<DT, METRIC, QMODE, 768>(a, stream);
-    }
-    return launch_one<DT, METRIC, QMODE, 0>(a, stream);
-}
-
-template <int DT, int QMODE> static hipError_t launch_metric(int metric, const SearchArgs& a, hipStream_t stream) {
-    switch (metric) {
-        case M_L2:
-            if constexpr (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
-            else return launch_dim<DT, M_L2, QMODE>(a, stream);
-        case M_IP:
-            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
-            else return launch_dim<DT, M_IP, QMODE>(a, stream);
-        case M_COS:
-            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_IP) return hipErrorInvalidValue;
-            else return launch_dim<DT, M_COS, QMODE>(a, stream);
-        default: return hipErrorInvalidValue;
-    }
-}
+hipError_t launch_search_f32(int metric, int qmode, const SearchArgs& a, hipStream_t stream);
+hipError_t launch_search_f16(int metric, int qmode, const SearchArgs& a, hipStream_t stream);
+hipError_t launch_search_i8(int metric, int qmode, const SearchArgs& a, hipStream_t stream);
+hipError_t launch_search_u8(int metric, int qmode, const SearchArgs& a, hipStream_t stream);
 
 hipError_t launch_search(int data_dtype, int metric, int qmode, const SearchArgs& a, hipStream_t stream) {
-    switch (qmode) {
-        case QM_FLOAT:
-            switch (data_dtype) {
-                case DT_F32: return launch_metric<DT_F32, QM_FLOAT>(metric, a, stream);
-                case DT_F16: return launch_metric<DT_F16, QM_FLOAT>(metric, a, stream);
-                case DT_I8: return launch_metric<DT_I8, QM_FLOAT>(metric, a, stream);
-                case DT_U8: return launch_metric<DT_U8, QM_FLOAT>(metric, a, stream);
-            }
-            break;
-        case QM_INT:
-            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_INT>(metric, a, stream);
-            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_INT>(metric, a, stream);
-            break;
-        case QM_SQ_IP:
-            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_SQ_IP>(metric, a, stream);
-            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_SQ_IP>(metric, a, stream);
-            break;
-        case QM_SQ_COS:
-            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_SQ_COS>(metric, a, stream);
-            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_SQ_COS>(metric, a, stream);
-            break;
-        case QM_SQ_L2:
-            if (data_dtype == DT_I8) return launch_metric<DT_I8, QM_SQ_L2>(metric, a, stream);
-            if (data_dtype == DT_U8) return launch_metric<DT_U8, QM_SQ_L2>(metric, a, stream);
-            break;
+    switch (data_dtype) {
+        case DT_F32: return launch_search_f32(metric, qmode, a, stream);
+        case DT_F16: return launch_search_f16(metric, qmode, a, stream);
+        case DT_I8: return launch_search_i8(metric, qmode, a, stream);
+        case DT_U8: return launch_search_u8(metric, qmode, a, stream);
     }
     return hipErrorInvalidValue;
 }

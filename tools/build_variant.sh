@@ -8,8 +8,8 @@ OUT=$R/variants/$NAME
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-unused-function"
 cd $R/scalablevectorsearch_amd/csrc
-for f in svsx_search; do /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o $OUT/$f.o & done
+for f in svsx_search_f32 svsx_search_f16 svsx_search_i8 svsx_search_u8; do /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o $OUT/$f.o & done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsvsx.so $OUT/svsx_search.o svsx_api.o svsx_distance.o svsx_build.o svsx_flat.o svsx_codes.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsvsx.so $OUT/svsx_search_f32.o $OUT/svsx_search_f16.o $OUT/svsx_search_i8.o $OUT/svsx_search_u8.o svsx_search.o svsx_api.o svsx_distance.o svsx_build.o svsx_flat.o svsx_codes.o
 rm -f $OUT/*.o
 echo built $OUT/libsvsx.so
