@@ -120,10 +120,11 @@ def _emit(line: str):
 
 
 def kernel_src_sha() -> str:
-    """Hash of the kernel sources: a PMC summary is only reused for the kernels it was measured on."""
+    """Hash of the device-code sources: a PMC summary is only reused for the kernels it was measured on."""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "scalablevectorsearch_amd", "csrc", "*.h*"))):
-        h.update(open(f, "rb").read())
+        if os.path.basename(f) != "svsx_api.hip":  # host-side C ABI: no device code
+            h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -134,7 +135,7 @@ def stat3(ms_list, nq):
             "qps_at_median": nq / (float(np.median(a)) * 1e-3), "qps_best": nq / (float(a[0]) * 1e-3)}
 
 
-def designed_lines(stats_i64, gstride, row_bytes, bound_codes, d, k):
+def designed_lines(stats_i64, gstride, row_bytes, bound_codes, d, k, record_bytes=32):
     """128-byte lines one launch is DESIGNED to request (what `roofline.achieved` prices): per expansion the adjacency block
     (ids, + inline records in mode 2), one code line per evaluated candidate in mode 1, the full row of every candidate
     that reaches the exact path (entry point, survivors of the bound / all evaluated candidates without a bound), the
@@ -146,7 +147,7 @@ def designed_lines(stats_i64, gstride, row_bytes, bound_codes, d, k):
     nq = stats_i64.shape[0]
     row_lines = -(-row_bytes // LINE)
     if bound_codes == 2:
-        adj = exp * (-(-(gstride * 36) // LINE))
+        adj = exp * (-(-(gstride * (4 + record_bytes)) // LINE))
         code = 0
     else:
         adj = exp * (-(-(gstride * 4) // LINE))
@@ -409,7 +410,9 @@ def main():
     exp_total, slots_total = int(st[:, 0].sum()), int(st[:, 1].sum())
     # SURVEY 8(d) algorithmic bytes of the REFERENCE traversal (visited set off, whole rows): reported, never used as the roofline fraction
     ref_alg_bytes = 4 * (exp_total + slots_total) + slots_total * d * 4 + local_shards * nq * (d * 4 + d * 4 + k * 12)
-    lines = designed_lines(stats.to(torch.int64).reshape(-1, 6), gstride, d * 4, mode, d, k)
+    kinfo = shards[0]["index"].last_kernel_info()  # ...codes=2/3/4> = 32- / 64- / 128-byte inline records
+    record_bytes = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(kinfo[-8:], 32)
+    lines = designed_lines(stats.to(torch.int64).reshape(-1, 6), gstride, d * 4, mode, d, k, record_bytes)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----------------------------------------
     for _ in range(args.warmup):
@@ -518,7 +521,7 @@ def main():
             "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "measured_copy_GBs": copy_gbs,
             "frac_of_measured_copy": achieved / copy_gbs,
-            "kernel": "svsx::search_kernel<f32,L2,float,96,codes=%d>" % mode,
+            "kernel": "svsx::" + kinfo,
             "kernel_ms": kern_ms,
             "kernel_src_sha": kernel_src_sha(),
             "designed_bytes_per_launch": designed_bytes,
@@ -578,7 +581,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         mk_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in mev]))
-        mlines = designed_lines(mstats.to(torch.int64), gstride, d * 4, mode, d, k)
+        mlines = designed_lines(mstats.to(torch.int64), gstride, d * 4, mode, d, k, record_bytes)
         mt, mt_src, _ = measured_traffic(f"{args.config}:n={n}:nq={nq}:window={lo_w}:R={R}:visited={args.visited}:codes={mode}")
         matched = {"window": lo_w, "recall_at_10": recall_at(gt, ids, k), "gpu_qps": nq * args.steps / dt, "kernel_ms": mk_ms,
                    "designed_lines_per_query": mlines["total"] / nq, "achieved_GBs": mlines["total"] * LINE / (mk_ms * 1e-3) / 1e9,

@@ -421,10 +421,10 @@ int build_fat_rows(svsx_index* ix) {
         }
     // 3. leading directions by subspace iteration + Rayleigh-Ritz (ANY orthonormal set is valid for the bound; a good one
     //    makes it tight).  m >= dc columns for convergence margin.
-    // candidate record sizes: a record larger than a sixth of the row it protects cannot pay for itself
+    // candidate record sizes: a record larger than a third of the row it protects cannot pay for itself
     uint32_t rb_max = 32;
-    if (ix->row_bytes >= 6 * 64) rb_max = 64;
-    if (ix->row_bytes >= 6 * 128) rb_max = 128;
+    if (ix->row_bytes >= 3 * 64) rb_max = 64;
+    if (ix->row_bytes >= 3 * 128) rb_max = 128;
     const uint32_t m = d < rb_max - meta + 12u ? d : rb_max - meta + 12u;
     std::vector<double> V(static_cast<size_t>(d) * m), W(static_cast<size_t>(d) * m);
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
@@ -471,7 +471,8 @@ int build_fat_rows(svsx_index* ix) {
     for (uint32_t i = 0; i < m; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return T[static_cast<size_t>(x) * m + x] > T[static_cast<size_t>(y) * m + y]; });
     // smallest record whose directions carry >= 95 % of the sample's second moment (the remainder only enters the bound through
-    // the product of remainder norms, which is loose); 32 bytes when nothing larger is allowed
+    // the product of remainder norms, which is loose); when none does (flat spectrum) the largest allowed one -- for d <= 124 that
+    // covers every dimension, like the 128-byte code rows of mode 1
     double trace = 0.0;
     for (uint32_t i = 0; i < d; ++i) trace += cov[static_cast<size_t>(i) * d + i];
     uint32_t rb = 32;
