@@ -470,16 +470,27 @@ int build_fat_rows(svsx_index* ix) {
     std::vector<uint32_t> order(m);
     for (uint32_t i = 0; i < m; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return T[static_cast<size_t>(x) * m + x] > T[static_cast<size_t>(y) * m + y]; });
-    // smallest record whose directions carry >= 95 % of the sample's second moment (the remainder only enters the bound through
-    // the product of remainder norms, which is loose); when none does (flat spectrum) the largest allowed one -- for d <= 124 that
-    // covers every dimension, like the 128-byte code rows of mode 1
+    // Record size by expected lines per hop: block lines (4 + RB bytes per slot) + the rows of the candidates the bound cannot
+    // exclude.  How many it excludes follows the share f of the sample's second moment the coded directions carry -- the remainder
+    // only enters the bound through a product of norms, which is loose: measured (profiles/r02_notes.md) the bound is useless
+    // below f ~ 0.6 and rejects ~88 % of the candidates at f ~ 1 -- modelled as rej = 0.88 clamp((f - 0.6) / 0.3, 0, 1).  A larger
+    // record must win by 10 % (the 32-byte form has static-dimension kernels and the fewest registers).
     double trace = 0.0;
     for (uint32_t i = 0; i < d; ++i) trace += cov[static_cast<size_t>(i) * d + i];
+    const double row_lines = static_cast<double>((ix->row_bytes + 127) / 128);
+    const double cand = 0.9 * static_cast<double>(ix->gstride);
     uint32_t rb = 32;
-    for (; rb < rb_max; rb *= 2) {
+    double best_cost = 0.0;
+    for (uint32_t r = 32; r <= rb_max; r *= 2) {
         double got = 0.0;
-        for (uint32_t c = 0; c < rb - meta && c < m; ++c) got += std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0);
-        if (got >= 0.95 * trace) break;
+        for (uint32_t c = 0; c < r - meta && c < m; ++c) got += std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0);
+        const double f = trace > 0.0 ? got / trace : 1.0;
+        const double rej = 0.88 * std::min(std::max((f - 0.6) / 0.3, 0.0), 1.0);
+        const double cost = static_cast<double>(ix->gstride) * (4.0 + r) / 128.0 + cand * (1.0 - rej) * row_lines;
+        if (r == 32 || cost < 0.9 * best_cost) {
+            best_cost = cost;
+            rb = r;
+        }
     }
     if (const char* force = getenv("SVSX_RECORD_BYTES")) { // experiments: 32 / 64 / 128
         const uint32_t f = static_cast<uint32_t>(atoi(force));
