@@ -230,8 +230,7 @@ int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
  * filter_estimate_batch = false).  id_bitmap: bit i of the (n + 63) / 64 words = IDFilter::is_member(i), local ids.
  * filter_stop: give up on a query (all-padding row) once its observed hit rate falls below it; 0 = never
  * (SearchParams::filter_stop, api_defs.h).  Per query the answer equals the reference's iterator loop: adaptive batches from
- * a BatchIterator until k members are found or the iterator is exhausted.  Host pointers, synchronous.
- * One iterator's search buffer is limited to 16 000 entries (one wave's LDS); a query that needs more keeps what it found. */
+ * a BatchIterator until k members are found or the iterator is exhausted.  Host pointers, synchronous. */
 int svsx_search_filtered(
     const svsx_index* index, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     const uint64_t* id_bitmap, float filter_stop, uint64_t* ids64, float* dists

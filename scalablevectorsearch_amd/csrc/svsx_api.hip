@@ -1234,8 +1234,10 @@ int svsx_iterator_next_device(
     if (batch_size >= 0xFFFFFFFFull) return fail(SVSX_INVALID_ARGUMENT, "batch size too large");
     const svsx_index* ix = it->ix;
     const size_t cap = it->max_capacity + batch_size;
-    if (cap > 16000)
-        return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu exceeds the LDS budget of one wave (restart with update())", cap);
+    // up to 16 000 entries the search buffer of a query lives in its wave's LDS; beyond that (low-hit-rate filters ask for batches
+    // up to n, vamana_index_impl.h:176-213) the kernel works in place on the query's row of the HBM state table
+    const bool spill = cap > 16000;
+    if (cap > (size_t(1) << 27)) return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu is out of range", cap);
     HIP_TRY(hipSetDevice(ix->device));
     size_t ybound = it->yield_bound + batch_size;
     if (ybound > ix->n) ybound = ix->n;
@@ -1244,8 +1246,9 @@ int svsx_iterator_next_device(
     SearchArgs a = base_search_args(ix, it->d_queries, it->q_dtype, it->q_stride, it->nq);
     a.general = 1;
     a.codes = nullptr;
-    a.window = static_cast<uint32_t>(cap); // per-query values come from the state table; this sizes the LDS buffer
-    a.capacity = static_cast<uint32_t>(cap);
+    a.window = static_cast<uint32_t>(spill ? 1 : cap); // per-query values come from the state table; this sizes the LDS buffer
+    a.capacity = static_cast<uint32_t>(spill ? 1 : cap);
+    a.it_spill = spill ? 1u : 0u;
     default_filter(ix, a, (ix->n >> 12) < 0xFFu ? 4096u : kDefaultFilterEntries); // result-neutral within one call
     a.it_entries = it->d_entries;
     a.it_estride = static_cast<uint32_t>(it->estride);
@@ -1332,16 +1335,8 @@ extern "C" int svsx_search_filtered(
         for (size_t i = 0; i < nq; ++i) {
             if (!active[i]) { per_query[i] = 0xFFFFFFFFu; continue; }
             batch[i] = predict(checked[i], found[i], k, batch[i], max_batch);
-            // the per-wave LDS budget bounds how far ONE iterator can grow; a batch that no longer fits is cut to what does
             per_query[i] = static_cast<uint32_t>(std::min<size_t>(batch[i], 0xFFFFFFFEu));
             round_max = std::max(round_max, batch[i]);
-        }
-        const size_t room = it->max_capacity < 16000 ? 16000 - it->max_capacity : 0;
-        if (room == 0) break; // buffers cannot grow any further: what was found so far stands (rows stay padded)
-        if (round_max > room) {
-            round_max = room;
-            for (size_t i = 0; i < nq; ++i)
-                if (active[i] && per_query[i] > room) per_query[i] = static_cast<uint32_t>(room);
         }
         b_ids.resize(nq * round_max);
         b_dists.resize(nq * round_max);

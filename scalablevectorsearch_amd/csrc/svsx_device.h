@@ -704,9 +704,18 @@ struct WaveBuffer {
     uint32_t best_unvisited;
     uint32_t window;
     uint32_t capacity;
+    bool hbm; // entries live in HBM (batched BatchIterator whose buffer outgrew one wave's LDS); constant false everywhere else
 };
 
 __device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+
+// Ordering of the cross-lane dependent accesses to the buffer.  In LDS a wave's operations execute in program order and a compiler
+// fence is all it takes; for a buffer in HBM the wave's own stores must have completed before other lanes reload them: a
+// workgroup-scope fence (s_waitcnt vmcnt(0); the wave's lanes share one L1, so no invalidate is needed).
+__device__ __forceinline__ void buf_order(const WaveBuffer& b) {
+    if (b.hbm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    else __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
 
 // SearchBuffer::insert_inner (search_buffer.h:353-403).  d / id are wave-uniform.  Returns true if inserted.
 // `unordered`: a NaN distance has reached the buffer, so it is no longer partitioned by the comparison and "the insert position"
@@ -736,7 +745,7 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
                 if ((en.y & kIdMask) == id) return false;
             } while (back != 0u);
         }
-        lds_order();
+        buf_order(b);
         const uint32_t end = b.size;
         if (end > pos) {
             const uint32_t nchunk = (end - pos + 63u) >> 6;
@@ -744,13 +753,13 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
                 const uint32_t i = pos + (static_cast<uint32_t>(c) << 6) + lane;
                 uint2 en = make_uint2(0, 0);
                 if (i < end) en = b.e[i];
-                lds_order();
+                buf_order(b);
                 if (i < end) b.e[i + 1] = en;
-                lds_order();
+                buf_order(b);
             }
         }
         if (lane == 0) b.e[pos] = make_uint2(__float_as_uint(d), id);
-        lds_order();
+        buf_order(b);
         b.size = (b.size + 1 < b.capacity) ? b.size + 1 : b.capacity;
         b.best_unvisited = pos < b.best_unvisited ? pos : b.best_unvisited;
         return true;
@@ -775,11 +784,11 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
         const unsigned long long m0 = __ballot(bf0), m1 = __ballot(bf1);
         if (__ballot(same) != 0ull) return false;
         const uint32_t pos = static_cast<uint32_t>(__popcll(m0) + __popcll(m1)); // sorted: the "before" entries are a prefix
-        lds_order();
+        buf_order(b);
         if (v0 && i0 >= pos) b.e[i0 + 1u] = e0;
         if (v1 && i1 >= pos) b.e[i1 + 1u] = e1;
         if (lane == 0) b.e[pos] = make_uint2(__float_as_uint(d), id);
-        lds_order();
+        buf_order(b);
         b.size = (b.size + 1 < b.capacity) ? b.size + 1 : b.capacity;
         b.best_unvisited = pos < b.best_unvisited ? pos : b.best_unvisited;
         return true;
@@ -803,7 +812,7 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
         if (cnt < nvalid) break; // sorted: nothing further can be "before"
     }
     if (dup) return false;
-    lds_order();
+    buf_order(b);
     // unsafe_insert: copy_backward [pos, size) one slot to the right, highest chunk first
     const uint32_t end = b.size;
     if (end > pos) {
@@ -812,13 +821,13 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
             const uint32_t i = pos + (static_cast<uint32_t>(c) << 6) + lane;
             uint2 en = make_uint2(0, 0);
             if (i < end) en = b.e[i];
-            lds_order();
+            buf_order(b);
             if (i < end) b.e[i + 1] = en;
-            lds_order();
+            buf_order(b);
         }
     }
     if (lane == 0) b.e[pos] = make_uint2(__float_as_uint(d), id);
-    lds_order();
+    buf_order(b);
     b.size = (b.size + 1 < b.capacity) ? b.size + 1 : b.capacity;
     b.best_unvisited = pos < b.best_unvisited ? pos : b.best_unvisited;
     return true;
@@ -882,7 +891,7 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
         minpos = le < minpos ? le : minpos;
     }
     if (__ballot(dupacc == 0u) != 0ull) return false;
-    lds_order();
+    buf_order(b);
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
         const uint32_t i = lane + 64u * t, p = i + c[t];
@@ -891,7 +900,7 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     const uint32_t pn = oldle + rank;
     const bool placed = cand && pn < b.capacity;
     if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
-    lds_order();
+    buf_order(b);
     n_inserted += static_cast<uint32_t>(__popcll(__ballot(placed)));
     b.size = (b.size + ncand < b.capacity) ? b.size + ncand : b.capacity;
     b.best_unvisited = minpos < b.best_unvisited ? minpos : b.best_unvisited;
@@ -901,9 +910,9 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
 // SearchBuffer::next (search_buffer.h:294-304): returns the node id, marks it visited, advances best_unvisited.
 __device__ __forceinline__ uint32_t wave_next(WaveBuffer& b, uint32_t lane, float& node_dist) {
     const uint2 en = b.e[b.best_unvisited];
-    lds_order();
+    buf_order(b);
     if (lane == 0) b.e[b.best_unvisited].y = en.y | kVisitedBit;
-    lds_order();
+    buf_order(b);
     node_dist = __uint_as_float(en.x);
     const uint32_t upper = b.size < b.window ? b.size : b.window;
     uint32_t nb = b.best_unvisited + 1;
@@ -976,7 +985,7 @@ __device__ __noinline__ void wave_std_sort(WaveBuffer& b, uint2* stack, uint32_t
         }
         if (!tie) return;
     }
-    lds_order();
+    buf_order(b);
     if (lane == 0) {
         uint2* a = b.e;
         uint32_t sp = 0;
@@ -1021,7 +1030,7 @@ __device__ __noinline__ void wave_std_sort(WaveBuffer& b, uint2* stack, uint32_t
             lane0_insertion_sort<GREATER>(a, 0u, n);
         }
     }
-    lds_order();
+    buf_order(b);
 }
 
 } // namespace svsx

@@ -61,6 +61,7 @@ struct SearchArgs {
     //   [0] size  [1] best_unvisited  [2] window  [3] capacity  [4] yielded  [5] iteration  [6] flags (1 restart, 2 exhausted)
     uint2* it_entries;       // [nq][it_estride] buffer entries {dist bits, id | visited << 31}
     uint32_t it_estride;
+    uint32_t it_spill;       // 1: the buffers no longer fit one wave's LDS; the kernel works on it_entries in place
     uint32_t* it_meta;       // nullptr = plain search
     uint32_t* it_yielded;    // [nq][it_ystride] ids already handed out, in yield order
     uint32_t it_ystride;

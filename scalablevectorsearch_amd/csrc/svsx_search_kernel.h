@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
 
     WaveBuffer buf;
     buf.e = reinterpret_cast<uint2*>(smem);
+    buf.hbm = false;
     buf.size = 0;
     buf.best_unvisited = 0;
     buf.window = a.window;
@@ -106,6 +107,10 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             buf.window = it_meta[2] + it_bs;      // SearchBufferConfig::increment (search_buffer.h:70-73)
             buf.capacity = it_meta[3] + it_bs;
             resume = (it_meta[6] & 1u) == 0u;
+            if (a.it_spill != 0u) { // the buffers outgrew one wave's LDS: work directly on this query's row of the state table in HBM
+                buf.e = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
+                buf.hbm = true;
+            }
         }
     }
     if constexpr (!GENERAL) {
@@ -337,12 +342,12 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                         if (i < buf.size) before = !cmpf<GREATER>(dd, __uint_as_float(buf.e[i].x));
                         pos += __popcll(__ballot(before));
                     }
-                    lds_order();
+                    buf_order(buf);
                     for (int i = static_cast<int>(buf.size) - 1; i >= static_cast<int>(pos); --i) {
                         if (lane == 0) buf.e[i + 1] = buf.e[i];
                     }
                     if (lane == 0) buf.e[pos] = make_uint2(__float_as_uint(dd), id);
-                    lds_order();
+                    buf_order(buf);
                     buf.size++;
                 }
             }
@@ -356,11 +361,11 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             const uint2* src = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
             for (uint32_t i = lane; i < buf.size; i += 64) {
                 const uint2 en = src[i];
-                buf.e[i] = en;
+                if (!buf.hbm) buf.e[i] = en;
                 nan_seen = nan_seen || __uint_as_float(en.x) != __uint_as_float(en.x);
             }
             nan_seen = __ballot(nan_seen) != 0ull; // a NaN left in the buffer by an earlier call
-            lds_order();
+            buf_order(buf);
             wave_std_sort<GREATER>(buf, sort_stack, lane, true);
         } else if (append_then_sort) {
             wave_std_sort<GREATER>(buf, sort_stack, lane, false);
@@ -643,7 +648,10 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             // ---- save the buffer for the next call; copy_from_scratch (iterator.h:104-124): the best entries not yet
             // handed out, in buffer order, at most batch_size of them -------------------------------------------------------
             uint2* dst = a.it_entries + static_cast<size_t>(qi) * a.it_estride;
-            for (uint32_t i = lane; i < buf.size; i += 64) dst[i] = buf.e[i];
+            if (!buf.hbm) {
+                for (uint32_t i = lane; i < buf.size; i += 64) dst[i] = buf.e[i];
+            }
+            buf_order(buf);
             const uint32_t n_old = it_meta[4];
             uint32_t* yl = a.it_yielded + static_cast<size_t>(qi) * a.it_ystride;
             uint32_t got = 0;

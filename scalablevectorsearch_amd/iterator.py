@@ -18,7 +18,6 @@ from . import _lib
 from .index import QueryResult, VamanaSearchParameters, dtype_code
 
 SKIP = 0xFFFFFFFF  # per-query batch size meaning "leave this query untouched"
-LDS_BUFFER_ENTRIES = 16000  # capacity limit of one iterator's search buffer (one wave's LDS)
 UNSIGNED_INTEGER_PLACEHOLDER = (1 << 64) - 1  # lib/preprocessor.h:177
 
 
@@ -150,14 +149,8 @@ def filtered_search(index, queries, k: int, is_member, search_parameters: Vamana
     while active.any():
         for i in np.flatnonzero(active):
             batch[i] = predict_further_processing(checked[i], found[i], k, batch[i], max_batch)
-        # one iterator's search buffer lives in one wave's LDS (16 000 entries, include/svsx.h): a predicted batch that no
-        # longer fits is cut to what does; once nothing fits, the queries still active keep what they found (same rule as
-        # svsx_search_filtered)
-        room = LDS_BUFFER_ENTRIES - getattr(it, "_cap_bound", LDS_BUFFER_ENTRIES - max_batch)  # the library's own bound: extra + sum of round sizes
-        if room <= 0:
-            break
-        step = np.minimum(batch, room)
-        per_query = np.where(active, step, SKIP).astype(np.uint32)
+        per_query = np.where(active, batch, SKIP).astype(np.uint32)
+        step = batch
         b_ids, b_dists, counts = it.next(int(step[active].max()), per_query)
         done = it.done()
         for i in np.flatnonzero(active):

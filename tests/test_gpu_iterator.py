@@ -187,11 +187,13 @@ def test_iterator_device_pointers_and_errors(svs, oracle, small_world):
         idx.batch_iterator(np.zeros((2, 5), np.float32))
     with pytest.raises(svs.SvsxError):  # scalar-fallback type pair
         idx.batch_iterator(np.zeros((2, 96), np.int8))
-    it2 = idx.batch_iterator(q, 15000)
-    with pytest.raises(svs.SvsxError):  # LDS budget of one wave
-        it2.next(2000)
-    ids, dists, counts = it2.next(10)  # the failed call left the state untouched
-    assert (counts == 10).all() and (it2.batch_number() == 1).all()
+    it2 = idx.batch_iterator(q[:2], 15000)
+    ids, dists, counts = it2.next(1400)  # 16 400 entries: beyond one wave's LDS, the buffer continues in HBM (1 500 points: everything comes out)
+    want2 = [oracle.iterate(L2, sw["x"], sw["graph"], sw["entry"], q[i], [1400], extra=15000) for i in range(2)]
+    for i in range(2):
+        got_n = int(counts[i])
+        assert got_n == len(want2[i][0][0][0]) and (ids[i, :got_n] == want2[i][0][0][0].astype(np.uint64)).all()
+    assert (it2.batch_number() == 1).all()
 
 
 def test_many_entry_points_use_std_sort_order(svs, oracle, small_world):
@@ -238,3 +240,34 @@ def test_range_and_filtered_search_on_gpu(svs, oracle, small_world):
     a = svs.filtered_search(idx, q, 3, few)
     c = idx.search_filtered(q, 3, few, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
     assert (a.indices == c.indices).all() and (c.indices != np.uint64(2**64 - 1)).all()
+
+
+def test_filtered_search_with_buffers_beyond_lds(svs, oracle):
+    """A filter almost nothing passes: the runtime's loop (vamana_index_impl.h:176-213) asks the iterator for batches of up to n,
+    so the per-query search buffer outgrows one wave's LDS (16 000 entries) and the kernel continues in place on the HBM state
+    table.  Same answers as the loop over the oracle's iterator, for the Python mirror and for svsx_search_filtered."""
+    import torch
+
+    from test_iterator_oracle import _FakeIndex, _OracleBatchIterator
+
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
+
+    n, d = 24_000, 32
+    x = deep_like(n, d, 8, seed=51)
+    q = deep_like(2, d, 8, seed=52)
+    g, entry = build_vamana_device(torch.from_numpy(x).cuda(), n, d, svs.DistanceL2(), VamanaBuildParameters(graph_max_degree=32, window_size=64, prune_to=28))
+    graph = device_graph_to_svs(g, 32)
+    ep = np.array([entry], np.uint32)
+    idx = svs.VamanaIndex(graph, x, svs.DistanceL2(), ep)
+    # window 4000: the loop starts with batches of 4000 (max(k, search_window_size)), so a handful of rounds cross the 16 000-entry line
+    idx.set_search_parameters(svs.VamanaSearchParameters(svs.SearchBufferConfig(4000)))
+    fake = _FakeIndex(oracle, L2, x, graph, ep, window=4000)
+    member = np.zeros(n, bool)
+    far = np.argsort(((x - q[0]) ** 2).sum(1))[-4:]  # the members are the points FARTHEST from the first query
+    member[far] = True
+    want = svs.filtered_search(fake, q, 3, member, make_iterator=_OracleBatchIterator)
+    got = svs.filtered_search(idx, q, 3, member)
+    assert (got.indices == want.indices).all() and (_bits(got.distances) == _bits(want.distances)).all()
+    lib = idx.search_filtered(q, 3, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(4000)))
+    assert (lib.indices == want.indices).all() and (_bits(lib.distances) == _bits(want.distances)).all()
+    assert (want.indices[0] != np.uint64(2**64 - 1)).all()  # found, through buffers far beyond the LDS budget
