@@ -3,7 +3,7 @@
    tools/kernel_regs.py [extra hipcc flags...]"""
 import os, re, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
-csrc = os.path.join(here, "..", "scalablevectorsearch_amd", "csrc")
+csrc = os.environ.get("SVSX_CSRC") or os.path.join(here, "..", "scalablevectorsearch_amd", "csrc")
 txt = ""
 procs = []
 for name in ("f32", "f16", "i8", "u8"):  # one translation unit per row type
