@@ -555,6 +555,21 @@ def main():
         hp = stat3(host_ms, nq)
         hp["ids_equal_device_path"] = bool((res_h.indices.astype(np.int64) == ids.cpu().numpy()).all())
         result["config"]["host_pointer"] = hp
+        try:  # the same call with the queries in page-locked host memory (what a serving process would hand over): no staging copy
+            qp = q.cpu().pin_memory()
+            qph = qp.numpy()
+            index.search(qph, k, sp)
+            pin_ms = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                res_p = index.search(qph, k, sp)
+                pin_ms.append(1e3 * (time.perf_counter() - t0))
+            hpp = stat3(pin_ms, nq)
+            hpp["ids_equal_device_path"] = bool((res_p.indices.astype(np.int64) == ids.cpu().numpy()).all())
+            result["config"]["host_pointer_pinned_queries"] = hpp
+            del qph, qp
+        except Exception as e:  # informational: never fail the line over it
+            log(f"[bench] pinned host-pointer timing skipped: {e}")
         result["config"]["device_resident"] = stat3([a.elapsed_time(b) for a, b in ev], nq)
         # smallest window with recall@10 >= 0.9 (binary search of index/vamana/calibrate.h:286-300), timed the same way
         lo_w, hi_w = k, args.window
