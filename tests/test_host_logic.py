@@ -119,8 +119,8 @@ def test_calibration_binary_search_logic():
 
 def test_tools_and_staged_scripts_compile():
     """every helper script that a GPU session will run (tools/, the staged round-3 test) at least parses"""
+    import ast
     import os
-    import py_compile
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = [os.path.join(root, "tools", f) for f in sorted(os.listdir(os.path.join(root, "tools"))) if f.endswith(".py")]
@@ -129,4 +129,4 @@ def test_tools_and_staged_scripts_compile():
         files.append(staged)
     assert len(files) >= 10
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        ast.parse(open(f).read(), filename=f)
