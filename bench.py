@@ -604,6 +604,30 @@ def main():
                    "traffic": mt, "traffic_source": mt_src, "frac_traffic": (mt / (mk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mt else None}
         ids_matched = ids.clone()
         result["config"]["matched_recall_point"] = matched
+        try:  # informational: the same kernel, graph and window on a 4x batch -- a launch pays ~0.2 ms of ramp and drain whatever its size
+            nq4 = 4 * nq
+            q4 = deep_like_device(nq4, d, 24, seed=3, device=device)
+            ids4 = torch.empty((nq4, k), dtype=torch.int64, device=device)
+            dists4 = torch.empty((nq4, k), dtype=torch.float32, device=device)
+            st4 = torch.zeros((nq4, 6), dtype=torch.int32, device=device)
+            index.search_device(q4, k, sp, d_ids64=ids4, d_dists=dists4, d_stats=st4)
+            for _ in range(args.warmup):
+                index.search_device(q4, k, sp, d_ids64=ids4, d_dists=dists4)
+            torch.cuda.synchronize()
+            e4 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, args.steps // 4))]
+            for a_, b_ in e4:
+                a_.record()
+                index.search_device(q4, k, sp, d_ids64=ids4, d_dists=dists4)
+                b_.record()
+            torch.cuda.synchronize()
+            ms4 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in e4]))
+            l4 = designed_lines(st4.to(torch.int64), gstride, d * 4, mode, d, k, record_bytes)
+            result["config"]["batch_x4"] = {"queries": nq4, "kernel_ms": ms4, "qps": nq4 / (ms4 * 1e-3), "designed_lines_per_query": l4["total"] / nq4,
+                                            "achieved_GBs": l4["total"] * LINE / (ms4 * 1e-3) / 1e9, "frac": l4["total"] * LINE / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "note": "not the headline batch; shows the per-launch ramp/drain share of the 10 000-query figure"}
+            del q4, ids4, dists4, st4
+        except Exception as e:
+            log(f"[bench] 4x batch point skipped: {e}")
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)  # restore window-128 results for the parity sample
         torch.cuda.synchronize()
         if not args.no_cpu_baseline:
