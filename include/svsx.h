@@ -115,8 +115,10 @@ typedef struct {
      * greedy_search.h:155 and once per query like extensions.h:575-578.  A word the caller may set to non-zero from any
      * thread while the call is in flight: svsx_search takes a HOST pointer (the library mirrors it into a device word the
      * kernel polls); svsx_search_device takes a DEVICE pointer (set it with an agent-scope store from another stream).
-     * After cancellation the call still returns SVSX_SUCCESS; rows of queries that had not started stay untouched,
-     * rows of queries in flight hold whatever their buffer contained (the reference leaves both unspecified). */
+     * After cancellation the call still returns SVSX_SUCCESS; rows of queries that had not started hold the "unspecified"
+     * sentinels (id all-ones, distance +inf; vamana_index_impl.h:115-123) after svsx_search and stay untouched after
+     * svsx_search_device; rows of queries in flight hold whatever their buffer contained (the reference leaves both
+     * unspecified).  svsx_search with a cancel word runs the batch as one launch on one stream (no chunk pipeline). */
     const volatile int* cancel_flag;
 } svsx_search_aux;
 
@@ -178,6 +180,24 @@ int svsx_merge_topk_strided_device(
 int svsx_flat_search_device(
     const svsx_index* index, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream
 );
+
+/* VamanaBuildParameters (index/vamana/build_params.h:28-75). */
+typedef struct {
+    float alpha;
+    size_t graph_max_degree;
+    size_t window_size;
+    size_t max_candidate_pool_size;
+    size_t prune_to;                /* 0 = graph_max_degree - 4 */
+    int use_full_search_history;    /* only 1 (the reference's default) is built */
+} svsx_build_params;
+
+/* Graph construction ("next" scope): the VamanaIndex build constructor (index/vamana/index.h:398-439 ->
+ * VamanaBuilder::construct twice, vamana_build.h:232-599) for an index created with svsx_index_create_device_view over the data,
+ * ONE entry point and a graph whose every slot is 0xFFFFFFFF.  Fills that graph in place; batch-synchronous and deterministic
+ * (the reference's build depends on its thread schedule: graphs are comparable by quality, not byte for byte).
+ * svsx_find_medoid_device: utils::find_medioid (core/medioid.h:292-353), the reference's default entry point. */
+int svsx_vamana_build_device(svsx_index* index, const svsx_build_params* params, void* hip_stream);
+int svsx_find_medoid_device(const svsx_index* index, uint32_t* medoid);
 
 /* Builder support ("next" scope): heuristic_prune_neighbors (index/vamana/prune.h:100-246; progressive
  * strategy for L2, iterative for IP / cosine) for a batch of vertices of `index`.  Device pointers:

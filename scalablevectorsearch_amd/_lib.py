@@ -57,12 +57,21 @@ class SearchAux(C.Structure):
     ]
 
 
+class BuildParams(C.Structure):
+    """svsx_build_params (index/vamana/build_params.h:28-75)."""
+
+    _fields_ = [
+        ("alpha", C.c_float), ("graph_max_degree", C.c_size_t), ("window_size", C.c_size_t), ("max_candidate_pool_size", C.c_size_t),
+        ("prune_to", C.c_size_t), ("use_full_search_history", C.c_int),
+    ]
+
+
 EXPORTS = [
     "svsx_index_create", "svsx_index_create_device_view", "svsx_index_destroy", "svsx_search", "svsx_search_device",
     "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
     "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
     "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
-    "svsx_last_kernel_info", "svsx_search_filtered",
+    "svsx_last_kernel_info", "svsx_search_filtered", "svsx_vamana_build_device", "svsx_find_medoid_device",
 ]
 
 _lib = None
@@ -123,6 +132,8 @@ def lib() -> C.CDLL:
         L.svsx_iterator_state.argtypes = [C.c_void_p, C.c_void_p]
         L.svsx_index_build_bound_codes.argtypes = [C.c_void_p, C.c_int]
         L.svsx_search_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        L.svsx_vamana_build_device.argtypes = [C.c_void_p, C.POINTER(BuildParams), C.c_void_p]
+        L.svsx_find_medoid_device.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 

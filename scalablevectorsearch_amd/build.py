@@ -179,6 +179,27 @@ def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildPar
     return graph, entry
 
 
+def build_vamana_native(d_data, n: int, d: int, distance, params: VamanaBuildParameters, data_dtype=np.float32, device: int = 0,
+                        entry_point: int | None = None, sq=None):
+    """Same contract as build_vamana_device, every step inside libsvsx (svsx_vamana_build_device: search with history, pool assembly,
+    prune, reverse edges -- csrc/svsx_builder.hip).  Returns (d_graph [n, gstride] int32 with -1 padding, entry_point)."""
+    import torch
+
+    fn = as_functor(distance)
+    R = params.graph_max_degree
+    gstride = (R + 15) // 16 * 16
+    dev = d_data.device
+    graph = torch.full((n, gstride), INVALID, dtype=torch.int32, device=dev)
+    d_entry = torch.tensor([0 if entry_point is None else entry_point], dtype=torch.int32, device=dev)
+    index = VamanaIndex.from_device(graph, d_data, fn, d_entry, n, d, data_dtype, device=device, sq=sq)
+    if entry_point is None:
+        entry_point = index.find_medoid()
+        d_entry.fill_(entry_point)  # the device view reads the entry point from this tensor at every search
+    index.vamana_build(params.alpha, R, params.window_size, params.max_candidate_pool_size, params.prune_to or max(R - 4, 1))
+    torch.cuda.synchronize(dev)
+    return graph, entry_point
+
+
 def device_graph_to_svs(d_graph, max_degree: int) -> np.ndarray:
     """Device layout -> SVS row layout [deg, ids...] (core/graph/graph.h:32-48) on the host."""
     g = d_graph.cpu().numpy().view(np.uint32)

@@ -51,6 +51,9 @@ struct svsx_index {
     uint32_t fat_rb = 32;
     float* d_pca = nullptr;      // [32][dpad] leading directions (float32, row-major, zero padded) | [dpad] mean | [32] bias
     float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_delta = 0.0f, pca_eq_abs = 0.0f, pca_ref_extra = 0.0f;
+    // host-pointer calls (svsx_search): persistent staging contexts, one per concurrent caller (HostCallContext below)
+    mutable std::mutex ctx_mutex;
+    mutable std::vector<struct HostCallContext*> ctx_free;
 };
 
 namespace {
@@ -121,6 +124,65 @@ struct CallStream {
         if (s) (void)hipStreamDestroy(s);
     }
     hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+};
+
+} // namespace
+
+// Everything a host-pointer svsx_search needs between calls: streams, page-locked bounce buffers and device staging, all grown on demand
+// and kept with the index -- the per-call hipStreamCreate / hipMallocAsync / pageable copies of round 2 cost 0.65 ms per 10 000-query batch.
+// The batch is cut into chunks, each on its own stream: H2D of chunk i+1 and D2H of chunk i-1 overlap the kernel of chunk i (queries are
+// independent, index/vamana/index.h:571-574, so the results are those of one launch).
+struct HostCallContext {
+    static constexpr int kMaxChunks = 8;
+    hipStream_t streams[kMaxChunks] = {};
+    void* d_in = nullptr;   size_t d_in_cap = 0;    // queries
+    void* d_out = nullptr;  size_t d_out_cap = 0;   // ids64 | ids32 | dists | stats | history ids | history dists | history len
+    void* h_in = nullptr;   size_t h_in_cap = 0;    // page-locked mirrors of the two
+    void* h_out = nullptr;  size_t h_out_cap = 0;
+    ~HostCallContext() {
+        for (auto st : streams) if (st) (void)hipStreamDestroy(st);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+    }
+    hipError_t reserve(size_t in_bytes, size_t out_bytes, int n_streams) {
+        for (int i = 0; i < n_streams; ++i)
+            if (!streams[i]) { hipError_t e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking); if (e != hipSuccess) return e; }
+        auto grow = [](void*& p, size_t& cap, size_t want, bool host) -> hipError_t {
+            if (want <= cap) return hipSuccess;
+            if (p) { (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; cap = 0; }
+            const size_t bytes = want + want / 4 + 4096;
+            hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+            if (e == hipSuccess) cap = bytes;
+            return e;
+        };
+        hipError_t e = grow(d_in, d_in_cap, in_bytes, false);
+        if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes, false);
+        if (e == hipSuccess) e = grow(h_in, h_in_cap, in_bytes, true);
+        if (e == hipSuccess) e = grow(h_out, h_out_cap, out_bytes, true);
+        return e;
+    }
+};
+
+namespace {
+
+// borrowed for the duration of one call; concurrent callers get one each (index/vamana/index.h:541-545)
+struct ContextLease {
+    const svsx_index* ix;
+    HostCallContext* c = nullptr;
+    explicit ContextLease(const svsx_index* index) : ix(index) {
+        {
+            std::lock_guard<std::mutex> lock(ix->ctx_mutex);
+            if (!ix->ctx_free.empty()) { c = ix->ctx_free.back(); ix->ctx_free.pop_back(); }
+        }
+        if (!c) c = new (std::nothrow) HostCallContext();
+    }
+    ~ContextLease() {
+        if (!c) return;
+        std::lock_guard<std::mutex> lock(ix->ctx_mutex);
+        ix->ctx_free.push_back(c);
+    }
 };
 
 int validate_common(int metric, int dtype, size_t n, size_t d) {
@@ -264,6 +326,7 @@ void svsx_index_destroy(svsx_index* ix) {
     if (ix->d_codes) (void)hipFree(ix->d_codes);
     if (ix->d_fat) (void)hipFree(ix->d_fat);
     if (ix->d_pca) (void)hipFree(ix->d_pca);
+    for (HostCallContext* c : ix->ctx_free) delete c;
     delete ix;
 }
 
@@ -776,6 +839,85 @@ int svsx_search_device(
     return search_common(ix, d_queries, q_dtype, nq, k, params, d_ids64, d_ids32, d_dists, d_aux, static_cast<hipStream_t>(hip_stream));
 }
 
+// Host pointers in, host results out (SURVEY 8d's QPS definition; benchmark/include/svs-benchmark/search.h:209-219 times exactly this call).
+// Chunk i: CPU copy into the page-locked mirror -> H2D -> kernel -> D2H on stream i, then CPU copy out once stream i has drained.  The first
+// and the last chunk are small: only their copies are exposed.
+static int search_host_pipelined(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux, size_t q_stride
+) {
+    ContextLease lease(ix);
+    HostCallContext* c = lease.c;
+    if (!c) return fail(SVSX_RUNTIME_ERROR, "out of host memory");
+    // chunk boundaries: small first / last chunks for batches worth pipelining, one chunk otherwise
+    size_t bounds[HostCallContext::kMaxChunks + 1];
+    int nc = 1;
+    bounds[0] = 0;
+    if (nq >= 4096) {
+        const size_t edge = nq / 10 < 1024 ? nq / 10 : 1024;
+        const int mid = nq >= 32768 ? 6 : 3;
+        nc = mid + 2;
+        bounds[1] = edge;
+        for (int i = 1; i <= mid; ++i) bounds[1 + i] = edge + (nq - 2 * edge) * static_cast<size_t>(i) / static_cast<size_t>(mid);
+        bounds[nc] = nq;
+    } else {
+        bounds[1] = nq;
+    }
+    // layout of the output staging (device and page-locked mirror alike): one region per output array
+    const size_t hcap = aux ? aux->history_cap : 0;
+    struct Region { void* host; size_t row_bytes; size_t offset; };
+    Region regions[7];
+    int nr = 0;
+    size_t out_bytes = 0;
+    auto add_region = [&](void* host, size_t row_bytes) -> int {
+        if (!host || row_bytes == 0) return -1;
+        regions[nr] = Region{host, row_bytes, out_bytes};
+        out_bytes += (row_bytes * nq + 255) & ~size_t(255);
+        return nr++;
+    };
+    const int r64 = add_region(ids64, k * 8), r32 = add_region(ids32, k * 4), rdd = add_region(dists, k * 4);
+    const int rst = add_region(aux ? aux->stats : nullptr, 24);
+    const int rhi = add_region(aux ? aux->history_ids : nullptr, hcap * 4), rhd = add_region(aux ? aux->history_dists : nullptr, hcap * 4);
+    const int rhl = add_region(aux ? aux->history_len : nullptr, 4);
+    HIP_TRY(c->reserve(q_stride * nq, out_bytes, nc));
+    auto dptr = [&](int r, size_t row) -> void* { return r < 0 ? nullptr : static_cast<unsigned char*>(c->d_out) + regions[r].offset + regions[r].row_bytes * row; };
+    for (int i = 0; i < nc; ++i) {
+        const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
+        if (cnt == 0) continue;
+        hipStream_t st = c->streams[i];
+        unsigned char* hq = static_cast<unsigned char*>(c->h_in) + q_stride * lo;
+        memcpy(hq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * cnt);
+        void* dq = static_cast<unsigned char*>(c->d_in) + q_stride * lo;
+        HIP_TRY(hipMemcpyAsync(dq, hq, q_stride * cnt, hipMemcpyHostToDevice, st));
+        svsx_search_aux daux;
+        memset(&daux, 0, sizeof(daux));
+        daux.query_row_stride_bytes = q_stride;
+        daux.history_cap = hcap;
+        daux.stats = static_cast<uint32_t*>(dptr(rst, lo));
+        daux.history_ids = static_cast<uint32_t*>(dptr(rhi, lo));
+        daux.history_dists = static_cast<float*>(dptr(rhd, lo));
+        daux.history_len = static_cast<uint32_t*>(dptr(rhl, lo));
+        if (int rc = search_common(ix, dq, q_dtype, cnt, k, params, static_cast<uint64_t*>(dptr(r64, lo)), static_cast<uint32_t*>(dptr(r32, lo)),
+                                   static_cast<float*>(dptr(rdd, lo)), &daux, st)) {
+            for (int j = 0; j <= i; ++j) (void)hipStreamSynchronize(c->streams[j]);
+            return rc;
+        }
+        for (int r = 0; r < nr; ++r) {
+            const size_t off = regions[r].offset + regions[r].row_bytes * lo;
+            HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(c->h_out) + off, static_cast<unsigned char*>(c->d_out) + off, regions[r].row_bytes * cnt, hipMemcpyDeviceToHost, st));
+        }
+    }
+    for (int i = 0; i < nc; ++i) {
+        const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
+        if (cnt == 0) continue;
+        HIP_TRY(hipStreamSynchronize(c->streams[i]));
+        for (int r = 0; r < nr; ++r)
+            memcpy(static_cast<unsigned char*>(regions[r].host) + regions[r].row_bytes * lo,
+                   static_cast<const unsigned char*>(c->h_out) + regions[r].offset + regions[r].row_bytes * lo, regions[r].row_bytes * cnt);
+    }
+    return SVSX_SUCCESS;
+}
+
 int svsx_search(
     const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux
@@ -791,14 +933,18 @@ int svsx_search(
     if (nq == 0) return SVSX_SUCCESS;
     HIP_TRY(hipSetDevice(ix->device));
     const size_t q_stride = (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype);
+    if (!(aux && aux->cancel_flag)) return search_host_pipelined(ix, queries, q_dtype, nq, k, params, ids64, ids32, dists, aux, q_stride);
+    // ---- with a cancel word: one chunk on one stream, the host thread polls the caller's word while the stream drains -------------------
     CallStream cs;
     HIP_TRY(cs.create());
     StreamBuffer dq, d64, d32, dd, dst, dhi, dhd, dhl;
     HIP_TRY(dq.alloc(q_stride * nq, cs.s));
     HIP_TRY(hipMemcpyAsync(dq.p, queries, q_stride * nq, hipMemcpyHostToDevice, cs.s));
-    if (ids64) HIP_TRY(d64.alloc(nq * k * 8, cs.s));
-    if (ids32) HIP_TRY(d32.alloc(nq * k * 4, cs.s));
-    if (dists) HIP_TRY(dd.alloc(nq * k * 4, cs.s));
+    // rows of queries the kernel never starts (or abandons) must not carry stale pool contents: "unspecified" sentinels, like
+    // vamana_index_impl.h:115-123 fills them
+    if (ids64) { HIP_TRY(d64.alloc(nq * k * 8, cs.s)); HIP_TRY(hipMemsetAsync(d64.p, 0xFF, nq * k * 8, cs.s)); }
+    if (ids32) { HIP_TRY(d32.alloc(nq * k * 4, cs.s)); HIP_TRY(hipMemsetAsync(d32.p, 0xFF, nq * k * 4, cs.s)); }
+    if (dists) { HIP_TRY(dd.alloc(nq * k * 4, cs.s)); HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dd.p), 0x7F800000, nq * k, cs.s)); }
     svsx_search_aux daux;
     memset(&daux, 0, sizeof(daux));
     daux.query_row_stride_bytes = q_stride;
@@ -1052,6 +1198,81 @@ int svsx_prune_device(
     a.out_stride = static_cast<uint32_t>(out_stride);
     hipError_t e = launch_prune(ix->data_dtype, ix->metric, ix->sq_enabled != 0, a, static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "prune kernel launch failed: %s", hipGetErrorString(e));
+    return SVSX_SUCCESS;
+}
+
+} // extern "C"
+
+namespace svsx { // svsx_builder.hip
+struct BuildTarget {
+    const svsx_index* index;
+    const void* d_data;
+    size_t row_bytes;
+    int data_dtype, metric;
+    uint32_t n, d;
+    int sq_enabled;
+    float sq_scale, sq_bias;
+    uint32_t* d_graph;
+    uint32_t gstride;
+};
+struct BuildParams {
+    float alpha;
+    uint32_t graph_max_degree, window_size, max_candidate_pool_size, prune_to;
+};
+int build_vamana(const BuildTarget& t, const BuildParams& p, hipStream_t stream, std::string& err);
+int find_medoid_device(const BuildTarget& t, uint32_t* medoid, hipStream_t stream, std::string& err);
+} // namespace svsx
+
+static svsx::BuildTarget build_target(const svsx_index* ix) {
+    svsx::BuildTarget t;
+    t.index = ix;
+    t.d_data = ix->d_data;
+    t.row_bytes = ix->row_bytes;
+    t.data_dtype = ix->data_dtype;
+    t.metric = ix->metric;
+    t.n = static_cast<uint32_t>(ix->n);
+    t.d = static_cast<uint32_t>(ix->d);
+    t.sq_enabled = ix->sq_enabled;
+    t.sq_scale = ix->sq_scale;
+    t.sq_bias = ix->sq_bias;
+    t.d_graph = ix->d_graph;
+    t.gstride = static_cast<uint32_t>(ix->gstride);
+    return t;
+}
+
+extern "C" {
+
+int svsx_vamana_build_device(svsx_index* ix, const svsx_build_params* params, void* hip_stream) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (!params) return fail(SVSX_INVALID_ARGUMENT, "null build parameters");
+    if (!ix->d_graph || ix->n_entry != 1) return fail(SVSX_INVALID_ARGUMENT, "the build needs a graph to fill and exactly one entry point");
+    if (ix->n >= (size_t(1) << 31)) return fail(SVSX_INVALID_ARGUMENT, "too many vectors for one graph");
+    if (params->graph_max_degree == 0 || params->graph_max_degree > ix->gstride)
+        return fail(SVSX_INVALID_ARGUMENT, "graph_max_degree %zu does not fit the graph rows of %zu ids", params->graph_max_degree, ix->gstride);
+    if (params->window_size == 0 || params->window_size > 8000) return fail(SVSX_INVALID_ARGUMENT, "build window_size out of range");
+    if (!(params->alpha > 0.0f)) return fail(SVSX_INVALID_ARGUMENT, "alpha must be positive");
+    if (!params->use_full_search_history) return fail(SVSX_NOT_IMPLEMENTED, "only use_full_search_history = true is built");
+    if (ix->d_fat || ix->d_codes) return fail(SVSX_INVALID_ARGUMENT, "bound codes describe a finished graph: build first");
+    HIP_TRY(hipSetDevice(ix->device));
+    svsx::BuildParams p;
+    p.alpha = params->alpha;
+    p.graph_max_degree = static_cast<uint32_t>(params->graph_max_degree);
+    p.window_size = static_cast<uint32_t>(params->window_size);
+    p.max_candidate_pool_size = static_cast<uint32_t>(params->max_candidate_pool_size ? params->max_candidate_pool_size : 750);
+    p.prune_to = static_cast<uint32_t>(params->prune_to);
+    std::string err;
+    const int rc = svsx::build_vamana(build_target(ix), p, static_cast<hipStream_t>(hip_stream), err);
+    if (rc != SVSX_SUCCESS) return fail(rc, "%s", err.c_str());
+    return SVSX_SUCCESS;
+}
+
+int svsx_find_medoid_device(const svsx_index* ix, uint32_t* medoid) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (!medoid) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    std::string err;
+    const int rc = svsx::find_medoid_device(build_target(ix), medoid, nullptr, err);
+    if (rc != SVSX_SUCCESS) return fail(rc, "%s", err.c_str());
     return SVSX_SUCCESS;
 }
 

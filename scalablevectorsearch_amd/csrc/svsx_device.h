@@ -175,21 +175,25 @@ __device__ __forceinline__ void float_row_distance(
     };
 
     int b = 0;
+    // static dimension: EVERY load of the row is issued before the first use -- the 64-blocks, the remaining 16-blocks and the ragged
+    // block.  (Round 2 issued the loads of the epilogue blocks after the 64-block arithmetic: at d = 96 the third cache line of each
+    // row was a dependent HBM round trip of its own inside every distance pass.)
+    constexpr int SB64 = DS > 0 ? (DS >> 6) * 4 : 0, SB1 = DS > 0 ? (DS >> 4) : 0, SRAG = (DS > 0 && (DS & 15) != 0) ? 1 : 0;
+    [[maybe_unused]] float xs[(SB1 + SRAG) > 0 ? (SB1 + SRAG) : 1][E];
+    if constexpr (DS > 0) {
+#pragma unroll
+        for (int i = 0; i < SB1 + SRAG; ++i) fetch(i, xs[i]);
+    }
     if (n64 > 0) {
         if constexpr (DS > 0) {
-            // static: issue every load of the 64-blocks first, then the arithmetic
-            constexpr int NB64 = (DS >> 6) * 4;
-            float x[NB64 > 0 ? NB64 : 1][E];
 #pragma unroll
-            for (int i = 0; i < NB64; ++i) fetch(i, x[i]);
-#pragma unroll
-            for (int i = 0; i < NB64; ++i) {
+            for (int i = 0; i < SB64; ++i) {
                 float q[E];
                 fetch_q(i, q);
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc_step<METRIC>(s[i & 3][e], n[i & 3][e], q[e], x[i][e]);
+                for (int e = 0; e < E; ++e) acc_step<METRIC>(s[i & 3][e], n[i & 3][e], q[e], xs[i][e]);
             }
-            b = NB64;
+            b = SB64;
         } else {
             for (int t = 0; t < n64; ++t) {
                 float x[4][E];
@@ -226,18 +230,14 @@ __device__ __forceinline__ void float_row_distance(
     }
     // full-width epilogue: remaining 16-blocks into s0
     if constexpr (DS > 0) {
-        constexpr int B0 = (DS >> 6) * 4, B1 = DS >> 4;
-        float x[(B1 - B0) > 0 ? (B1 - B0) : 1][E];
 #pragma unroll
-        for (int i = B0; i < B1; ++i) fetch(i, x[i - B0]);
-#pragma unroll
-        for (int i = B0; i < B1; ++i) {
+        for (int i = SB64; i < SB1; ++i) {
             float q[E];
             fetch_q(i, q);
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc_step<METRIC>(s[0][e], n[0][e], q[e], x[i - B0][e]);
+            for (int e = 0; e < E; ++e) acc_step<METRIC>(s[0][e], n[0][e], q[e], xs[i][e]);
         }
-        b = B1;
+        b = SB1;
     } else {
         for (; b < nb; ++b) {
             float x[E], q[E];
@@ -250,7 +250,12 @@ __device__ __forceinline__ void float_row_distance(
     // ragged epilogue: masked lane-slots keep their accumulator (mask3_fmadd)
     if ((d & 15) != 0) {
         float x[E], q[E];
-        fetch(b, x);
+        if constexpr (DS > 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = xs[SB1][e];
+        } else {
+            fetch(b, x);
+        }
         fetch_q(b, q);
         const int first = 16 * b + sub * E;
 #pragma unroll

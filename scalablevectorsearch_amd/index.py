@@ -249,6 +249,20 @@ class VamanaIndex:
         _lib.check(_lib.lib().svsx_flat_search_device(self._h, d_queries.data_ptr(), code, nq, num_neighbors, d_ids64.data_ptr(), d_dists.data_ptr(), C.c_void_p(s)))
         return d_ids64, d_dists
 
+    def vamana_build(self, alpha: float, graph_max_degree: int, window_size: int, max_candidate_pool_size: int = 750, prune_to: int = 0, stream=None) -> None:
+        """VamanaIndex build constructor (index/vamana/index.h:398-439) on this device-view index: fills its (all 0xFFFFFFFF) graph in place."""
+        import torch
+
+        bp = _lib.BuildParams(float(alpha), int(graph_max_degree), int(window_size), int(max_candidate_pool_size), int(prune_to), 1)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().svsx_vamana_build_device(self._h, C.byref(bp), C.c_void_p(s)))
+
+    def find_medoid(self) -> int:
+        """utils::find_medioid (core/medioid.h:292-353): the vector closest to the component-wise mean."""
+        m = C.c_uint32(0)
+        _lib.check(_lib.lib().svsx_find_medoid_device(self._h, C.byref(m)))
+        return int(m.value)
+
     def prune_device(self, d_node_ids, d_pool_ids, d_pool_dists, max_out: int, alpha: float, out_stride: int, stream=None):
         """heuristic_prune_neighbors (index/vamana/prune.h:100-246) for a batch of vertices, on torch CUDA tensors:
         node ids int32 [B], pool ids int32 [B,P] (sorted best-first, -1 padded), pool dists f32 [B,P] -> int32 [B,out_stride]."""

@@ -81,13 +81,26 @@ def world128(oracle):
     return dict(x=x, q=q, graph=graph, entry=entry)
 
 
+_WORLDS = {}
+
+
+def _world(oracle, d):
+    """1500 x d deep-like vectors + an oracle-built graph, one per static dimension (cached for the module)"""
+    if d not in _WORLDS:
+        x = deep_like(1500, d, 24, seed=100 + d)
+        q = deep_like(48, d, 24, seed=200 + d)
+        graph, entry = oracle.build_vamana(L2, x, R=32, L=48)
+        _WORLDS[d] = dict(x=x, q=q, graph=graph, entry=entry)
+    return _WORLDS[d]
+
+
 @pytest.mark.parametrize("metric", [L2, IP, COS])
 @pytest.mark.parametrize("ddt,qdt", [(F32, F32), (F32, F16), (F16, F32), (F16, F16)])
-@pytest.mark.parametrize("d", [96, 128])
+@pytest.mark.parametrize("d", [64, 96, 100, 128, 160, 200, 512, 768])
 def test_every_static_float_instantiation(svs, oracle, small_world, world128, metric, ddt, qdt, d):
-    """K7: launch_dim's static-dimension table.  Each (rows, metric, d) instantiation is run against the oracle
-    and the library reports that it -- not the runtime-d kernel -- served the call."""
-    w = small_world if d == 96 else world128
+    """K7: launch_dim's static-dimension table = the reference's supported_dim_list (distance_core.h:31-32).  Each
+    (rows, metric, d) instantiation is run against the oracle and the library reports that it -- not the runtime-d kernel -- served the call."""
+    w = small_world if d == 96 else world128 if d == 128 else _world(oracle, d)
     conv = lambda a, dt: a.astype(np.float16) if dt == F16 else a
     x, q = conv(w["x"], ddt), conv(w["q"], qdt)
     idx = svs.VamanaIndex(w["graph"], x, _fn(svs, metric), w["entry"])
@@ -98,6 +111,26 @@ def test_every_static_float_instantiation(svs, oracle, small_world, world128, me
         assert (res.indices == ids.astype(np.uint64)).all(), (metric, ddt, qdt, d, win)
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, ddt, qdt, d, win)
         assert (st[:, :2] == ost[:, :2]).all()
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("d", [64, 100, 160, 200])
+def test_static_inline_record_instantiations(svs, oracle, metric, d, monkeypatch):
+    """the 32-byte inline-record kernels of the remaining static dimensions (96 / 128 are covered by the config tests)"""
+    monkeypatch.setenv("SVSX_RECORD_BYTES", "32")
+    w = _world(oracle, d)
+    idx = svs.VamanaIndex(w["graph"], w["x"], _fn(svs, metric), w["entry"])
+    idx.build_bound_codes(2)
+    res, st = idx.search(w["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(64), 1), stats=True)
+    assert idx.last_kernel_info() == f"search_kernel<dt=0,metric={metric},qmode=0,ds={d},general=0,codes=2>"
+    ids, dists, ost = oracle.search(metric, w["x"], w["graph"], w["entry"], w["q"], 10, 64, visited_set=True, stats=True)
+    assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all()
+    assert (st[:, :2] == ost[:, :2]).all()
+    # buffers beyond 128 entries leave the static kernel for the runtime-d one: same answers
+    res2 = idx.search(w["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(200), 1))
+    assert idx.last_kernel_info() == f"search_kernel<dt=0,metric={metric},qmode=0,ds=0,general=0,codes=2>"
+    ids2, dists2 = oracle.search(metric, w["x"], w["graph"], w["entry"], w["q"], 10, 200, visited_set=True)
+    assert (res2.indices == ids2.astype(np.uint64)).all() and (_bits(res2.distances) == _bits(dists2)).all()
 
 
 @pytest.mark.parametrize("metric", [IP, COS])
@@ -271,16 +304,23 @@ def test_cancel_flag_device_and_host(svs, oracle, small_world):
     hid = np.full((big.shape[0], k), 7, np.uint64)
     hd = np.zeros((big.shape[0], k), np.float32)
     spb = svs.VamanaSearchParameters(svs.SearchBufferConfig(256))._c()
-    _lib.check(L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux)))
     full, _ = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"], k, 256)
     full = np.tile(full.astype(np.uint64), (400, 1))
-    assert not (hid == full).all()                         # cancelled before anything ran
+    flag.value = 0                                         # first a complete search: the library's staging memory now holds valid-looking rows
+    _lib.check(L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux)))
+    assert (hid == full).all()
+    flag.value = 1
+    _lib.check(L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux)))
+    # cancelled before anything ran: every row holds the "unspecified" sentinels (vamana_index_impl.h:115-123), never stale results
+    assert (hid == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and np.isposinf(hd).all()
     flag.value = 0
     t = threading.Thread(target=lambda: (time.sleep(0.0005), setattr(flag, "value", 1)))
     t.start()
     rc = L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux))
     t.join()
     assert rc == 0                                         # cancellation is not an error (the reference returns normally)
+    untouched = (hid == np.uint64(0xFFFFFFFFFFFFFFFF)).all(1)
+    assert (np.isposinf(hd[untouched])).all()              # rows of queries that never started: sentinels in both arrays
     flag.value = 0                                         # and a lowered flag gives the full, exact answer again
     _lib.check(L.svsx_search(idx._h, big.ctypes.data, 0, big.shape[0], k, C.byref(spb), hid.ctypes.data, None, hd.ctypes.data, C.byref(aux)))
     assert (hid == full).all()

@@ -466,6 +466,53 @@ def test_concurrent_host_callers(svs, oracle, small_world):
     assert not errors, errors
 
 
+def test_host_pointer_pipeline_equals_one_launch(svs, oracle, small_world):
+    """svsx_search cuts batches of >= 4096 queries into chunks, each on its own stream (H2D / kernel / D2H of neighbouring chunks overlap).
+    Queries are independent (index/vamana/index.h:571-574): every output -- 64- and 32-bit ids, distances, statistics, search history, with
+    dense and strided query rows -- must equal ONE launch over device-resident queries, and the oracle on a sample."""
+    import ctypes as C
+
+    import torch
+
+    from scalablevectorsearch_amd import _lib
+
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    rng = np.random.default_rng(5)
+    nq, k, d = 5003, 10, sw["x"].shape[1]
+    q = (sw["q"][rng.integers(0, sw["q"].shape[0], nq)] + np.float32(1e-3) * rng.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(24, 40), True)
+    dq = torch.from_numpy(q).cuda()
+    ids64 = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    dst = torch.zeros((nq, 6), dtype=torch.int32, device="cuda")
+    idx.search_device(dq, k, sp, d_ids64=ids64, d_dists=dd, d_stats=dst)
+    torch.cuda.synchronize()
+    want_i, want_d, want_s = ids64.cpu().numpy(), dd.cpu().numpy(), dst.cpu().numpy()
+    oi, od = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], q[:64], k, 24, 40, visited_set=True)
+    assert (want_i[:64] == oi).all() and (want_d[:64].view(np.uint32) == od.view(np.uint32)).all()
+    for stride_pad in (0, 16):  # dense rows, then rows of a wider host matrix
+        host = np.zeros((nq, d + stride_pad), np.float32)
+        host[:, :d] = q
+        h64 = np.zeros((nq, k), np.uint64); h32 = np.zeros((nq, k), np.uint32); hd = np.zeros((nq, k), np.float32)
+        hst = np.zeros((nq, 6), np.uint32); hcap = 8
+        hhi = np.zeros((nq, hcap), np.uint32); hhd = np.zeros((nq, hcap), np.float32); hhl = np.zeros(nq, np.uint32)
+        aux = _lib.SearchAux()
+        aux.stats, aux.history_ids, aux.history_dists, aux.history_len = hst.ctypes.data, hhi.ctypes.data, hhd.ctypes.data, hhl.ctypes.data
+        aux.history_cap = hcap
+        aux.query_row_stride_bytes = host.strides[0]
+        spc = sp._c()
+        _lib.check(_lib.lib().svsx_search(idx._h, host.ctypes.data, 0, nq, k, C.byref(spc), h64.ctypes.data, h32.ctypes.data, hd.ctypes.data, C.byref(aux)))
+        assert (h64.astype(np.int64) == want_i).all() and (h32 == want_i.astype(np.uint32)).all()
+        assert (hd.view(np.uint32) == want_d.view(np.uint32)).all()
+        assert (hst.astype(np.int64) == want_s.astype(np.int64)).all()
+        assert (hhl == want_s[:, 0].astype(np.uint32)).all()          # history_len = expansions
+        assert (hhi[:, 0] == np.uint32(sw["entry"][0] if np.ndim(sw["entry"]) else sw["entry"])).all()  # every search expands the entry point first
+    # a second call on the same index reuses the staging context; concurrent callers get their own (test_concurrent_host_callers)
+    r = idx.search(q, k, sp)
+    assert (r.indices.astype(np.int64) == want_i).all()
+
+
 def test_partial_distance_rejection_matches_analysis(svs, oracle, small_world):
     """f32 L2, 64 < d <= 128: the kernel stops after the first 64 dimensions when the partial sum already exceeds the
     worst buffer entry (result-neutral; parity is covered by every f32-L2 test above).  The number of such rejections

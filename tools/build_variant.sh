@@ -10,6 +10,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-c
 cd $R/scalablevectorsearch_amd/csrc
 for f in svsx_search_f32 svsx_search_f16 svsx_search_i8 svsx_search_u8; do /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o $OUT/$f.o & done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsvsx.so $OUT/svsx_search_f32.o $OUT/svsx_search_f16.o $OUT/svsx_search_i8.o $OUT/svsx_search_u8.o svsx_search.o svsx_api.o svsx_distance.o svsx_build.o svsx_flat.o svsx_codes.o
+# every other object of the in-tree build (run `make` first), whatever the Makefile's source list is
+OTHERS=$(ls *.o | grep -v -E '^svsx_search_(f32|f16|i8|u8)\.o$')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsvsx.so $OUT/svsx_search_f32.o $OUT/svsx_search_f16.o $OUT/svsx_search_i8.o $OUT/svsx_search_u8.o $OTHERS
 rm -f $OUT/*.o
 echo built $OUT/libsvsx.so
