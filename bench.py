@@ -5,13 +5,11 @@
 
 Default workload = BASELINE config 2: one "step" = one batch search (10 000 queries, k = 10, search_window = 128) over a
 deep-1M-like index (1 000 000 x 96 float32, L2, Vamana R = 64) resident in HBM, queries / results device resident.
-  N > 1 (torch.distributed.run, one rank per GPU): every rank owns one read-only 1M-vector shard (weak scaling: the database
-        grows with N), the query batch is the same on all ranks, per-shard top-k travel through ONE RCCL all-gather and are
-        merged on the GPU (SURVEY 8e).  `value` counts (query, shard) searches per second, the units the ranks processed;
-        `config.merged_answer_qps` is the rate of merged answers.
-  --config c5: BASELINE config 5 in the SURVEY 8(e) sense: a FIXED number of shards (--shards, default 8) of --n vectors
-        each, every rank owns shards/N of them, local merge -> one packed all-gather -> global merge; `value` = merged
-        answers per second, "scaling": "strong" (total work fixed), so N = 1 is one GPU searching all 8 shards.
+  N > 1 (torch.distributed.run, one rank per GPU): REPLICAS -- every rank holds the same 1M-vector index and answers its own
+        10 000-query batch; no data-path collective; `value` = answers per second of the whole job (N = 1 equals the single-GPU line).
+  Every line also carries `config.sharded_c5`: the sharded search of SURVEY 8(e) -- a FIXED set of 8 shards, 8/N per GPU, per-shard
+        top-k -> local merge -> ONE RCCL all-gather -> global merge, all inside libsvsx (svsx_sharded_*), merged answers per second.
+  --config c5: the same sharded search as the headline, at --n vectors per shard (default 12 500 000: BASELINE config 5).
 """
 from __future__ import annotations
 
@@ -265,6 +263,89 @@ def build_or_load_graph(svs, x, n, d, R, local_rank, cache):
     return graph, entry, time.time() - t0
 
 
+def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reuse_shard0, steps, warmup):
+    """SURVEY 8(e) as a measurement inside the default line: a FIXED set of 8 shards of --c5-n vectors (contiguous id ranges, global
+    ids), 8 / N per GPU, every rank passes the same query batch to svsx_sharded_search_device: per-shard searches, local merge, ONE
+    ncclAllGather on a communicator the library joined itself, world-way merge.  Collective: every rank calls this.  Returns a dict
+    (merged answers per second over max-over-ranks time, recall against the global exact top-k)."""
+    import torch
+    import torch.distributed as dist
+
+    from scalablevectorsearch_amd.sharded import NativeShardedSearcher
+
+    total = 8
+    if total % world:
+        return {"skipped": f"8 shards do not divide over {world} GPUs"}
+    per = total // world
+    n5, nq = args.c5_n, q.shape[0]
+    t0 = time.time()
+    keep, indexes = [], []
+    for s_ in range(per):
+        sid = rank * per + s_
+        if sid == 0 and reuse_shard0 is not None and n5 == reuse_shard0["n"]:
+            sh = reuse_shard0  # shard 0 IS the replica's database (seed 1, id offset 0)
+        else:
+            x = deep_like_device(n5, d, 24, seed=1 + 1000 * sid, device=device)
+            graph, entry, _ = build_or_load_graph(svs, x, n5, d, R, local_rank, "")
+            d_entry = torch.tensor([entry], dtype=torch.int32, device=device)
+            index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n5, d, np.float32, device=local_rank, id_offset=sid * n5)
+            if args.bound_codes:
+                index.build_bound_codes(args.bound_codes)
+            sh = dict(x=x, graph=graph, entry=entry, d_entry=d_entry, index=index, sid=sid, n=n5)
+        keep.append(sh)
+        indexes.append(sh["index"])
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    ns = NativeShardedSearcher(indexes, single_rank_comm=True)  # a real RCCL communicator at every N, also N = 1
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window), search_buffer_visited_set=args.visited)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=device)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
+    for _ in range(max(1, warmup)):
+        ns.search(q, k, sp, d_ids64=out_i, d_dists=out_d)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ns.search(q, k, sp, d_ids64=out_i, d_dists=out_d)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # recall against the exact global top-k: exact per-shard lists (MFMA flat search + exact re-rank), gathered, best k overall
+    gd, gi = [], []
+    for sh in keep:
+        flat = svs.VamanaIndex.from_device(sh["graph"], sh["x"], svs.DistanceL2(), sh["d_entry"], n5, d, np.float32, device=local_rank)
+        ids_, _ = flat.flat_search_device(q, k)
+        torch.cuda.synchronize()
+        del flat
+        gd.append(((q[:, None, :] - sh["x"][ids_]) ** 2).sum(-1))
+        gi.append(ids_ + sh["sid"] * n5)
+    cd, ci = torch.cat(gd, 1), torch.cat(gi, 1)
+    if world > 1:
+        a_d = torch.empty((world,) + tuple(cd.shape), device=device)
+        a_i = torch.empty((world,) + tuple(ci.shape), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(a_d.view(-1), cd.contiguous().view(-1))
+        dist.all_gather_into_tensor(a_i.view(-1), ci.contiguous().view(-1))
+        cd, ci = a_d.permute(1, 0, 2).reshape(nq, -1), a_i.permute(1, 0, 2).reshape(nq, -1)
+    gt = torch.gather(ci, 1, torch.topk(cd, k, dim=1, largest=False).indices)
+    info = ns.info()
+    res = {"shards_total": total, "shards_per_gpu": per, "vectors_per_shard": n5, "n_gpus": world, "batch": nq, "window_per_shard": args.window,
+           "merged_answers_per_s": nq * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "steps": steps, "recall_at_10": recall_at(gt, out_i, k),
+           "rccl_communicator": info["communicator"], "rccl_ranks": info["world"], "build_seconds_this_rank": t_build,
+           "path": "svsx_sharded_search_device (libsvsx: per-shard search -> local merge -> ONE ncclAllGather -> world-way merge, one stream)",
+           "scaling": "strong (the set of 8 shards is fixed as N grows)",
+           "shard_size_note": f"{n5} vectors per shard so that the build fits the bench's time budget; the 12.5 M-vector shard of BASELINE config 5 is --config c5"}
+    ns.close()
+    return res
+
+
 def main():
     _claim_stdout()
     ap = argparse.ArgumentParser()
@@ -282,6 +363,8 @@ def main():
     ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
     ap.add_argument("--bound-codes", type=int, default=2, help="result-neutral lower-bound rejection: 2 graph-inline records (default), 1 128-B code rows, 0 off")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph(s) here (lets a profiler run skip the build)")
+    ap.add_argument("--c5-n", type=int, default=1_000_000, help="vectors per shard of the config.sharded_c5 point of the default line (0 = skip it)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational points (sharded_c5, other configs, 4x batch)")
     args = ap.parse_args()
 
     import torch
@@ -297,7 +380,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     c5 = args.config == "c5"
-    multi = world > 1 or args.force_dist or c5
+    multi = args.force_dist or c5   # the default workload has no exchange step at any N (replicas)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -306,14 +389,15 @@ def main():
 
     d, nq, k, R = 96, args.nq, 10, args.degree
     n = args.n or (12_500_000 if c5 else 1_000_000)
-    total_shards = args.shards if c5 else world
+    total_shards = args.shards if c5 else 1
     if c5 and total_shards % world:
         raise SystemExit(f"--shards {total_shards} must be a multiple of the number of GPUs {world}")
     local_shards = total_shards // world if c5 else 1
-    first_shard = rank * local_shards
+    first_shard = rank * local_shards if c5 else 0   # default workload: every rank holds shard 0 = the whole index (replicas)
 
     # ---- shards of a (total_shards x n) database: independent seeds per shard, global ids = local + shard * n -----------------
-    q = deep_like_device(nq, d, 24, seed=2, device=device)  # identical on every rank
+    # c5: the same batch on every rank (every shard sees every query); replicas: each rank answers its own batch
+    q = deep_like_device(nq, d, 24, seed=2 if (c5 or rank == 0) else 2 + 7919 * rank, device=device)
     shards = []
     t_gen = t_build = 0.0
     total_hbm = torch.cuda.get_device_properties(device).total_memory
@@ -396,7 +480,7 @@ def main():
         gt_i_parts.append(gi + sh["sid"] * n)
     cd = torch.cat(gt_d_parts, 1)
     ci = torch.cat(gt_i_parts, 1)
-    if use_dist and world > 1:
+    if use_dist and world > 1 and c5:
         g_d = torch.empty((world,) + tuple(cd.shape), device=device)
         g_i = torch.empty((world,) + tuple(ci.shape), dtype=torch.int64, device=device)
         dist.all_gather_into_tensor(g_d.view(-1), cd.contiguous().view(-1))
@@ -440,6 +524,32 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / local_shards  # per search_kernel launch
     step_ms = [ev_step[i].elapsed_time(ev_step[i + 1]) for i in range(args.steps)]
 
+    # ---- the sharded search of SURVEY 8(e), measured in the same run (every rank takes part) -----------------------------------------
+    sharded = None
+    if not c5 and not args.no_extras and args.c5_n > 0:
+        import threading
+
+        def give_up():  # a collective that never returns must not cost the headline line
+            if rank == 0:
+                v = world * nq * args.steps / elapsed
+                _emit(json.dumps({"metric": "QPS at recall@10>=0.9 (batch=10k); achieved HBM GB/s vs roofline", "value": v, "unit": "queries/s", "n_gpus": world,
+                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                  "config": {"workload": f"deep-1M-like d=96 float32 L2, batch={nq}, search_window={args.window}, k=10", "recall_at_10": recall,
+                                             "sharded_c5": {"error": "timed out"}, "note": "emergency line: the sharded extra did not return"}}))
+            os._exit(0)
+
+        dog = threading.Timer(420.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sh0 = dict(shards[0], n=n)
+            sharded = sharded_c5_point(args, svs, q if rank == 0 else deep_like_device(nq, d, 24, seed=2, device=device), k, R, d, rank, world, local_rank, device,
+                                       sh0 if rank == 0 else None, max(3, args.steps // 2), args.warmup)
+        except Exception as e:  # informational: never fail the line over it
+            sharded = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[bench] rank {rank}: sharded_c5 point failed: {e}")
+        dog.cancel()
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -465,7 +575,7 @@ def main():
         value, scaling, counts = merged_qps, "strong", "merged answers (queries) per second over the whole fixed-size sharded index"
     else:
         value, scaling = world * nq * args.steps / elapsed, "weak"
-        counts = "queries answered per second" if world == 1 else "(query, shard) searches per second = the units all ranks processed (every query visits every shard); merged answers per second = config.merged_answer_qps"
+        counts = "queries answered per second" if world == 1 else f"queries answered per second by {world} replicas (each GPU holds the whole index and answers its own {nq}-query batch; no exchange step)"
     designed_bytes = lines["total"] * LINE / local_shards  # per search_kernel launch
     achieved = designed_bytes / (kern_ms * 1e-3) / 1e9
     wkey = f"{args.config}:n={n}:nq={nq}:window={args.window}:R={R}:visited={args.visited}:codes={mode}"
@@ -473,7 +583,7 @@ def main():
     if c5:
         workload = f"synthetic {total_shards} x {n} x 96 float32 L2 sharded index ({local_shards} shard(s) per GPU), batch={nq}, search_window={args.window} per shard, k=10, {world}xMI355X"
     else:
-        workload = f"deep-1M-like d=96 float32 L2, batch={nq}, search_window={args.window}, k=10, 1xMI355X per shard"
+        workload = f"deep-1M-like d=96 float32 L2, batch={nq}, search_window={args.window}, k=10, 1xMI355X" + (f" x {world} replicas" if world > 1 else "")
     result = {
         "metric": "QPS at recall@10>=0.9 (batch=10k); achieved HBM GB/s vs roofline",
         "value": value,
@@ -490,14 +600,15 @@ def main():
         "config": {
             "workload": workload,
             "value_counts": counts,
-            "inputs": "queries and results resident in HBM (svsx_search_device); the host-pointer rate is config.host_pointer",
+            "inputs": "value: queries and results resident in HBM when the timed region starts (svsx_search_device); the same batch through the host-pointer "
+                      "entry point svsx_search (SURVEY 8d's wording: host queries in, host results out) is config.host_pointer, 1 warm-up + 5 timed",
             "vectors_per_shard": n,
             "shards_total": total_shards,
             "shards_per_gpu": local_shards,
             "graph": f"Vamana R={R} L={2*R} alpha=1.2 (GPU-built, mean degree {deg_mean:.1f})",
             "generator": "G(24, 0.1) unit norm, own counter-based RNG (splitmix64 hash + Box-Muller), base seed 1 + 1000*shard, query seed 2",
             "recall_at_10": recall,
-            "merged_answer_qps": merged_qps,
+            "merged_answer_qps": merged_qps if c5 else value,
             "step_ms_min_median_max": [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
             "expansions_per_query": exp_total / nq,
             "neighbor_slots_per_query": slots_total / nq,
@@ -511,10 +622,14 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "achieved": achieved,
+            "achieved": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
+            "frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else achieved / HBM_PEAK_GBS,
+            "frac_basis": ("fabric bytes per launch from the rocprofv3 PMC passes of these kernel sources (roofline.traffic) / this run's kernel time / 8 TB/s"
+                           if traffic else "designed bytes (no PMC summary matches these kernel sources): see achieved_designed"),
+            "achieved_designed": achieved,
+            "frac_designed": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_src,
             "traffic_rate": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
@@ -530,8 +645,9 @@ def main():
             "random_line_roof_Glines_per_s": 49.0,
             "reference_algorithmic_bytes_per_launch": ref_alg_bytes / local_shards,
             "reference_algorithmic_GBs": ref_alg_bytes / local_shards / (kern_ms * 1e-3) / 1e9,
-            "note": "achieved = bytes the kernel is DESIGNED to move (128-byte lines counted from its own per-query statistics: adjacency blocks, "
-                    "rows of the candidates that reach the exact path, query, results) / kernel time; frac = achieved / 8 TB/s.  "
+            "note": "achieved / frac = measured fabric traffic per launch (PMC) / kernel time (HIP events of this run) -- what a third party can recompute; "
+                    "achieved_designed / frac_designed = bytes the kernel is DESIGNED to move (128-byte lines counted from its own per-query statistics: "
+                    "adjacency blocks, rows of the candidates that reach the exact path, query, results) / kernel time.  "
                     "reference_algorithmic_* = the SURVEY 8(d) figure for the reference traversal (visited set off, whole rows for every neighbour); "
                     "the kernel proves most of those reads unnecessary, so that figure exceeds what moves and is not a roofline fraction.  "
                     "traffic = fabric bytes from the committed PMC passes of these kernel sources (null when none matches).  "
@@ -539,37 +655,38 @@ def main():
         },
     }
 
+    if sharded is not None:
+        result["config"]["sharded_c5"] = sharded
     single = world == 1 and not c5 and not args.force_dist
     ids = loc_i
     dists = loc_d
     index = shards[0]["index"]
     if single:
-        # host-pointer entry point (SURVEY 8d wording: host queries in, host results out): 1 warm-up + 5 timed runs
+        # host-pointer entry point (SURVEY 8d wording: host queries in, host results out; the call the reference's harness times,
+        # benchmark/include/svs-benchmark/search.h:209-219): svsx_search through the C ABI, pageable numpy arrays on both sides, 1 warm-up + 5 timed
         qh = q.cpu().numpy()
-        index.search(qh, k, sp)
+        h_ids = np.empty((nq, k), np.uint64)
+        h_d = np.empty((nq, k), np.float32)
+        spc = sp._c()
+        aux0 = _lib.SearchAux()
+
+        def host_call():
+            _lib.check(L.svsx_search(index._h, qh.ctypes.data, 0, nq, k, C.byref(spc), h_ids.ctypes.data, None, h_d.ctypes.data, C.byref(aux0)))
+
+        host_call()
         host_ms = []
         for _ in range(5):
             t0 = time.perf_counter()
-            res_h = index.search(qh, k, sp)
+            host_call()
             host_ms.append(1e3 * (time.perf_counter() - t0))
         hp = stat3(host_ms, nq)
-        hp["ids_equal_device_path"] = bool((res_h.indices.astype(np.int64) == ids.cpu().numpy()).all())
+        hp["ids_equal_device_path"] = bool((h_ids.astype(np.int64) == ids.cpu().numpy()).all())
+        dev_med = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        hp["over_device_resident"] = dev_med / hp["median_ms"]
+        hp["how"] = ("one launch that starts before the queries have left the caller's buffer: the kernel reads them from page-locked host memory the calling thread "
+                     "fills chunk by chunk (flag per chunk), results are written straight to page-locked host memory and copied into the caller's arrays")
         result["config"]["host_pointer"] = hp
-        try:  # the same call with the queries in page-locked host memory (what a serving process would hand over): no staging copy
-            qp = q.cpu().pin_memory()
-            qph = qp.numpy()
-            index.search(qph, k, sp)
-            pin_ms = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                res_p = index.search(qph, k, sp)
-                pin_ms.append(1e3 * (time.perf_counter() - t0))
-            hpp = stat3(pin_ms, nq)
-            hpp["ids_equal_device_path"] = bool((res_p.indices.astype(np.int64) == ids.cpu().numpy()).all())
-            result["config"]["host_pointer_pinned_queries"] = hpp
-            del qph, qp
-        except Exception as e:  # informational: never fail the line over it
-            log(f"[bench] pinned host-pointer timing skipped: {e}")
+        result["config"]["host_pointer_qps"] = hp["qps_at_median"]
         result["config"]["device_resident"] = stat3([a.elapsed_time(b) for a, b in ev], nq)
         # smallest window with recall@10 >= 0.9 (binary search of index/vamana/calibrate.h:286-300), timed the same way
         lo_w, hi_w = k, args.window
@@ -605,6 +722,8 @@ def main():
         ids_matched = ids.clone()
         result["config"]["matched_recall_point"] = matched
         try:  # informational: the same kernel, graph and window on a 4x batch -- a launch pays ~0.2 ms of ramp and drain whatever its size
+            if args.no_extras:
+                raise RuntimeError("--no-extras")
             nq4 = 4 * nq
             q4 = deep_like_device(nq4, d, 24, seed=3, device=device)
             ids4 = torch.empty((nq4, k), dtype=torch.int64, device=device)
@@ -628,6 +747,49 @@ def main():
             del q4, ids4, dists4, st4
         except Exception as e:
             log(f"[bench] 4x batch point skipped: {e}")
+        if not args.no_extras:
+            try:  # BASELINE config 3 as a point of the same line: sift-1M-like, 1 M x 128 float16 rows, float32 queries, inner product
+                from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device
+
+                t0 = time.time()
+                n3, d3 = 1_000_000, 128
+                x3 = deep_like_device(n3, d3, 32, seed=31, device=device, normalize=False).half()
+                q3 = deep_like_device(nq, d3, 32, seed=32, device=device, normalize=False)
+                g3, e3 = build_vamana_device(x3, n3, d3, svs.DistanceIP(), VamanaBuildParameters(alpha=0.95, graph_max_degree=R, window_size=2 * R, prune_to=R - 4),
+                                             data_dtype=np.float16, device=local_rank)
+                i3 = svs.VamanaIndex.from_device(g3, x3, svs.DistanceIP(), torch.tensor([e3], dtype=torch.int32, device=device), n3, d3, np.float16, device=local_rank)
+                i3.build_bound_codes(2)
+                torch.cuda.synchronize()
+                t_b3 = time.time() - t0
+                ids3 = torch.empty((nq, k), dtype=torch.int64, device=device)
+                dd3 = torch.empty((nq, k), dtype=torch.float32, device=device)
+                st3 = torch.zeros((nq, 6), dtype=torch.int32, device=device)
+                i3.search_device(q3, k, sp, d_ids64=ids3, d_dists=dd3, d_stats=st3)
+                for _ in range(args.warmup):
+                    i3.search_device(q3, k, sp, d_ids64=ids3, d_dists=dd3)
+                torch.cuda.synchronize()
+                e3v = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                for a_, b_ in e3v:
+                    a_.record()
+                    i3.search_device(q3, k, sp, d_ids64=ids3, d_dists=dd3)
+                    b_.record()
+                torch.cuda.synchronize()
+                ms3 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in e3v]))
+                gt3, _ = i3.flat_search_device(q3, k)
+                torch.cuda.synchronize()
+                k3 = i3.last_kernel_info()
+                rb3 = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(k3[-8:], 32)
+                l3 = designed_lines(st3.to(torch.int64), gstride, d3 * 2, 2, d3, k, rb3)
+                result["config"].setdefault("other_configs", {})["c3"] = {
+                    "workload": f"sift-1M-like d=128 float16 rows, float32 queries, inner product, batch={nq}, search_window={args.window}, k=10, 1xMI355X",
+                    "qps": nq / (ms3 * 1e-3), "kernel_ms": ms3, "recall_at_10": recall_at(gt3, ids3, k), "kernel": "svsx::" + k3,
+                    "designed_lines_per_query": l3["total"] / nq, "frac_designed": l3["total"] * LINE / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "expansions_per_query": int(st3[:, 0].sum()) / nq, "bound_code_rejects_per_query": int(st3[:, 5].sum()) / nq,
+                    "distance_evals_per_query": int(st3[:, 2].sum()) / nq, "build_seconds": t_b3,
+                    "graph": f"Vamana R={R} L={2*R} alpha=0.95 (built by svsx_vamana_build_device)"}
+                del x3, q3, g3, i3, ids3, dd3, st3, gt3
+            except Exception as e:  # informational: never fail the line over it
+                log(f"[bench] config-3 point skipped: {e}")
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)  # restore window-128 results for the parity sample
         torch.cuda.synchronize()
         if not args.no_cpu_baseline:

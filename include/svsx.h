@@ -105,6 +105,8 @@ typedef struct {
  *   history_*    per query, the expanded nodes in order (id, distance) -- the builder's
  *                use_full_search_history pool (vamana_build.h:54-91); history_len may exceed history_cap. */
 typedef struct {
+    size_t struct_size;             /* sizeof(svsx_search_aux) as the CALLER compiled it (0 = this version's): fields beyond it read as 0,
+                                       so the struct can grow at its end without breaking callers built against an older header */
     uint32_t* stats;
     uint32_t* history_ids;
     float* history_dists;
@@ -171,6 +173,28 @@ int svsx_merge_topk_device(
 int svsx_merge_topk_strided_device(
     int metric, size_t n_shards, size_t nq, size_t k, const float* d_dists, size_t dist_shard_stride, const uint64_t* d_ids,
     size_t id_shard_stride, float* d_out_dists, uint64_t* d_out_ids, void* hip_stream
+);
+
+/* Sharded search (new design -- the reference has no sharded mode, the closest anchor is its partition of the queries over
+ * threads, index/vamana/index.h:571-574).  One object per process / GPU.  This rank's `n_local` shards are the global shards
+ * rank * n_local + s in order (contiguous id ranges: svsx_index_desc.id_offset); every rank passes the same query batch.  Per call:
+ * search every local shard, merge them locally, ONE ncclAllGather (RCCL over xGMI) of nq * k * 12 bytes per rank, world-way merge --
+ * ties -> lower shard, then position, so the answer equals one merge over all shards in shard order and is identical on every rank.
+ *   svsx_sharded_unique_id         ncclGetUniqueId (128 bytes): rank 0 makes it, the host program hands it to every rank
+ *   svsx_sharded_create            joins the communicator (ncclCommInitRank; collective).  id128 == NULL with world == 1: no exchange step
+ *   svsx_sharded_create_with_comm  for hosts that already own an ncclComm_t (not destroyed with the object)
+ *   svsx_sharded_search_device     device pointers, enqueued on hip_stream; nq * k must be even
+ *   svsx_sharded_info              info[0] local shards, [1] world, [2] rank, [3] 1 when a communicator is attached
+ * RCCL is loaded at run time (librccl.so.1); without it only world == 1 / id128 == NULL objects can be created. */
+typedef struct svsx_sharded svsx_sharded;
+int svsx_sharded_unique_id(void* id128);
+int svsx_sharded_create(const svsx_index* const* local_shards, size_t n_local, const void* id128, int rank, int world, svsx_sharded** out);
+int svsx_sharded_create_with_comm(const svsx_index* const* local_shards, size_t n_local, void* nccl_comm, int rank, int world, svsx_sharded** out);
+void svsx_sharded_destroy(svsx_sharded* sharded);
+int svsx_sharded_info(const svsx_sharded* sharded, uint64_t info[4]);
+int svsx_sharded_search_device(
+    svsx_sharded* sharded, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params, uint64_t* d_ids64,
+    float* d_dists, void* hip_stream
 );
 
 /* Exhaustive search: svs::index::flat::FlatIndex::search (index/flat/flat.h:322-460) -- every query
@@ -256,17 +280,20 @@ int svsx_search_filtered(
     const uint64_t* id_bitmap, float filter_stop, uint64_t* ids64, float* dists
 );
 
-/* Bound codes (no reference counterpart; result-neutral).  The search kernel turns them into a rigorous LOWER BOUND of
- * the L2 distance and drops candidates that can_skip (search_buffer.h:338-340) would drop anyway before their full row
- * is fetched -- ids and distances returned are unchanged, only the number of 128-byte lines requested per hop falls.
- *   mode 1  one 128-byte row per vector: 8-bit codes of its first min(d, 120) components + exact coding error
- *           (d = 96 or 128; +128 B of HBM per vector; one extra line per candidate)
- *   mode 2  graph-inline records: every adjacency row carries a 32-byte record per neighbour (28 8-bit codes of the
- *           leading components in a PCA basis of the data, coding error, norm of the uncoded tail), so one hop reads ONE
- *           contiguous block of (4 + 32) * max_degree bytes and bounds all its neighbours at once
- *           (32 <= d <= 128; +32 B x max_degree per vector)
- *   mode 0  frees either.
- * float32 or float16 data, L2 (SVSX_NOT_IMPLEMENTED otherwise).  Call while no search is in flight on this index. */
+/* Bound codes (no reference counterpart; result-neutral).  The search kernel turns them into a rigorous BOUND of the distance (lower
+ * bound for L2, upper bound for inner product / cosine) and drops candidates that SearchBuffer::can_skip (search_buffer.h:338-340) would
+ * drop anyway before their full row is fetched -- ids and distances returned are unchanged, only the number of 128-byte lines requested
+ * per hop falls.
+ *   mode 2        graph-inline records (the default of bench.py): every adjacency row carries a 32- / 64- / 128-byte record per neighbour
+ *                 (8-bit codes of the leading coordinates in a principal basis of the data, coding error, norm of the uncoded remainder),
+ *                 so one hop reads ONE contiguous block of (4 + record) * max_degree bytes and bounds all its neighbours at once.  The record
+ *                 size is chosen from the data's spectrum (expected lines per hop).  float32 / float16 rows under any metric, scalar-
+ *                 quantized rows under inner product / cosine; dimension 32..4096; + record * max_degree bytes of HBM per vector.
+ *   mode 32 / 64 / 128   the same with exactly this record size (refused when larger than a third of the rows it protects)
+ *   mode 1        one 128-byte row per vector: 8-bit codes of its first min(d, 120) components + exact coding error (float32 / float16
+ *                 rows, L2, d = 96 or 128; +128 B per vector, one extra line per candidate).  For indexes whose inline rows do not fit.
+ *   mode 0        frees either.
+ * SVSX_NOT_IMPLEMENTED for other row types.  Call while no search is in flight on this index. */
 int svsx_index_build_bound_codes(svsx_index* index, int mode);
 
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),

@@ -130,12 +130,16 @@ template <typename T, typename Dist> class VamanaIndex {
         if (cancel()) return; // extensions.h:575-578: nothing starts
         svsx_search_params p{sp.buffer_config_.get_search_window_size(), sp.buffer_config_.get_total_capacity(),
                              sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
-        std::atomic<int> flag{0}, finished{0};
+        // the word the library polls is a plain volatile int (what the C ABI declares); the helper thread is its only writer, through
+        // an atomic_ref, so no object of another type is passed off as one
+        alignas(std::atomic_ref<int>::required_alignment) volatile int flag = 0;
+        std::atomic<int> finished{0};
         svsx_search_aux aux{};
-        aux.cancel_flag = reinterpret_cast<const volatile int*>(&flag);
+        aux.struct_size = sizeof(aux);
+        aux.cancel_flag = &flag;
         std::thread poller([&] {
             while (!finished.load(std::memory_order_acquire)) {
-                if (cancel()) { flag.store(1, std::memory_order_release); return; }
+                if (cancel()) { std::atomic_ref<int>(const_cast<int&>(flag)).store(1, std::memory_order_release); return; }
                 std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
         });
@@ -150,8 +154,20 @@ template <typename T, typename Dist> class VamanaIndex {
         search(r.view(), queries, defaults_);
         return r;
     }
-    // optional, result-neutral: 128 B of lower-bound codes per vector (float32 L2, d = 96 / 128); see svsx.h
-    void build_bound_codes(bool enable = true) { check(svsx_index_build_bound_codes(h_, enable ? 1 : 0)); }
+    // optional, result-neutral (svsx.h): 2 = graph-inline bound records sized from the data's spectrum (the default and the fast path of
+    // bench.py), 32 / 64 / 128 = records of that size, 1 = one 128-byte code row per vector (float rows, L2, d = 96 / 128), 0 = off
+    void build_bound_codes(int mode = 2) { check(svsx_index_build_bound_codes(h_, mode)); }
+    // runtime VamanaIndex::search(n, x, k, distances, labels, params, IDFilter* filter) (bindings/cpp/include/svs/runtime/vamana_index.h:75-83):
+    // `is_member` = one bit per id ((size() + 63) / 64 words); unfilled result slots hold id all-ones / distance +inf
+    template <typename Q>
+    void search(QueryResultView<size_t> result, const Q* queries, const VamanaSearchParameters& sp, std::span<const uint64_t> is_member,
+                float filter_stop = 0.0f) const {
+        svsx_search_params p{sp.buffer_config_.get_search_window_size(), sp.buffer_config_.get_total_capacity(),
+                             sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
+        if (is_member.size() * 64 < size()) throw ANNException(SVSX_INVALID_ARGUMENT, "is_member must hold one bit per vector");
+        check(svsx_search_filtered(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), &p, is_member.data(), filter_stop,
+                                   reinterpret_cast<uint64_t*>(result.indices), result.distances));
+    }
     const svsx_index* handle() const { return h_; }
     size_t size() const { uint64_t info[6]; check(svsx_index_info(h_, info)); return info[0]; }
 };

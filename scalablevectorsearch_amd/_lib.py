@@ -52,9 +52,18 @@ class SearchParams(C.Structure):
 
 class SearchAux(C.Structure):
     _fields_ = [
-        ("stats", C.c_void_p), ("history_ids", C.c_void_p), ("history_dists", C.c_void_p), ("history_len", C.c_void_p),
+        ("struct_size", C.c_size_t), ("stats", C.c_void_p), ("history_ids", C.c_void_p), ("history_dists", C.c_void_p), ("history_len", C.c_void_p),
         ("history_cap", C.c_size_t), ("query_row_stride_bytes", C.c_size_t), ("cancel_flag", C.c_void_p),
     ]
+
+
+def _aux_init(self, *a, **kw):
+    C.Structure.__init__(self, *a, **kw)
+    if not self.struct_size:
+        self.struct_size = C.sizeof(SearchAux)
+
+
+SearchAux.__init__ = _aux_init
 
 
 class BuildParams(C.Structure):
@@ -72,6 +81,8 @@ EXPORTS = [
     "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
     "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
     "svsx_last_kernel_info", "svsx_search_filtered", "svsx_vamana_build_device", "svsx_find_medoid_device",
+    "svsx_sharded_unique_id", "svsx_sharded_create", "svsx_sharded_create_with_comm", "svsx_sharded_destroy", "svsx_sharded_info",
+    "svsx_sharded_search_device",
 ]
 
 _lib = None
@@ -134,6 +145,13 @@ def lib() -> C.CDLL:
         L.svsx_search_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.svsx_vamana_build_device.argtypes = [C.c_void_p, C.POINTER(BuildParams), C.c_void_p]
         L.svsx_find_medoid_device.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.svsx_sharded_unique_id.argtypes = [C.c_void_p]
+        L.svsx_sharded_create.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.svsx_sharded_create_with_comm.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.svsx_sharded_destroy.argtypes = [C.c_void_p]
+        L.svsx_sharded_destroy.restype = None
+        L.svsx_sharded_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.svsx_sharded_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

@@ -81,9 +81,10 @@ def find_medoid(data_f32) -> int:
     return arg
 
 
-def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildParameters, data_dtype=np.float32, device: int = 0,
-                        entry_point: int | None = None, progress=None, sq=None):
-    """Build a Vamana graph over `d_data` (torch tensor on cuda:device in the device layout: rows padded to 16 elements).
+def build_vamana_torch_glue(d_data, n: int, d: int, distance, params: VamanaBuildParameters, data_dtype=np.float32, device: int = 0,
+                            entry_point: int | None = None, progress=None, sq=None):
+    """Round-2 builder, kept as the CHECKER of the in-library one (tests/test_gpu_native_builder.py): the same batch-synchronous algorithm
+    with pool assembly and reverse-edge bookkeeping as torch tensor ops around the HIP search and prune kernels.
 
     Returns (d_graph [n, gstride] int32 with -1 padding, entry_point).
     """
@@ -179,10 +180,14 @@ def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildPar
     return graph, entry
 
 
-def build_vamana_native(d_data, n: int, d: int, distance, params: VamanaBuildParameters, data_dtype=np.float32, device: int = 0,
-                        entry_point: int | None = None, sq=None):
-    """Same contract as build_vamana_device, every step inside libsvsx (svsx_vamana_build_device: search with history, pool assembly,
-    prune, reverse edges -- csrc/svsx_builder.hip).  Returns (d_graph [n, gstride] int32 with -1 padding, entry_point)."""
+def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildParameters, data_dtype=np.float32, device: int = 0,
+                        entry_point: int | None = None, progress=None, sq=None):
+    """Build a Vamana graph over `d_data` (torch tensor on cuda:device in the device layout: rows padded to 16 elements), every step inside
+    libsvsx (svsx_vamana_build_device: search with history, pool assembly, prune, reverse edges, overflow re-prune; svsx_find_medoid_device
+    for the entry point -- csrc/svsx_builder.hip; index/vamana/vamana_build.h:232-599, prune.h:100-246, core/medioid.h:292-353).
+    `progress` is accepted for source compatibility (the build is one library call).
+
+    Returns (d_graph [n, gstride] int32 with -1 padding, entry_point)."""
     import torch
 
     fn = as_functor(distance)
@@ -210,3 +215,6 @@ def device_graph_to_svs(d_graph, max_degree: int) -> np.ndarray:
     out[:, 0] = deg
     out[:, 1:] = np.where(ids != 0xFFFFFFFF, ids, 0)
     return out
+
+
+build_vamana_native = build_vamana_device  # round-3 staging name

@@ -44,7 +44,7 @@ struct svsx_index {
     mutable float* d_norm2 = nullptr;
     // bound codes (svsx_index_build_bound_codes): 128 B per vector
     void* d_codes = nullptr;
-    float code_scale = 1.0f, code_bias = 0.0f;
+    float code_scale = 1.0f, code_bias = 0.0f, code_eq_abs = 0.0f;
     // graph-inline records (svsx_index_build_bound_codes mode 2; svsx_codes.hip)
     void* d_fat = nullptr;
     size_t fat_stride = 0;
@@ -70,6 +70,26 @@ int fail(int code, const char* fmt, ...) {
     g_error = buf;
     return code;
 }
+
+} // namespace
+
+namespace svsx { // for the other translation units of the library (svsx_sharded.hip)
+int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+void index_facts(const svsx_index* ix, int* metric, int* device) {
+    *metric = ix->metric;
+    *device = ix->device;
+}
+} // namespace svsx
+
+namespace {
 
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
@@ -139,7 +159,13 @@ struct HostCallContext {
     void* d_out = nullptr;  size_t d_out_cap = 0;   // ids64 | ids32 | dists | stats | history ids | history dists | history len
     void* h_in = nullptr;   size_t h_in_cap = 0;    // page-locked mirrors of the two
     void* h_out = nullptr;  size_t h_out_cap = 0;
+    uint32_t* h_flags = nullptr;                    // kFlagWords "chunk has arrived" words, page-locked (queries read in place)
+    uint32_t* d_flags = nullptr;                    // the same in HBM (queries DMA'd; written by hipStreamWriteValue32 behind each chunk's copy)
+    uint32_t epoch = 0;                             // value that means "arrived" for the current call
+    static constexpr size_t kFlagWords = 1024;
     ~HostCallContext() {
+        if (h_flags) (void)hipHostFree(h_flags);
+        if (d_flags) (void)hipFree(d_flags);
         for (auto st : streams) if (st) (void)hipStreamDestroy(st);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
@@ -153,16 +179,28 @@ struct HostCallContext {
             if (want <= cap) return hipSuccess;
             if (p) { (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; cap = 0; }
             const size_t bytes = want + want / 4 + 4096;
-            hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+            hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocCoherent) : hipMalloc(&p, bytes); // coherent: the kernel reads / writes it in place (zero-copy path)
             if (e == hipSuccess) cap = bytes;
             return e;
         };
-        hipError_t e = grow(d_in, d_in_cap, in_bytes, false);
-        if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes, false);
+        hipError_t e = hipSuccess;
+        if (n_streams > 0) { // DMA path: device staging next to the page-locked mirrors
+            e = grow(d_in, d_in_cap, in_bytes, false);
+            if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes, false);
+        }
         if (e == hipSuccess) e = grow(h_in, h_in_cap, in_bytes, true);
         if (e == hipSuccess) e = grow(h_out, h_out_cap, out_bytes, true);
+        if (e == hipSuccess && !h_flags) {
+            e = hipHostMalloc(reinterpret_cast<void**>(&h_flags), kFlagWords * sizeof(uint32_t), hipHostMallocCoherent);
+            if (e == hipSuccess) memset(h_flags, 0, kFlagWords * sizeof(uint32_t));
+        }
+        if (e == hipSuccess && !d_flags) {
+            e = hipMalloc(reinterpret_cast<void**>(&d_flags), kFlagWords * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemset(d_flags, 0, kFlagWords * sizeof(uint32_t));
+        }
         return e;
     }
+    hipError_t stream0() { return streams[0] ? hipSuccess : hipStreamCreateWithFlags(&streams[0], hipStreamNonBlocking); }
 };
 
 namespace {
@@ -422,7 +460,7 @@ void orthonormalize_columns(std::vector<double>& V, uint32_t d, uint32_t m) {
 }
 
 // graph-inline records: sample -> leading principal directions (host, f64) -> per-vector records (device) -> node rows (device)
-int build_fat_rows(svsx_index* ix) {
+int build_fat_rows(svsx_index* ix, uint32_t forced_rb) {
     const uint32_t d = static_cast<uint32_t>(ix->d), n = static_cast<uint32_t>(ix->n);
     const size_t es = dtype_size(ix->data_dtype);
     const bool l2 = ix->metric == M_L2, cosine = ix->metric == M_COS;
@@ -555,9 +593,9 @@ int build_fat_rows(svsx_index* ix) {
             rb = r;
         }
     }
-    if (const char* force = getenv("SVSX_RECORD_BYTES")) { // experiments: 32 / 64 / 128
-        const uint32_t f = static_cast<uint32_t>(atoi(force));
-        if ((f == 32 || f == 64 || f == 128) && f <= rb_max) rb = f;
+    if (forced_rb != 0) { // the caller asked for this record size (svsx_index_build_bound_codes mode 32 / 64 / 128)
+        if (forced_rb > rb_max) return fail(SVSX_INVALID_ARGUMENT, "records of %u bytes exceed a third of the %zu-byte rows they protect", forced_rb, ix->row_bytes);
+        rb = forced_rb;
     }
     const uint32_t dc = rb - meta;
     const uint32_t dcu = dc < m ? dc : m; // directions really used (d < dc cannot happen: d >= 32 and m >= dc unless d is smaller)
@@ -664,7 +702,12 @@ int build_fat_rows(svsx_index* ix) {
 
 extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
     if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
-    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows) or 2 (graph-inline records)");
+    uint32_t forced_rb = 0;
+    if (mode == 32 || mode == 64 || mode == 128) { // graph-inline records of exactly this size
+        forced_rb = static_cast<uint32_t>(mode);
+        mode = 2;
+    }
+    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows), 2 (graph-inline records) or 32 / 64 / 128 (inline records of that size)");
     HIP_TRY(hipSetDevice(ix->device));
     std::lock_guard<std::mutex> lock(ix->shadow_mutex);
     HIP_TRY(hipDeviceSynchronize());
@@ -675,12 +718,13 @@ extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
     if (mode == 2) {
         // float32 / float16 rows (any metric) and scalar-quantized rows under inner product / cosine (the compressed L2 distance
         // is taken between CODED query and data, scalar.h:58-105, and the raw int8 x int8 kernels are exact integer paths)
-        if (ix->d_fat) return SVSX_SUCCESS;
+        if (ix->d_fat && (forced_rb == 0 || forced_rb == ix->fat_rb)) return SVSX_SUCCESS;
+        if (ix->d_fat) { (void)hipFree(ix->d_fat); ix->d_fat = nullptr; }
         const bool float_rows = (ix->data_dtype == DT_F32 || ix->data_dtype == DT_F16) && !ix->sq_enabled;
         const bool sq_rows = ix->sq_enabled && ix->metric != M_L2;
         if (!float_rows && !sq_rows) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover float32 / float16 rows and scalar-quantized rows under inner product or cosine");
         if (ix->d < 32 || ix->d > 4096 || !ix->d_graph) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover graph indexes of dimension 32..4096");
-        return build_fat_rows(ix);
+        return build_fat_rows(ix, forced_rb);
     }
     if (ix->metric != M_L2 || (ix->data_dtype != DT_F32 && ix->data_dtype != DT_F16) || ix->sq_enabled)
         return fail(SVSX_NOT_IMPLEMENTED, "128-byte bound-code rows cover float32 / float16 L2 indexes");
@@ -706,6 +750,7 @@ extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
     }
     ix->code_scale = scale;
     ix->code_bias = lo;
+    ix->code_eq_abs = static_cast<float>(std::sqrt(static_cast<double>(dc)) * 2.4e-7 * (std::fabs(static_cast<double>(lo)) + 255.0 * scale) * 1.01);
     ix->d_codes = codes;
     return SVSX_SUCCESS;
 }
@@ -735,6 +780,7 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
         a.codes = static_cast<const unsigned char*>(ix->d_codes);
         a.code_scale = ix->code_scale;
         a.code_bias = ix->code_bias;
+        a.code_eq_abs = ix->code_eq_abs;
     }
     if (ix->d_fat && !a.general) { // graph-inline records: same guarantee, one contiguous block per expansion
         a.fat = static_cast<const unsigned char*>(ix->d_fat);
@@ -761,6 +807,9 @@ static void default_filter(const svsx_index* ix, SearchArgs& a, uint32_t fe) {
     a.filter_tag8 = (a.filter_entries && (ix->n >> __builtin_ctz(a.filter_entries)) < 0xFFu) ? 1u : 0u;
     if (a.fat != nullptr) a.filter_tag8 = 0; // the inline-record kernel keeps only fetched rows in the filter: 16-bit tags, no variant
 }
+
+static thread_local const uint32_t* g_host_flags = nullptr; // set by search_host_zero_copy around its search_common call
+static thread_local uint32_t g_host_flag_shift = 0, g_host_flag_epoch = 0;
 
 static int search_common(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
@@ -814,6 +863,9 @@ static int search_common(
         a.history_cap = static_cast<uint32_t>(aux->history_cap);
         a.cancel = const_cast<const int*>(aux->cancel_flag); // device word here (svsx_search mirrors the caller's host word into one)
     }
+    a.q_ready = g_host_flags;
+    a.q_ready_shift = g_host_flag_shift;
+    a.q_ready_epoch = g_host_flag_epoch;
     hipError_t e = launch_search(ix->data_dtype, ix->metric, qmode, a, stream);
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "search kernel launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
@@ -829,19 +881,84 @@ static int check_search_args(const svsx_index* ix, const void* queries, int q_dt
     return SVSX_SUCCESS;
 }
 
+// the caller's aux through the size it was compiled with (svsx.h: struct_size)
+static const svsx_search_aux* normalise_aux(const svsx_search_aux* in, svsx_search_aux& store) {
+    if (!in) return nullptr;
+    if (in->struct_size == 0 || in->struct_size >= sizeof(svsx_search_aux)) return in;
+    memset(&store, 0, sizeof(store));
+    memcpy(&store, in, in->struct_size < sizeof(size_t) ? sizeof(size_t) : in->struct_size);
+    return &store;
+}
+
 int svsx_search_device(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
-    uint64_t* d_ids64, uint32_t* d_ids32, float* d_dists, const svsx_search_aux* d_aux, void* hip_stream
+    uint64_t* d_ids64, uint32_t* d_ids32, float* d_dists, const svsx_search_aux* d_aux_in, void* hip_stream
 ) {
+    svsx_search_aux aux_store;
+    const svsx_search_aux* d_aux = normalise_aux(d_aux_in, aux_store);
     if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k)) return rc;
     if (nq == 0) return SVSX_SUCCESS;
     HIP_TRY(hipSetDevice(ix->device));
     return search_common(ix, d_queries, q_dtype, nq, k, params, d_ids64, d_ids32, d_dists, d_aux, static_cast<hipStream_t>(hip_stream));
 }
 
+#ifdef SVSX_DIAG
+// Experimental (DIAG builds, SVSX_HOST_IN=1): ONE launch that starts before the queries have left the caller's buffer.  The kernel reads
+// them from page-locked HOST memory the calling thread fills chunk by chunk while the kernel runs; a wave polls the "arrived" word of its own
+// query's chunk (relaxed, system scope; the words hold a per-call epoch, nothing is reset).  Results: D2H copy behind the kernel (out 0) or
+// written by the kernel straight to page-locked host memory (out 1).  The flags are written by the HOST THREAD, never by a stream operation:
+// a kernel must not wait for work queued on another stream -- streams share hardware queues, and the round-3 variant that waited for
+// hipStreamWriteValue32 behind an H2D copy dead-locked under test_concurrent_host_callers.  Measurements: profiles/r03_notes.md.
+enum HostMode { kHostDma = 0, kHostZeroCopy = 1 };
+static int search_host_single_launch(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    uint64_t* ids64, uint32_t* ids32, float* dists, size_t q_stride, int out_mode
+) {
+    ContextLease lease(ix);
+    HostCallContext* c = lease.c;
+    if (!c) return fail(SVSX_RUNTIME_ERROR, "out of host memory");
+    const size_t o64 = 0, o32 = ids64 ? ((nq * k * 8 + 255) & ~size_t(255)) : 0;
+    const size_t odd = o32 + (ids32 ? ((nq * k * 4 + 255) & ~size_t(255)) : 0);
+    const size_t out_bytes = odd + (dists ? nq * k * 4 : 0);
+    HIP_TRY(c->reserve(q_stride * nq, out_bytes, 2));
+    // chunks of 2^shift queries, at most kFlagWords of them
+    uint32_t shift = 9; // 512 queries = 196 KB of float32 d = 96 rows: a few microseconds per chunk
+    while ((nq >> shift) + 1 > HostCallContext::kFlagWords) ++shift;
+    const size_t per = size_t(1) << shift, nchunks = (nq + per - 1) / per;
+    c->epoch = c->epoch + 1u ? c->epoch + 1u : 1u;
+    const uint32_t epoch = c->epoch;
+    hipStream_t sk = c->streams[0];
+    svsx_search_aux daux;
+    memset(&daux, 0, sizeof(daux));
+    daux.query_row_stride_bytes = q_stride;
+    unsigned char* out = static_cast<unsigned char*>(out_mode == kHostZeroCopy ? c->h_out : c->d_out);
+    g_host_flags = c->h_flags;
+    g_host_flag_shift = shift;
+    g_host_flag_epoch = epoch;
+    const int rc = search_common(ix, c->h_in, q_dtype, nq, k, params, ids64 ? reinterpret_cast<uint64_t*>(out + o64) : nullptr,
+                                 ids32 ? reinterpret_cast<uint32_t*>(out + o32) : nullptr, dists ? reinterpret_cast<float*>(out + odd) : nullptr, &daux, sk);
+    g_host_flags = nullptr;
+    if (rc != SVSX_SUCCESS) return rc;
+    if (out_mode == kHostDma) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, sk)); // behind the kernel
+    // the launch is on its way: now feed it
+    for (size_t i = 0; i < nchunks; ++i) {
+        const size_t lo = i * per, cnt = (lo + per <= nq) ? per : nq - lo;
+        unsigned char* hq = static_cast<unsigned char*>(c->h_in) + q_stride * lo;
+        memcpy(hq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * cnt);
+        __atomic_store_n(&c->h_flags[i], epoch, __ATOMIC_RELEASE);
+    }
+    HIP_TRY(hipStreamSynchronize(sk));
+    const unsigned char* res = static_cast<const unsigned char*>(c->h_out);
+    if (ids64) memcpy(ids64, res + o64, nq * k * 8);
+    if (ids32) memcpy(ids32, res + o32, nq * k * 4);
+    if (dists) memcpy(dists, res + odd, nq * k * 4);
+    return SVSX_SUCCESS;
+}
+#endif // SVSX_DIAG
+
 // Host pointers in, host results out (SURVEY 8d's QPS definition; benchmark/include/svs-benchmark/search.h:209-219 times exactly this call).
-// Chunk i: CPU copy into the page-locked mirror -> H2D -> kernel -> D2H on stream i, then CPU copy out once stream i has drained.  The first
-// and the last chunk are small: only their copies are exposed.
+// The form that also serves the side outputs (statistics, search history): page-locked mirror -> H2D -> kernel -> D2H on one stream with
+// persistent staging.  (DIAG builds can cut the batch into chunks on separate streams for A/B: measured slower than one launch.)
 static int search_host_pipelined(
     const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux, size_t q_stride
@@ -853,13 +970,17 @@ static int search_host_pipelined(
     size_t bounds[HostCallContext::kMaxChunks + 1];
     int nc = 1;
     bounds[0] = 0;
-    if (nq >= 4096) {
-        const size_t edge = nq / 10 < 1024 ? nq / 10 : 1024;
-        const int mid = nq >= 32768 ? 6 : 3;
-        nc = mid + 2;
-        bounds[1] = edge;
-        for (int i = 1; i <= mid; ++i) bounds[1 + i] = edge + (nq - 2 * edge) * static_cast<size_t>(i) / static_cast<size_t>(mid);
-        bounds[nc] = nq;
+    // Two launches on two streams: the first 4 096 queries start as soon as their 1.5 MB have crossed PCIe, the rest is copied while they
+    // run.  More chunks lose: a later launch only gets compute units when an earlier one has drained, so every extra launch adds a drain
+    // (five chunks: 1.43-1.50 ms against 1.15 ms for the kernel alone; profiles/r03_notes.md).
+    size_t first = nq > 4096 ? 4096 : nq;
+#ifdef SVSX_DIAG
+    if (const char* e = getenv("SVSX_HOST_SPLIT")) first = std::min<size_t>(nq, std::max<size_t>(1, static_cast<size_t>(atol(e))));
+#endif
+    if (first < nq) {
+        nc = 2;
+        bounds[1] = first;
+        bounds[2] = nq;
     } else {
         bounds[1] = nq;
     }
@@ -880,6 +1001,11 @@ static int search_host_pipelined(
     const int rhi = add_region(aux ? aux->history_ids : nullptr, hcap * 4), rhd = add_region(aux ? aux->history_dists : nullptr, hcap * 4);
     const int rhl = add_region(aux ? aux->history_len : nullptr, 4);
     HIP_TRY(c->reserve(q_stride * nq, out_bytes, nc));
+#ifdef SVSX_DIAG
+    const auto diag_t0 = std::chrono::steady_clock::now();
+    auto diag_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - diag_t0).count(); };
+    double diag_in[HostCallContext::kMaxChunks] = {}, diag_enq[HostCallContext::kMaxChunks] = {}, diag_sync[HostCallContext::kMaxChunks] = {}, diag_out[HostCallContext::kMaxChunks] = {};
+#endif
     auto dptr = [&](int r, size_t row) -> void* { return r < 0 ? nullptr : static_cast<unsigned char*>(c->d_out) + regions[r].offset + regions[r].row_bytes * row; };
     for (int i = 0; i < nc; ++i) {
         const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
@@ -887,6 +1013,9 @@ static int search_host_pipelined(
         hipStream_t st = c->streams[i];
         unsigned char* hq = static_cast<unsigned char*>(c->h_in) + q_stride * lo;
         memcpy(hq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * cnt);
+#ifdef SVSX_DIAG
+        diag_in[i] = diag_us();
+#endif
         void* dq = static_cast<unsigned char*>(c->d_in) + q_stride * lo;
         HIP_TRY(hipMemcpyAsync(dq, hq, q_stride * cnt, hipMemcpyHostToDevice, st));
         svsx_search_aux daux;
@@ -906,22 +1035,40 @@ static int search_host_pipelined(
             const size_t off = regions[r].offset + regions[r].row_bytes * lo;
             HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(c->h_out) + off, static_cast<unsigned char*>(c->d_out) + off, regions[r].row_bytes * cnt, hipMemcpyDeviceToHost, st));
         }
+#ifdef SVSX_DIAG
+        diag_enq[i] = diag_us();
+#endif
     }
     for (int i = 0; i < nc; ++i) {
         const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
         if (cnt == 0) continue;
         HIP_TRY(hipStreamSynchronize(c->streams[i]));
+#ifdef SVSX_DIAG
+        diag_sync[i] = diag_us();
+#endif
         for (int r = 0; r < nr; ++r)
             memcpy(static_cast<unsigned char*>(regions[r].host) + regions[r].row_bytes * lo,
                    static_cast<const unsigned char*>(c->h_out) + regions[r].offset + regions[r].row_bytes * lo, regions[r].row_bytes * cnt);
+#ifdef SVSX_DIAG
+        diag_out[i] = diag_us();
+#endif
     }
+#ifdef SVSX_DIAG
+    if (getenv("SVSX_HOST_TIMELINE")) {
+        fprintf(stderr, "[svsx host timeline, us] chunks %d:", nc);
+        for (int i = 0; i < nc; ++i) fprintf(stderr, "  #%d(%zu) in %.0f enq %.0f sync %.0f out %.0f", i, bounds[i + 1] - bounds[i], diag_in[i], diag_enq[i], diag_sync[i], diag_out[i]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return SVSX_SUCCESS;
 }
 
 int svsx_search(
     const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
-    uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux
+    uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux_in
 ) {
+    svsx_search_aux aux_store;
+    const svsx_search_aux* aux = normalise_aux(aux_in, aux_store);
     if (!ix) {
         // vamana_index_impl.h:115-123: outputs filled with the "unspecified" sentinels
         if (dists) for (size_t i = 0; i < nq * k; ++i) dists[i] = __builtin_inff();
@@ -933,6 +1080,13 @@ int svsx_search(
     if (nq == 0) return SVSX_SUCCESS;
     HIP_TRY(hipSetDevice(ix->device));
     const size_t q_stride = (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype);
+#ifdef SVSX_DIAG
+    const bool side_outputs = aux && (aux->stats || aux->history_ids || aux->history_dists || aux->history_len);
+    if (!(aux && aux->cancel_flag) && !side_outputs) {
+        if (const char* e = getenv("SVSX_HOST_IN"))
+            if (atoi(e) == 1) return search_host_single_launch(ix, queries, q_dtype, nq, k, params, ids64, ids32, dists, q_stride, getenv("SVSX_HOST_OUT") ? atoi(getenv("SVSX_HOST_OUT")) : 0);
+    }
+#endif
     if (!(aux && aux->cancel_flag)) return search_host_pipelined(ix, queries, q_dtype, nq, k, params, ids64, ids32, dists, aux, q_stride);
     // ---- with a cancel word: one chunk on one stream, the host thread polls the caller's word while the stream drains -------------------
     CallStream cs;
@@ -1381,7 +1535,7 @@ int svsx_iterator_create(
     if (qmode < 0)
         return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d%s) pair", q_dtype, ix->data_dtype, ix->sq_enabled ? ", SQ" : "");
     if (extra == ~size_t(0)) extra = 100; // lib/preprocessor.h:177,187
-    if (extra > 16000) return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu exceeds the LDS budget of one wave", extra);
+    if (extra >= (size_t(1) << 31)) return fail(SVSX_INVALID_ARGUMENT, "extra search buffer capacity %zu out of range", extra); // beyond one wave's LDS the buffers live in HBM
     HIP_TRY(hipSetDevice(ix->device));
     svsx_batch_iterator* it = new (std::nothrow) svsx_batch_iterator();
     if (!it) return fail(SVSX_RUNTIME_ERROR, "out of memory");
@@ -1467,6 +1621,7 @@ int svsx_iterator_next_device(
     SearchArgs a = base_search_args(ix, it->d_queries, it->q_dtype, it->q_stride, it->nq);
     a.general = 1;
     a.codes = nullptr;
+    a.fat = nullptr; // the iterator kernel reads neither code rows nor inline records: the default filter below then keeps its 8-bit tags
     a.window = static_cast<uint32_t>(spill ? 1 : cap); // per-query values come from the state table; this sizes the LDS buffer
     a.capacity = static_cast<uint32_t>(spill ? 1 : cap);
     a.it_spill = spill ? 1u : 0u;
@@ -1537,64 +1692,101 @@ extern "C" int svsx_search_filtered(
     }
     const size_t sws = params ? params->search_window_size : 0;
     const size_t max_batch = ix->n;
-    svsx_batch_iterator* it = nullptr;
-    if (int rc = svsx_iterator_create(ix, queries, q_dtype, nq, ~size_t(0), &it)) return rc;
-    std::vector<size_t> found(nq, 0), checked(nq, 0), batch(nq, std::max(k, sws));
-    std::vector<char> active(nq, 1);
-    std::vector<uint32_t> per_query(nq), counts(nq), meta(nq * 8);
-    std::vector<uint64_t> b_ids;
-    std::vector<float> b_dists;
+    const size_t q_row = ix->d * dtype_size(q_dtype);
     auto predict = [](size_t processed, size_t hits, size_t goal, size_t hint, size_t max_value) -> size_t { // svs_runtime_utils.h:411-419
         if (hits == 0 || hits >= goal) return std::min(hint, max_value);
         const float bs = static_cast<float>(goal - hits) * processed / hits;
         return std::min(std::max(static_cast<size_t>(bs), size_t(1)), max_value);
     };
-    int rc = SVSX_SUCCESS;
-    size_t n_active = nq;
-    while (n_active > 0 && rc == SVSX_SUCCESS) {
-        size_t round_max = 0;
-        for (size_t i = 0; i < nq; ++i) {
-            if (!active[i]) { per_query[i] = 0xFFFFFFFFu; continue; }
-            batch[i] = predict(checked[i], found[i], k, batch[i], max_batch);
-            per_query[i] = static_cast<uint32_t>(std::min<size_t>(batch[i], 0xFFFFFFFEu));
-            round_max = std::max(round_max, batch[i]);
-        }
-        b_ids.resize(nq * round_max);
-        b_dists.resize(nq * round_max);
-        rc = svsx_iterator_next(it, round_max, per_query.data(), b_ids.data(), b_dists.data(), counts.data());
-        if (rc != SVSX_SUCCESS) break;
-        rc = svsx_iterator_state(it, meta.data());
-        if (rc != SVSX_SUCCESS) break;
-        for (size_t i = 0; i < nq; ++i) {
-            if (!active[i]) continue;
-            const size_t c = counts[i];
-            checked[i] += c;
-            for (size_t j = 0; j < c && found[i] < k; ++j) {
-                const uint64_t id = b_ids[i * round_max + j];
-                const uint64_t local = id - ix->id_offset;
-                if (local < ix->n && ((id_bitmap[local >> 6] >> (local & 63)) & 1ull)) {
-                    ids64[i * k + found[i]] = id;
-                    dists[i * k + found[i]] = b_dists[i * round_max + j];
-                    ++found[i];
+    // One group of queries advancing together, one kernel launch per round.  Every buffer of a group is sized by the largest batch /
+    // capacity ANY of its queries asks for (iterator state table: m * (capacity + 1) * 8 bytes), and one low-hit-rate query can ask for
+    // batches of up to n: a query whose search buffer would outgrow `cap_limit` entries is therefore taken out of the group and handed
+    // back in `postponed`; the caller runs those in small groups of their own, from the start -- a query's batch schedule depends on
+    // nothing but its own hits, so the replay gives the answer the reference's per-query loop (vamana_index_impl.h:176-213) gives.
+    auto run_group = [&](const std::vector<size_t>& qidx, size_t cap_limit, std::vector<size_t>* postponed) -> int {
+        const size_t m = qidx.size();
+        std::vector<unsigned char> qbuf(m * q_row);
+        for (size_t i = 0; i < m; ++i) memcpy(&qbuf[i * q_row], static_cast<const unsigned char*>(queries) + qidx[i] * q_row, q_row);
+        svsx_batch_iterator* it = nullptr;
+        if (int rc = svsx_iterator_create(ix, qbuf.data(), q_dtype, m, ~size_t(0), &it)) return rc;
+        std::vector<size_t> found(m, 0), checked(m, 0), batch(m, std::max(k, sws)), grown(m, 0);
+        std::vector<char> active(m, 1);
+        std::vector<uint32_t> per_query(m), counts(m), meta(m * 8);
+        std::vector<uint64_t> b_ids;
+        std::vector<float> b_dists;
+        int rc = SVSX_SUCCESS;
+        size_t n_active = m;
+        while (n_active > 0 && rc == SVSX_SUCCESS) {
+            size_t round_max = 0;
+            for (size_t i = 0; i < m; ++i) {
+                if (!active[i]) { per_query[i] = 0xFFFFFFFFu; continue; }
+                batch[i] = predict(checked[i], found[i], k, batch[i], max_batch);
+                if (postponed != nullptr && grown[i] + batch[i] > cap_limit) { // would outgrow this group's memory: replayed on its own later
+                    for (size_t j = 0; j < k; ++j) {
+                        ids64[qidx[i] * k + j] = ~0ull;
+                        dists[qidx[i] * k + j] = __builtin_inff();
+                    }
+                    postponed->push_back(qidx[i]);
+                    active[i] = 0;
+                    --n_active;
+                    per_query[i] = 0xFFFFFFFFu;
+                    continue;
+                }
+                grown[i] += batch[i];
+                per_query[i] = static_cast<uint32_t>(std::min<size_t>(batch[i], 0xFFFFFFFEu));
+                round_max = std::max(round_max, batch[i]);
+            }
+            if (n_active == 0) break;
+            b_ids.resize(m * round_max);
+            b_dists.resize(m * round_max);
+            rc = svsx_iterator_next(it, round_max, per_query.data(), b_ids.data(), b_dists.data(), counts.data());
+            if (rc != SVSX_SUCCESS) break;
+            rc = svsx_iterator_state(it, meta.data());
+            if (rc != SVSX_SUCCESS) break;
+            for (size_t i = 0; i < m; ++i) {
+                if (!active[i]) continue;
+                const size_t o = qidx[i] * k;
+                const size_t c = counts[i];
+                checked[i] += c;
+                for (size_t j = 0; j < c && found[i] < k; ++j) {
+                    const uint64_t id = b_ids[i * round_max + j];
+                    const uint64_t local = id - ix->id_offset;
+                    if (local < ix->n && ((id_bitmap[local >> 6] >> (local & 63)) & 1ull)) {
+                        ids64[o + found[i]] = id;
+                        dists[o + found[i]] = b_dists[i * round_max + j];
+                        ++found[i];
+                    }
+                }
+                bool stop = false; // should_stop_filtered_search (svs_runtime_utils.h:424-434)
+                if (filter_stop > 0.0f && checked[i] != 0)
+                    stop = found[i] == 0 || static_cast<float>(found[i]) / checked[i] < filter_stop;
+                const bool done = meta[i * 8 + 4] == ix->n || (meta[i * 8 + 6] & 2u) != 0u;
+                if (stop) {
+                    for (size_t j = 0; j < k; ++j) {
+                        ids64[o + j] = ~0ull;
+                        dists[o + j] = __builtin_inff();
+                    }
+                    found[i] = 0;
+                }
+                if (stop || found[i] >= k || done) {
+                    active[i] = 0;
+                    --n_active;
                 }
             }
-            bool stop = false; // should_stop_filtered_search (svs_runtime_utils.h:424-434)
-            if (filter_stop > 0.0f && checked[i] != 0)
-                stop = found[i] == 0 || static_cast<float>(found[i]) / checked[i] < filter_stop;
-            const bool done = meta[i * 8 + 4] == ix->n || (meta[i * 8 + 6] & 2u) != 0u;
-            if (stop) {
-                for (size_t j = 0; j < k; ++j) {
-                    ids64[i * k + j] = ~0ull;
-                    dists[i * k + j] = __builtin_inff();
-                }
-                found[i] = 0;
-            }
-            if (stop || found[i] >= k || done) {
-                active[i] = 0;
-                --n_active;
-            }
         }
+        svsx_iterator_destroy(it);
+        return rc;
+    };
+    // memory budget: ~128 M buffer entries per group (state table 8 B + yielded list 4 B + batch outputs 12 B each, host and device)
+    constexpr size_t kBudgetEntries = size_t(128) << 20;
+    std::vector<size_t> all(nq), heavy;
+    for (size_t i = 0; i < nq; ++i) all[i] = i;
+    const size_t cap_limit = std::min<size_t>(ix->n, std::max<size_t>(kBudgetEntries / nq, 1024));
+    if (int rc = run_group(all, cap_limit, &heavy)) return rc;
+    const size_t per_group = std::max<size_t>(1, kBudgetEntries / std::max<size_t>(ix->n, 1));
+    for (size_t lo = 0; lo < heavy.size(); lo += per_group) {
+        std::vector<size_t> grp(heavy.begin() + lo, heavy.begin() + std::min(heavy.size(), lo + per_group));
+        if (int rc = run_group(grp, 0, nullptr)) return rc;
     }
-    svsx_iterator_destroy(it);
-    return rc;
+    return SVSX_SUCCESS;
 }

@@ -38,14 +38,32 @@ template <typename To, typename From> __device__ __forceinline__ To bit_cast_(Fr
 }
 
 // quad-local lane exchange through DPP (no LDS traffic): lane ^ 1 and lane ^ 2.
+// (every lane of the wave is active wherever these are used, and a quad permutation never reads out of bounds, so the `old` operand is
+// never seen: mov_dpp leaves it undefined, which spares the v_mov 0 that update_dpp(0, ...) costs per exchange)
 __device__ __forceinline__ float xor1f(float v) {
-    return bit_cast_<float>(__builtin_amdgcn_update_dpp(0, bit_cast_<int>(v), 0xB1, 0xf, 0xf, false));
+    return bit_cast_<float>(__builtin_amdgcn_mov_dpp(bit_cast_<int>(v), 0xB1, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float xor2f(float v) {
-    return bit_cast_<float>(__builtin_amdgcn_update_dpp(0, bit_cast_<int>(v), 0x4E, 0xf, 0xf, false));
+    return bit_cast_<float>(__builtin_amdgcn_mov_dpp(bit_cast_<int>(v), 0x4E, 0xf, 0xf, true));
 }
-__device__ __forceinline__ int xor1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
-__device__ __forceinline__ int xor2i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); }
+__device__ __forceinline__ int xor1i(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); }
+__device__ __forceinline__ int xor2i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true); }
+// v + (v of lane ^ 1 / ^ 2) as ONE instruction: the opaque barrier keeps the SLP vectorizer from pairing the adds into v_pk_add_f32
+// (which has no DPP form: 2 v_mov_dpp + 1 v_pk_add per pair), so each exchange folds into its add (v_add_f32_dpp; the compiler
+// inserts the DPP hazard wait states itself).  Same IEEE add, same bits.  The VALU issue port is what bounds the search kernel
+// (profiles/r03_notes.md): 8 instead of 22 instructions per 4-slot reduction.
+__device__ __forceinline__ float opaque_f(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int opaque_i(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float add_xor1f(float v) { return opaque_f(v + xor1f(v)); }
+__device__ __forceinline__ float add_xor2f(float v) { return opaque_f(v + xor2f(v)); }
+__device__ __forceinline__ int add_xor1i(int v) { return opaque_i(v + xor1i(v)); }
+__device__ __forceinline__ int add_xor2i(int v) { return opaque_i(v + xor2i(v)); }
 
 // ---------------------------------------------------------------------------------------------------------
 // element traits: E lane-slots per lane, G = 16/E lanes per candidate row, chunk = E elements per load
@@ -100,16 +118,16 @@ template <int METRIC> __device__ __forceinline__ void acc_step(float& s, float& 
 template <int E> __device__ __forceinline__ float reduce_slots(float (&v)[E]) {
     if constexpr (E == 4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] + xor2f(v[e]); // t[j] = v[j+8] + v[j]
+        for (int e = 0; e < 4; ++e) v[e] = add_xor2f(v[e]); // t[j] = v[j+8] + v[j]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] + xor1f(v[e]); // u[j] = t[j+4] + t[j]
+        for (int e = 0; e < 4; ++e) v[e] = add_xor1f(v[e]); // u[j] = t[j+4] + t[j]
         const float w0 = v[0] + v[2];
         const float w1 = v[1] + v[3];
         return w0 + w1;
     } else {
         static_assert(E == 8, "E must be 4 or 8");
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] + xor1f(v[e]); // t[j] = v[j+8] + v[j]
+        for (int e = 0; e < 8; ++e) v[e] = add_xor1f(v[e]); // t[j] = v[j+8] + v[j]
         float u[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) u[j] = v[j + 4] + v[j];     // u[j] = t[j+4] + t[j]
@@ -481,12 +499,8 @@ __device__ __forceinline__ void float_row_distance_bc(
         // s0 = (s0 + s1) + (s2 + s3) per lane-slot; afterwards every lane of the group holds the combined vector
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float a = s[e] + xor1f(s[e]);
-            s[e] = a + xor2f(a);
-            if constexpr (METRIC == M_COS) {
-                const float b = n[e] + xor1f(n[e]);
-                n[e] = b + xor2f(b);
-            }
+            s[e] = add_xor2f(add_xor1f(s[e]));
+            if constexpr (METRIC == M_COS) n[e] = add_xor2f(add_xor1f(n[e]));
         }
     }
     for (int b = 4 * n64; b < nb; ++b) {
@@ -565,10 +579,8 @@ __device__ __forceinline__ void int_row_sums(
         const uint4 x = *reinterpret_cast<const uint4*>(row + 16 * m);
         dots(x, *reinterpret_cast<const uint4*>(qw + 4 * m));
     }
-    sab += xor1i(sab);
-    sab += xor2i(sab);
-    sbb += xor1i(sbb);
-    sbb += xor2i(sbb);
+    sab = add_xor2i(add_xor1i(sab));
+    sbb = add_xor2i(add_xor1i(sbb));
     ab = sab;
     bb = sbb;
 }
@@ -849,21 +861,20 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
 // are modelled as +-inf sentinels; comparisons must be a strict weak order).  Returns false -- with LDS untouched -- if a candidate duplicates a buffer entry (same id at equal
 // distance, search_buffer.h:377-389); the caller then takes the sequential path for this pass.
 template <bool GREATER, int EPL>
-__device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted) {
+__device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted, float& worst_out) {
     // EPL buffer entries per lane (capacity <= 64 EPL).  Written to stay off the scalar unit (one SALU issue slot per CU per
     // cycle is the scarce resource of this kernel): no boolean mask algebra -- validity is folded into sentinel values, counters
     // advance with carry-in adds, the tie rule of the candidate ranks is one 64-bit compare of (order key, lane).
     constexpr float kPast = GREATER ? -__builtin_inff() : __builtin_inff(); // no candidate compares better than an empty slot
     uint2 e[EPL];
     float dv[EPL];
-    uint32_t idv[EPL], c[EPL];
+    uint32_t c[EPL];
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
         const uint32_t i = lane + 64u * t;
         e[t] = make_uint2(__float_as_uint(kPast), kInvalidId);
         if (i < b.size) e[t] = b.e[i];
         dv[t] = __uint_as_float(e[t].x);
-        idv[t] = e[t].y & kIdMask; // kInvalidId & kIdMask is no valid id either (ids < 2^31 - 1)
         c[t] = 0u;
     }
     // total-order key of my own distance (+0.0 first: -0 and +0 compare equal as floats), ascending = better first
@@ -871,14 +882,14 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     uint32_t key = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
     if (GREATER) key = ~key;
     const unsigned long long mykey = (static_cast<unsigned long long>(key) << 32) | lane;
-    uint32_t rank = 0, oldle = 0, minpos = 0xFFFFFFFFu, dupacc = 0xFFFFFFFFu;
+    uint32_t rank = 0, minpos = 0xFFFFFFFFu;
+    int oldle = 0;
     unsigned long long m = __ballot(cand);
     const uint32_t ncand = static_cast<uint32_t>(__popcll(m));
-    while (m != 0ull) {
+    while (m != 0ull) { // 9 vector instructions per candidate (the VALU issue port bounds this kernel)
         const int bl = __builtin_ctzll(m);
         m &= ~(1ull << bl);
         const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
-        const uint32_t idj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id), bl));
         const uint32_t kj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), bl));
         uint32_t after = 0; // old entries (and empty slots) candidate j goes before: a suffix of the sorted buffer
 #pragma unroll
@@ -886,29 +897,168 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
             const bool lt = cmpf<GREATER>(dj, dv[t]);
             c[t] += lt ? 1u : 0u;
             after += static_cast<uint32_t>(__popcll(__ballot(lt)));
-            const uint32_t x = idv[t] ^ idj;
-            dupacc = x < dupacc ? x : dupacc;
         }
         const uint32_t le = 64u * EPL - after; // old entries that stay before j (empty slots always count as "after")
         const unsigned long long kjl = (static_cast<unsigned long long>(kj) << 32) | static_cast<uint32_t>(bl);
         rank += kjl < mykey ? 1u : 0u; // new entries before mine: better, or equal and earlier in adjacency order
-        oldle = lane == static_cast<uint32_t>(bl) ? le : oldle;
+        // lane bl keeps its own count: one v_writelane instead of compare + select.  (inline asm: the compiler's hazard recogniser does not
+        // look inside, so the wait states a lane select / source written by the scalar unit needs are spelled out)
+        // (the lane select goes through m0: one constant-bus operand per instruction on gfx9)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(oldle) : "s"(le), "s"(bl) : "m0");
         minpos = le < minpos ? le : minpos;
     }
-    if (__ballot(dupacc == 0u) != 0ull) return false;
+    // duplicates (search_buffer.h:377-389: same id at equal distance is not inserted): the same id gives the same distance bits, so a
+    // duplicate needs an old entry of EQUAL distance, and the last old entry that stays before candidate j -- index le_j - 1 -- is one if
+    // any is.  One lane-parallel LDS read per pass instead of an id compare per candidate and entry; any tie sends the pass down the
+    // sequential path, which does the exact id walk.
+    {
+        bool tie = false;
+        if (cand && oldle > 0) {
+            const float prev = __uint_as_float(b.e[oldle - 1].x);
+            tie = prev == dist;
+        }
+        if (__ballot(tie) != 0ull) return false;
+    }
     buf_order(b);
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
         const uint32_t i = lane + 64u * t, p = i + c[t];
         if (i < b.size && c[t] != 0u && p < b.capacity) b.e[p] = e[t];
     }
-    const uint32_t pn = oldle + rank;
+    const uint32_t pn = static_cast<uint32_t>(oldle) + rank;
     const bool placed = cand && pn < b.capacity;
     if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
     buf_order(b);
     n_inserted += static_cast<uint32_t>(__popcll(__ballot(placed)));
+    const uint32_t old_size = b.size;
     b.size = (b.size + ncand < b.capacity) ? b.size + ncand : b.capacity;
     b.best_unvisited = minpos < b.best_unvisited ? minpos : b.best_unvisited;
+    if (b.size == b.capacity) {
+        // the entry that ends at position capacity - 1 is in some lane's registers: the caller's `worst` without an LDS round trip
+        float wv = 0.0f;
+        bool hit = false;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const uint32_t i = lane + 64u * t;
+            if (i < old_size && i + c[t] + 1u == b.capacity) {
+                wv = dv[t];
+                hit = true;
+            }
+        }
+        if (placed && pn + 1u == b.capacity) {
+            wv = dist;
+            hit = true;
+        }
+        const unsigned long long hm = __ballot(hit);
+        if (hm != 0ull) worst_out = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), __builtin_ctzll(hm)));
+        else worst_out = __uint_as_float(b.e[b.capacity - 1].x); // not reached: exactly one entry ends there
+    }
+    return true;
+}
+
+// The same merge without a scalar loop over the candidates (round 3).  The loop form above walks the candidates one by one through the
+// scalar unit (s_ff1 -> v_readlane -> v_cmp -> s_bcnt -> ...): ~150 cycles of dependent VALU <-> SALU hand-overs per candidate, ~2 000 cycles
+// per expansion in the phase profile (profiles/r03_notes.md) -- the longest link of the per-expansion chain.  Here everything is lane-parallel:
+//   1. the m candidates of the pass are compacted into LDS scratch in lane (= adjacency) order: {distance bits, order key}
+//   2. every lane reads them back (broadcast reads, m <= 64 / G) and counts, for each of its EPL old entries, the candidates strictly
+//      better (c), the bit-equal distances (tie -> sequential path, see below) and -- for its own candidate -- the candidates ranked before it
+//   3. c is non-decreasing along the sorted buffer, so "old entries that stay before the r-th best candidate" le[r] = #{i : c_i <= r} is
+//      the index of the first old entry with c_i > r: the lanes whose c steps up write it to LDS (c of the predecessor through one DPP shift)
+//   4. candidate lanes read le[rank]; old entries move to i + c_i, new ones go to le[rank] + rank
+// `scratch`: 48 words of LDS (16 x {dist, key} + 16 x le).  Same preconditions and the same result as wave_merge_insert; a candidate whose
+// distance bits equal an old entry's sends the pass down the sequential path (a duplicate id has identical distance bits, so this is a
+// superset of search_buffer.h:377-389's "same id at equal distance").
+template <bool GREATER, int EPL>
+__device__ __forceinline__ bool wave_merge_insert2(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted, float& worst_out,
+                                                   uint32_t* scratch) {
+    constexpr float kPast = GREATER ? -__builtin_inff() : __builtin_inff(); // no candidate compares better than an empty slot
+    uint2* cs = reinterpret_cast<uint2*>(scratch);
+    uint32_t* le_s = scratch + 32;
+    const unsigned long long cm = __ballot(cand);
+    const uint32_t m = static_cast<uint32_t>(__popcll(cm));
+    if (m > 16u) return false; // more candidates than scratch slots (cannot happen: 64 / G <= 16 rows per pass)
+    const uint32_t slot = static_cast<uint32_t>(__popcll(cm & ((1ull << lane) - 1ull)));
+    // total-order key of my own distance (+0.0 first: -0 and +0 compare equal as floats), ascending = better first
+    const uint32_t fb = __float_as_uint(dist + 0.0f);
+    uint32_t key = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+    if (GREATER) key = ~key;
+    if (cand) cs[slot] = make_uint2(__float_as_uint(dist), key);
+    if (lane < 16u) le_s[lane] = b.size; // default: every old entry stays before the candidate
+    uint2 e[EPL];
+    float dv[EPL];
+    uint32_t c[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const uint32_t i = lane + 64u * t;
+        e[t] = make_uint2(__float_as_uint(kPast), kInvalidId);
+        if (i < b.size) e[t] = b.e[i];
+        dv[t] = __uint_as_float(e[t].x);
+        c[t] = 0u;
+    }
+    lds_order();
+    const unsigned long long mykey = (static_cast<unsigned long long>(key) << 32) | slot;
+    uint32_t rank = 0, tieacc = 0xFFFFFFFFu;
+    for (uint32_t j = 0; j < m; ++j) { // uniform trip count; the reads are broadcasts
+        const uint2 cj = cs[j];
+        const float dj = __uint_as_float(cj.x);
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            c[t] += cmpf<GREATER>(dj, dv[t]) ? 1u : 0u;
+            const uint32_t x = cj.x ^ e[t].x;
+            tieacc = x < tieacc ? x : tieacc;
+        }
+        const unsigned long long kjl = (static_cast<unsigned long long>(cj.y) << 32) | j;
+        rank += kjl < mykey ? 1u : 0u; // candidates before mine: better, or equal and earlier in adjacency order
+    }
+    if (__ballot(tieacc == 0u) != 0ull) return false;
+    // le[r] for r in [c_{i-1}, c_i) is i: written by the lane that owns entry i (usually one r, at most m)
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int carry = t == 0 ? 0 : __builtin_amdgcn_readlane(static_cast<int>(c[t - 1]), 63); // entry 64 t - 1 lives in lane 63
+        uint32_t r = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(carry, static_cast<int>(c[t]), 0x138, 0xf, 0xf, false)); // wave_shr:1
+        const uint32_t i = lane + 64u * t;
+        while (__ballot(r < c[t]) != 0ull) {
+            if (r < c[t]) le_s[r] = i;
+            ++r;
+        }
+    }
+    lds_order();
+    uint32_t pn = 0xFFFFFFFFu;
+    if (cand) pn = le_s[rank] + rank;
+    const uint32_t minpos = m != 0u ? le_s[0] : 0xFFFFFFFFu; // the best candidate (rank 0) lands at le[0]
+    buf_order(b);
+    const uint32_t old_size = b.size;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const uint32_t i = lane + 64u * t, p = i + c[t];
+        if (i < old_size && c[t] != 0u && p < b.capacity) b.e[p] = e[t];
+    }
+    const bool placed = cand && pn < b.capacity;
+    if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
+    buf_order(b);
+    n_inserted += static_cast<uint32_t>(__popcll(__ballot(placed)));
+    b.size = (old_size + m < b.capacity) ? old_size + m : b.capacity;
+    b.best_unvisited = minpos < b.best_unvisited ? minpos : b.best_unvisited;
+    if (b.size == b.capacity) {
+        // the entry that ends at position capacity - 1 is in some lane's registers: the caller's `worst` without an LDS round trip
+        float wv = 0.0f;
+        bool hit = false;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const uint32_t i = lane + 64u * t;
+            if (i < old_size && i + c[t] + 1u == b.capacity) {
+                wv = dv[t];
+                hit = true;
+            }
+        }
+        if (placed && pn + 1u == b.capacity) {
+            wv = dist;
+            hit = true;
+        }
+        const unsigned long long hm = __ballot(hit);
+        if (hm != 0ull) worst_out = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), __builtin_ctzll(hm)));
+        else worst_out = __uint_as_float(b.e[b.capacity - 1].x); // not reached: exactly one entry ends there
+    }
     return true;
 }
 

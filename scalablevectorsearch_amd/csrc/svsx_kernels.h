@@ -39,7 +39,7 @@ struct SearchArgs {
     uint32_t history_cap;
     // optional 128-B bound-code rows (f32 L2, d = 96 or 128): rigorous lower-bound rejection before a row is fetched
     const unsigned char* codes;
-    float code_scale, code_bias;
+    float code_scale, code_bias, code_eq_abs; // code_eq_abs: absolute rounding term of the query's coding residual (svsx_api.hip)
     // graph-inline records (svsx_codes.hip; CODES == 2): node rows [ids | plane 0 | plane 1] per chunk of <= 64 slots
     const unsigned char* fat;
     size_t fat_stride;        // bytes per node
@@ -55,6 +55,11 @@ struct SearchArgs {
     float pca_ref_extra;      // scalar-quantized inner product: 2 |bias| sqrt(d), enters the slack for the reference's own rounding
     // cancellation (index/vamana/index.h:541-545, greedy_search.h:155): device word polled once per expansion; non-zero = stop
     const int* cancel;
+    // host-pointer calls (svsx_search): the queries are still on their way while the kernel runs; q_ready[qi >> q_ready_shift] becomes
+    // q_ready_epoch (a per-call value: the words are never reset) once the chunk of query qi has arrived
+    const uint32_t* q_ready;
+    uint32_t q_ready_shift;
+    uint32_t q_ready_epoch;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
     uint32_t general;
     // BatchIterator (index/vamana/iterator.h): per-query state in HBM.  meta = 8 u32 per query:

@@ -32,28 +32,35 @@
 #define SVSX_CODE_BATCH 2
 #endif
 
-// SVSX_EARLY_BLOCK (default 1; -DSVSX_EARLY_BLOCK=0 for A/B builds): see "early block" in search_kernel
+// SVSX_EARLY_BLOCK (default 0; -DSVSX_EARLY_BLOCK=1 for A/B builds): see "Next block, requested early" in search_kernel
 #ifndef SVSX_EARLY_BLOCK
-#define SVSX_EARLY_BLOCK 1
+#define SVSX_EARLY_BLOCK 0
+#endif
+// SVSX_MERGE_V2 (default 0): 1 = lane-parallel merge insert (wave_merge_insert2) for A/B builds.  Measured (profiles/r03_notes.md): its LDS
+// round trips cost what the scalar loop's VALU <-> SALU hand-overs cost (config 2: 1.084 vs 1.070 ms), so the loop form stays.
+#ifndef SVSX_MERGE_V2
+#define SVSX_MERGE_V2 0
 #endif
 
 namespace svsx {
 
-// Early block (see search_kernel) is compiled into the kernel families below, each with the occupancy floor it had without it: the extra
-// scalar state otherwise tips the register allocator of some instantiations over a bracket (123 -> 175 VGPRs on the d = 768 int8 kernel),
-// and a wave lost costs more than an overlapped round trip gains.  0 = family without early block, no floor.
+// Occupancy floors (amdgpu_waves_per_eu) of the inline-record kernel families: the register allocator otherwise settles some instantiations
+// just over a VGPR bracket (123 -> 175 VGPRs on the d = 768 int8 kernel once the early-block state was added), and a resident wave lost
+// costs more than the few registers buy.  Chosen per family so that no instantiation spills (tools/kernel_regs.py); 0 = no floor.  The
+// same families can carry the early block (SVSX_EARLY_BLOCK, off by default -- measured: profiles/r03_notes.md).
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BIG> constexpr int early_block_floor() {
-    if (SVSX_EARLY_BLOCK == 0 || GENERAL || CODES < 2) return 0;
+    if (GENERAL || CODES < 2) return 0;
     if (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         // configs 2, 3, 5 (static 96 / 128, 32-byte records): <= 80 VGPRs -- the scalar registers allow 6 waves; float16 rows of 96 need 88
-        if ((DS == 96 || DS == 128) && CODES == 2 && BIG == 0 && METRIC != M_COS) return (DT == DT_F16 && DS == 96) ? 5 : 6;
-        // any dimension, 32- / 64-byte records: <= 96 (float16 inner product: <= 80)
-        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES <= 3) return (DT == DT_F16 && METRIC == M_IP) ? 6 : 5;
+        // (float32 rows of 128 keep 8 x 16 bytes of a row in flight per lane: 6 waves would spill 92 bytes)
+        if ((DS == 96 || DS == 128) && CODES == 2 && BIG == 0 && METRIC != M_COS) return (DT == DT_F32 && DS == 128) ? 4 : (DT == DT_F16 && DS == 96) ? 5 : 6;
+        // any dimension, 32- / 64-byte records: <= 96
+        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES <= 3) return 5;
     }
     // windows 513 .. 1024 with 128-byte records (config 4 at recall >= 0.9): 143 VGPRs instead of 181, no scratch -> 3 waves per SIMD instead of 2
     if (DS == 768 && BIG == 2 && CODES == 4 && (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS)) return 3;
     if (DS == 768 && BIG <= 1) { // config 4 and its inner-product sibling
-        if (QMODE == QM_SQ_IP) return (BIG == 1 && CODES == 4) ? 4 : 5;
+        if (QMODE == QM_SQ_IP) return BIG == 1 ? 4 : 5;
         if (QMODE == QM_SQ_COS) return 4;
     }
     return 0;
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
     // FAT: the query's own record codes; 32-byte records keep them in SGPRs afterwards, so the 128 bytes alias the compaction scratch
     [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + (CODES >= 3 ? 256u : 0u));
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + ((a.filter_entries || CODES != 0) ? 256u : 0u) + (CODES >= 3 ? 128u : 0u)); // GENERAL only
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + 256u + (CODES >= 3 ? 128u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -141,6 +148,13 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     }
     if constexpr (!GENERAL) {
         if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return; // extensions.h:575-578
+        if (a.q_ready != nullptr) { // queries still arriving from the host (svsx_search): wait for this query's chunk
+            const uint32_t* flag = a.q_ready + (qi >> a.q_ready_shift);
+            // relaxed, system scope: the word and the queries live in fine-grained host memory, which the GPU never caches -- an ACQUIRE here
+            // would invalidate the L2 under every running wave (measured: +0.7 ms per 10 000-query launch)
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.q_ready_epoch) __builtin_amdgcn_s_sleep(16);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST); // the query loads stay behind the poll (issue order = program order within a wave)
+        }
     }
     const uint32_t fmask = a.filter_entries - 1u;
     const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));
@@ -160,7 +174,8 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     //     sqrt(distance_L2) >= ||q_C - x_C|| >= ||qhat - xhat|| - eq - ex = scale * sqrt(sum (cq - cx)^2) - eq - ex,
     // and the integer sum is exact (v_dot4).  A candidate whose bound already exceeds the worst buffer entry would be
     // skipped by can_skip (search_buffer.h:338-340) whatever its exact distance -> its 384-B row is never fetched.
-    // Margins (0.99998 on the code distance, 1.001 on eq, 1.0001 on the threshold) cover every float rounding involved.
+    // Margins: 0.99998 on the code distance, 1.001 on eq plus the absolute term code_eq_abs (round 3: the residual v - fl(bias + fl(scale c))
+    // rounds at the magnitude of the OFFSET, not of eq), 1.0001 on the threshold; tests/test_bound_math.py restates them on the CPU.
     uint32_t qc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     int code_qq = 0;
     float code_eq = 0.0f;
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     // expansion is already decided, and the 18 lines of its adjacency block are requested now, while this expansion's rows are in flight --
     // the two dependent memory round trips of an expansion overlap, at no extra traffic (the block is always used).  A hint only: the block
     // is loaded again (from L2) by the next iteration, so results cannot depend on it.
-    constexpr bool EARLY = early_block_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() > 0;
+    constexpr bool EARLY = SVSX_EARLY_BLOCK != 0 && early_block_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() > 0;
     [[maybe_unused]] uint32_t early_sink = 0u, early_sink2 = 0u;
     // static-dimension kernels with 32-byte records have the registers to KEEP the early block (id + 2 planes per lane): the next iteration
     // then starts on data that is already there instead of an L2 round trip
@@ -182,10 +197,26 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
 #pragma unroll
         for (int p = 0; p < RW; ++p) kept_rec[p] = make_uint4(0u, 0u, 0u, 0u);
     }
+#if defined(SVSX_DIAG) && SVSX_DIAG == 2
+    // phase profile of an expansion (tools/diag_phases.py): shader-clock stamps at 0 loop top, 1 node known, 2 adjacency block arrived, 3 bound +
+    // filter + compaction done, 4 distances of a pass known (row wait + arithmetic), 5 inserts done; stats words 1..5 = cycles between them
+    uint64_t ph_last = 0;
+    uint32_t ph_acc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#define SVSX_PHASE_USE(v) asm volatile("" ::"s"(v))
+#define SVSX_PHASE_STAMP(i)                                          \
+    do {                                                             \
+        const uint64_t now_ = __builtin_readcyclecounter();          \
+        ph_acc[i] += static_cast<uint32_t>(now_ - ph_last);          \
+        ph_last = now_;                                              \
+    } while (0)
+#else
+#define SVSX_PHASE_USE(v)
+#define SVSX_PHASE_STAMP(i)
+#endif
 #ifdef SVSX_DIAG
     // diagnostic builds only (tools/build_variant.sh diag -DSVSX_DIAG=1; tools/timeline.py): stats words 3 / 4 / 5 = expansions whose next
     // block was requested early, wall_clock64 (100 MHz) at wave start / end
-    uint32_t diag_early = 0u;
+    uint32_t diag_early = 0u, diag_have = 0u;
     const uint32_t diag_t0 = static_cast<uint32_t>(wall_clock64());
 #endif
     if constexpr (CODES == 1) {
@@ -218,7 +249,9 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
         qq += xor1i(qq);
         qq += xor2i(qq);
         code_qq = __builtin_amdgcn_readfirstlane(qq); // wave-uniform values live in SGPRs
-        code_eq = __builtin_sqrtf(e2) * 1.001f + 1.0e-7f;
+        // relative margin for the float32 sum + the explicit absolute term for the rounding of v - fl(bias + fl(scale c)) per coordinate
+        // (<= 2^-23 (|v| + |bias| + 255 scale); a.code_eq_abs = sqrt(DC) 2.4e-7 (|bias| + 255 scale) 1.01, svsx_index_build_bound_codes)
+        code_eq = __builtin_sqrtf(e2) * 1.001f + 1.0e-7f + a.code_eq_abs;
         if (!(code_eq < 3.0e38f)) code_eq = __builtin_inff(); // non-finite query: the bound never fires
         code_eq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, code_eq)));
     }
@@ -424,6 +457,40 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     bool full = buf.size == buf.capacity;
     float worst = (full && buf.capacity > 0u) ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
 
+    // Next block, requested early (inline records, single-chunk rows).  Once the distances of an expansion's LAST pass are known, the node
+    // expanded next is decided -- the best new candidate if it is strictly better than the buffer's next unvisited entry (equal distances
+    // insert behind, search_buffer.h:353-389), else that entry -- although the buffer has not been updated yet.  Its adjacency block is
+    // requested at that moment, so the HBM round trip runs under the merge insert and the `next()` scan instead of after them.  A hint
+    // only: the loop top checks `kept_node == node` (a duplicate that the insert drops can make the prediction wrong) and loads the block
+    // itself otherwise, so results cannot depend on it.  Kernels without the registers to keep the block touch its lines into L2 instead.
+    [[maybe_unused]] auto request_block = [&](uint32_t next_node) {
+#ifdef SVSX_DIAG
+        ++diag_early;
+#endif
+        if constexpr (EARLY_KEEP) { // gstride <= 64 here: one chunk, laid out [ids | plane 0 | plane 1]
+            const uint32_t* kids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(next_node) * a.fat_stride);
+            const uint4* kplanes = reinterpret_cast<const uint4*>(kids + a.gstride);
+            kept_nid = kInvalidId;
+#pragma unroll
+            for (int p = 0; p < RW; ++p) kept_rec[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < a.gstride) {
+                kept_nid = kids[lane];
+#pragma unroll
+                for (int p = 0; p < RW; ++p) kept_rec[p] = kplanes[static_cast<uint32_t>(p) * a.gstride + lane];
+            }
+            kept_node = next_node;
+        } else if constexpr (EARLY) {
+            const unsigned char* nb = a.fat + static_cast<size_t>(next_node) * a.fat_stride;
+            // one line per lane: a block of <= 64 slots is at most 64 * (4 + 16 RW) bytes = 18 / 34 / 66 lines
+            const uint32_t off = lane * 128u;
+            // plain assignments: any arithmetic on the loaded word here would make the compiler wait for it on the spot
+            if (off < a.fat_stride) early_sink = *reinterpret_cast<const uint32_t*>(nb + off);
+            if constexpr (RW == 8) {
+                if (off + 8192u < a.fat_stride) early_sink2 = *reinterpret_cast<const uint32_t*>(nb + off + 8192u);
+            }
+        }
+    };
+
     // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
     int cancel_seen = 0;
     while (!wave_done(buf)) {
@@ -431,8 +498,11 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             if (cancel_seen != 0) break;
             cancel_seen = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        SVSX_PHASE_STAMP(0);
         float node_dist;
         const uint32_t node = wave_next(buf, lane, node_dist);
+        SVSX_PHASE_USE(node);
+        SVSX_PHASE_STAMP(1);
         if (a.history_ids != nullptr && lane == 0 && n_exp < a.history_cap) {
             a.history_ids[static_cast<size_t>(qi) * a.history_cap + n_exp] = node;
             if (a.history_dists != nullptr) a.history_dists[static_cast<size_t>(qi) * a.history_cap + n_exp] = node_dist;
@@ -454,6 +524,9 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 bool have = false;
                 if constexpr (EARLY_KEEP) {
                     have = kept_node == node; // the same read-only bytes, requested one expansion ago
+#ifdef SVSX_DIAG
+                    diag_have += have ? 1u : 0u;
+#endif
                     if (have) {
                         nid = kept_nid;
 #pragma unroll
@@ -479,9 +552,10 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 }
             }
             const uint32_t deg_here = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
+            SVSX_PHASE_USE(deg_here);
+            SVSX_PHASE_STAMP(2);
             n_slots += deg_here;
             uint32_t cnt = deg_here;
-            [[maybe_unused]] bool early_ok = false;
             if constexpr (FAT) {
                 bool keep = nid != kInvalidId;
                 // visited filter (greedy_search.h:191-193), here holding only the ids whose rows were really fetched: a candidate the
@@ -495,7 +569,6 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                     // bound of every candidate of this chunk, lane-parallel (svsx_codes.hip has the geometry).  `worst` can only
                     // improve while this expansion's survivors are inserted, so a bound taken against it stays valid.
                     bool rej;
-                    [[maybe_unused]] bool far = false;
                     constexpr int NW = RW * 4;  // words per record; the last one holds float16 fields
                     auto recw = [&](int w) -> uint32_t {
                         const uint4& r = rec[w >> 2];
@@ -535,12 +608,6 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                         const float bb = (t > 0.0f ? t : 0.0f) * 0.99999f;
                         const float rhs = wp - bb * bb + e * (r2 + e) * 1.00001f;
                         rej = fi * fat_s2m > rhs; // false for NaN / inf thresholds
-                        if constexpr (EARLY) {
-                            // the same test with nx_d in place of worst: rhs(nx_d) = rhs - (wp - wn) - e (r2 - rn) 1.00001, the two differences uniform
-                            const float wn = nx_d * 1.0001f;
-                            const float rn = 2.0f * __builtin_amdgcn_sqrtf(wn) * 1.00001f;
-                            far = fi * fat_s2m > rhs - (wp - wn) - e * ((r2 - rn) * 1.00001f); // distance > nx_d
-                        }
                     } else {
                         // q . z <= s^2 I + ||uhat|| ex + eq (ny + ex) + tq tx,  I = sum cq cx (exact);  all record fields are upper bounds
                         int dot = 0;
@@ -562,13 +629,11 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                             ub += static_cast<float>(d + 2) * 6.1e-8f * fat_nq * (ny + ex + tx + a.pca_ref_extra);
                         }
                         rej = ub < worst; // false whenever anything is NaN / inf
-                        if constexpr (EARLY) far = ub < nx_d; // similarity < the next entry's proven
                     }
                     const uint32_t nrej = __popcll(__ballot(keep && rej));
                     n_code_rej += nrej;
                     n_eval += nrej;
                     keep = keep && !rej;
-                    if constexpr (EARLY) early_ok = nx_id != kInvalidId && __ballot(keep && !far) == 0ull;
                 }
                 if (use_filter && keep) filt[fh] = static_cast<uint16_t>(ftag);
                 const unsigned long long km = __ballot(keep);
@@ -579,32 +644,9 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                 lds_order();
                 nid = lane < cnt ? compact[lane] : kInvalidId;
                 lds_order();
-#ifdef SVSX_DIAG
-                if constexpr (EARLY) diag_early += early_ok ? 1u : 0u;
-#endif
                 if constexpr (EARLY) {
-                    if (early_ok && EARLY_KEEP) { // gstride <= 64 here: one chunk, laid out [ids | plane 0 | plane 1]
-                        const uint32_t* kids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(nx_id) * a.fat_stride);
-                        const uint4* kplanes = reinterpret_cast<const uint4*>(kids + a.gstride);
-                        kept_nid = kInvalidId;
-#pragma unroll
-                        for (int p = 0; p < RW; ++p) kept_rec[p] = make_uint4(0u, 0u, 0u, 0u);
-                        if (lane < a.gstride) {
-                            kept_nid = kids[lane];
-#pragma unroll
-                            for (int p = 0; p < RW; ++p) kept_rec[p] = kplanes[static_cast<uint32_t>(p) * a.gstride + lane];
-                        }
-                        kept_node = nx_id;
-                    } else if (early_ok) { // the records are dead by now: the request costs one address register
-                        const unsigned char* nb = a.fat + static_cast<size_t>(nx_id) * a.fat_stride;
-                        // one line per lane: a block of <= 64 slots is at most 64 * (4 + 16 RW) bytes = 18 / 34 / 66 lines
-                        const uint32_t off = lane * 128u;
-                        // plain assignments: any arithmetic on the loaded word here would make the compiler wait for it on the spot
-                        if (off < a.fat_stride) early_sink = *reinterpret_cast<const uint32_t*>(nb + off);
-                        if constexpr (RW == 8) {
-                            if (off + 8192u < a.fat_stride) early_sink2 = *reinterpret_cast<const uint32_t*>(nb + off + 8192u);
-                        }
-                    }
+                    // nothing went on to the exact path: the buffer stays as it is and the next expansion is its next unvisited entry
+                    if (cnt == 0u && nx_id != kInvalidId) request_block(nx_id);
                 }
             } else if (a.filter_entries != 0u && !nan_seen) { // with a NaN in the buffer a repeated insert is no longer a no-op: filter off
                 // emplace_visited (greedy_search.h:191-193): drop ids already evaluated, keep adjacency order
@@ -699,36 +741,87 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                     cnt = nsurv;
                 }
             }
+            SVSX_PHASE_USE(cnt);
+            SVSX_PHASE_STAMP(3);
             for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
                 const uint32_t ci = p0 + grp;
                 const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
                 const bool act = ci < cnt;
+                if constexpr (EARLY) {
+                    // an earlier pass of this expansion changed the buffer: the next unvisited entry is read again (before the row loads, the
+                    // LDS round trip hides behind them)
+                    if (p0 > 0u && p0 + RPP >= cnt) {
+                        nx_id = kInvalidId;
+                        const uint32_t upper = buf.size < buf.window ? buf.size : buf.window;
+                        if (buf.best_unvisited < upper && a.gstride <= 64u && !nan_seen) {
+                            const uint2 en = buf.e[buf.best_unvisited];
+                            nx_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(en.y & kIdMask)));
+                            nx_d = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(en.x))));
+                        }
+                    }
+                }
                 const float dist = group_distance(cid, act, full ? worst * 1.00004f : __builtin_inff());
                 const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
                 const bool cand = act && sub == 0 && !skip;
                 unsigned long long m = __ballot(cand);
+                if constexpr (EARLY) {
+                    if (p0 + RPP >= cnt && a.gstride <= 64u && !nan_seen) { // last pass: every distance of this expansion is known
+                        uint32_t pred = nx_id;
+                        // candidates strictly better than the next unvisited entry (all of them when there is none): the best one, the earliest in
+                        // adjacency order among equals -- the order the inserts give them
+                        unsigned long long bm = nx_id != kInvalidId ? __ballot(cand && cmpf<GREATER>(dist, nx_d)) : m;
+                        if (bm != 0ull) {
+                            int bl = __builtin_ctzll(bm);
+                            bm &= bm - 1ull;
+                            float bd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
+                            while (bm != 0ull) {
+                                const int l2 = __builtin_ctzll(bm);
+                                bm &= bm - 1ull;
+                                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), l2));
+                                if (cmpf<GREATER>(dj, bd)) {
+                                    bd = dj;
+                                    bl = l2;
+                                }
+                            }
+                            pred = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
+                        }
+                        if (pred != kInvalidId) request_block(pred);
+                    }
+                }
+                SVSX_PHASE_USE(m);
+                SVSX_PHASE_STAMP(4);
                 n_eval += (cnt - p0) < static_cast<uint32_t>(RPP) ? (cnt - p0) : static_cast<uint32_t>(RPP);
                 if constexpr (!GENERAL) {
                     // all accepted candidates of the pass in ONE merge (wave_merge_insert); NaN distances and duplicates of buffer
                     // entries (possible when the visited filter is off or evicted) take the one-by-one path below
                     if (m != 0ull && buf.capacity <= (BIG == 2 ? 1024u : BIG == 1 ? 512u : 128u)) {
-                        nan_seen = nan_seen || (__ballot(cand && dist != dist) != 0ull);
+                        // one test for NaN and +-inf candidates: either sends the pass down the sequential path, which keeps `nan_seen`
                         const bool finite = __ballot(cand && !(__builtin_fabsf(dist) < __builtin_inff())) == 0ull;
                         bool merged = false;
                         if (!nan_seen && finite) {
+#if SVSX_MERGE_V2
                             if constexpr (BIG == 2) {
-                                merged = wave_merge_insert<GREATER, 16>(buf, cand, dist, cid, lane, n_ins);
+                                merged = wave_merge_insert2<GREATER, 16>(buf, cand, dist, cid, lane, n_ins, worst, compact);
                             } else if constexpr (BIG == 1) {
-                                if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, cand, dist, cid, lane, n_ins);
-                                else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins);
+                                if (buf.capacity <= 256u) merged = wave_merge_insert2<GREATER, 4>(buf, cand, dist, cid, lane, n_ins, worst, compact);
+                                else merged = wave_merge_insert2<GREATER, 8>(buf, cand, dist, cid, lane, n_ins, worst, compact);
                             } else {
-                                merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins);
+                                merged = wave_merge_insert2<GREATER, 2>(buf, cand, dist, cid, lane, n_ins, worst, compact);
                             }
+#else
+                            if constexpr (BIG == 2) {
+                                merged = wave_merge_insert<GREATER, 16>(buf, cand, dist, cid, lane, n_ins, worst);
+                            } else if constexpr (BIG == 1) {
+                                if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, cand, dist, cid, lane, n_ins, worst);
+                                else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins, worst);
+                            } else {
+                                merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins, worst);
+                            }
+#endif
                         }
                         if (merged) {
                             m = 0ull;
-                            full = buf.size == buf.capacity;
-                            if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
+                            full = buf.size == buf.capacity; // `worst` came out of the merge (the entry that ended at capacity - 1)
                         }
                     }
                 }
@@ -745,6 +838,8 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                         if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
                     }
                 }
+                SVSX_PHASE_USE(buf.best_unvisited);
+                SVSX_PHASE_STAMP(5);
             }
             if (deg_here < 64u) break;
         }
@@ -831,9 +926,13 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             st[4] = n_early;
             st[5] = n_code_rej;
 #ifdef SVSX_DIAG
+            st[2] = diag_have;
             st[3] = diag_early;
             st[4] = diag_t0;
             st[5] = static_cast<uint32_t>(wall_clock64());
+#if SVSX_DIAG == 2
+            for (int i = 1; i <= 5; ++i) st[i] = ph_acc[i]; // [0] stays the expansion count; ph_acc[0] = between expansions (loop control)
+#endif
 #endif
         }
         if (a.history_len != nullptr) a.history_len[qi] = n_exp;
@@ -858,7 +957,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       ((a.filter_entries || CODES != 0) ? 64 * 4 : 0) + (CODES >= 3 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
+                       64 * 4 /* compaction / merge scratch */ + (CODES >= 3 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #ifdef SVSX_DIAG
     size_t lds_request = lds;

@@ -219,9 +219,9 @@ class VamanaIndex:
         return QueryResult(ids, dists)
 
     def build_bound_codes(self, mode: int | bool = 1) -> None:
-        """svsx_index_build_bound_codes: result-neutral lower-bound rejection for float32 / float16 L2 indexes.
-        mode 1 (True): 128-byte code row per vector (d = 96 / 128); mode 2: graph-inline 32-byte records per neighbour
-        (32 <= d <= 128); 0 (False): off."""
+        """svsx_index_build_bound_codes: result-neutral bound rejection.  mode 2: graph-inline records per neighbour, size chosen from the
+        data's spectrum (float32 / float16 rows, any metric; SQ rows under IP / cosine; 32 <= d <= 4096); 32 / 64 / 128: the same with that
+        record size; mode 1 (True): 128-byte code row per vector (float rows, L2, d = 96 / 128); 0 (False): off."""
         _lib.check(_lib.lib().svsx_index_build_bound_codes(self._h, int(mode)))
 
     def last_kernel_info(self) -> str:

@@ -188,3 +188,75 @@ class PipelinedShardSearch:
 
         torch.cuda.current_stream().synchronize()
         self.s_merge.synchronize()
+
+
+class NativeShardedSearcher:
+    """The same search inside libsvsx (svsx_sharded_*: per-shard searches, local merge, ONE ncclAllGather on an RCCL communicator the
+    library joins itself, world-way merge -- all on one stream, no torch collective on the data path).  What a C++ host of the
+    reference would call; `torch.distributed` is only used here to hand rank 0's 128-byte unique id to the other ranks.
+
+    indexes: this rank's VamanaIndex objects, global shards rank * len(indexes) + s (their id_offset makes the ids global).
+    use_rccl: None = whenever the process group's backend is nccl or the world has one rank and `single_rank_comm` is set."""
+
+    def __init__(self, indexes, group=None, single_rank_comm: bool = False):
+        import torch
+        import torch.distributed as dist
+
+        self.indexes = list(indexes)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        L = _lib.lib()
+        id_ptr = None
+        self._id = None
+        if self.world > 1 or single_rank_comm:
+            buf = (C.c_char * 128)()
+            if self.rank == 0:
+                _lib.check(L.svsx_sharded_unique_id(buf))
+            if self.world > 1:  # hand the id to every rank through the process group that exists anyway (works on nccl and gloo groups)
+                dev = torch.device("cuda", self.indexes[0].device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+                t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone().to(dev)
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                raw = bytes(t.cpu().numpy().tobytes())
+                buf = (C.c_char * 128).from_buffer_copy(raw)
+            self._id = buf
+            id_ptr = C.cast(buf, C.c_void_p)
+        arr = (C.c_void_p * len(self.indexes))(*[ix._h for ix in self.indexes])
+        self._h = C.c_void_p()
+        _lib.check(L.svsx_sharded_create(arr, len(self.indexes), id_ptr, self.rank, self.world, C.byref(self._h)))
+
+    def info(self) -> dict:
+        a = (C.c_uint64 * 4)()
+        _lib.check(_lib.lib().svsx_sharded_info(self._h, a))
+        return dict(local_shards=int(a[0]), world=int(a[1]), rank=int(a[2]), communicator=bool(a[3]))
+
+    @property
+    def shards_total(self) -> int:
+        return self.world * len(self.indexes)
+
+    def search(self, d_queries, k: int, search_parameters=None, d_ids64=None, d_dists=None, stream=None):
+        """queries: torch CUDA tensor [nq, d]; returns (dists f32 [nq,k], ids int64 [nq,k]) -- same order as ShardedSearcher.search"""
+        import torch
+
+        nq = d_queries.shape[0]
+        code = {torch.float32: 0, torch.float16: 1, torch.int8: 2, torch.uint8: 3}[d_queries.dtype]
+        if d_ids64 is None:
+            d_ids64 = torch.empty((nq, k), dtype=torch.int64, device=d_queries.device)
+        if d_dists is None:
+            d_dists = torch.empty((nq, k), dtype=torch.float32, device=d_queries.device)
+        sp = (search_parameters or self.indexes[0]._params)._c()
+        s = stream if stream is not None else torch.cuda.current_stream(d_queries.device).cuda_stream
+        if d_queries.stride(0) != d_queries.shape[1] or d_queries.stride(1) != 1:
+            d_queries = d_queries.contiguous()
+        _lib.check(_lib.lib().svsx_sharded_search_device(self._h, d_queries.data_ptr(), code, nq, k, C.byref(sp), d_ids64.data_ptr(), d_dists.data_ptr(), C.c_void_p(s)))
+        return d_dists, d_ids64
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().svsx_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass

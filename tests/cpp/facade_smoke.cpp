@@ -32,6 +32,28 @@ int main(int argc, char**) {
         r3.view().indices[0] = 12345;
         index.search(r3.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}), [] { return true; });
         if (r3.index(0, 0) != 12345) return 8;
+        {   // graph-inline bound records (the default fast path; result-neutral) and the runtime's IDFilter argument on a 64-point ring in 32 dimensions
+            const size_t n2 = 64, d2 = 32;
+            std::vector<float> data2(n2 * d2, 0.0f);
+            for (size_t i = 0; i < n2; ++i) { data2[i * d2] = static_cast<float>(i); data2[i * d2 + 1] = 0.25f * static_cast<float>(i % 5); }
+            std::vector<uint32_t> graph2(n2 * (R + 1));
+            for (size_t i = 0; i < n2; ++i) { graph2[i * 3] = 2; graph2[i * 3 + 1] = (i + 1) % n2; graph2[i * 3 + 2] = (i + n2 - 1) % n2; }
+            std::vector<float> q2(d2, 0.0f);
+            q2[0] = 40.2f;
+            svsx::VamanaIndex<float, svsx::DistanceL2> index2(graph2.data(), R + 1, data2.data(), n2, d2, {entry, 1});
+            const auto sp2 = svsx::VamanaSearchParameters{}.buffer_config({16}).search_buffer_visited_set(true);
+            svsx::QueryResult<size_t> plain(1, 4), coded(1, 4), filtered(1, 4);
+            index2.search(plain.view(), q2.data(), sp2);
+            index2.build_bound_codes();   // mode 2
+            index2.search(coded.view(), q2.data(), sp2);
+            for (size_t j = 0; j < 4; ++j)
+                if (plain.index(0, j) != coded.index(0, j) || plain.distance(0, j) != coded.distance(0, j)) return 11;
+            if (plain.index(0, 0) != 40) return 12;
+            std::vector<uint64_t> even(1, 0x5555555555555555ull); // ids 0, 2, 4, ... are members
+            index2.search(filtered.view(), q2.data(), sp2, std::span<const uint64_t>(even.data(), even.size()));
+            std::printf("filtered: %zu %zu %zu %zu\n", filtered.index(0, 0), filtered.index(0, 1), filtered.index(0, 2), filtered.index(0, 3));
+            if (!(filtered.index(0, 0) == 40 && filtered.index(0, 1) == 42 && filtered.index(0, 2) == 38 && filtered.index(0, 3) == 44)) return 13;
+        }
         // BatchIterator: 8 points on a ring, batches of 3 -> 5 6 4 | 7 3 2 | 1 0 | (done)
         svsx::BatchIterator<float> it(index, q.data(), 1);
         const size_t want[8] = {5, 6, 4, 7, 3, 2, 1, 0};

@@ -123,4 +123,5 @@ def test_cxx_facade_search_on_gpu(lib, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.splitlines()
     assert lines[0].split() == ["5", "6", "4"]
-    assert [ln.split()[2] for ln in lines[1:]] == ["5", "6", "4", "7", "3", "2", "1", "0"]  # BatchIterator, batches of 3
+    assert lines[1].split() == ["filtered:", "40", "42", "38", "44"]                        # IDFilter overload, inline-record index
+    assert [ln.split()[2] for ln in lines[2:]] == ["5", "6", "4", "7", "3", "2", "1", "0"]  # BatchIterator, batches of 3

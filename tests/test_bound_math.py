@@ -30,7 +30,9 @@ def query_codes(q, dc, scale, bias):
     e2 = f32(0.0)
     for v in r:  # f32 accumulation (the kernel's order differs; the 1.001 margin covers any order)
         e2 = f32(e2 + f32(v * v))
-    eq = f32(np.sqrt(e2)) * f32(1.001) + f32(1.0e-7)
+    # round 3: + the absolute term of the residual's own rounding, which happens at the magnitude of the offset (svsx_index_build_bound_codes)
+    eq_abs = f32(np.sqrt(np.float64(dc)) * 2.4e-7 * (abs(np.float64(bias)) + 255.0 * np.float64(scale)) * 1.01)
+    eq = f32(f32(np.sqrt(e2)) * f32(1.001) + f32(1.0e-7)) + eq_abs
     return c.astype(np.int64), eq
 
 
@@ -54,9 +56,12 @@ def _datasets():
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     yield x, np.zeros((4, 96), f32) + f32(1e-4)                                                    # all candidates equidistant
     yield np.concatenate([x[:100], x[:100]]), x[:20] + f32(1e-3)                                   # exact duplicates
+    for off, spread in ((1e3, 1e-2), (1e5, 1e-1)):                                                # far offset band: |x| / spread up to 10^6
+        xb = (deep_like(300, 96, 8, seed=7, normalize=False) * f32(spread) + f32(off)).astype(f32)
+        yield xb, (xb[:16] + f32(spread) * rng.standard_normal((16, 96)).astype(f32)).astype(f32)
 
 
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(8))
 def test_bound_never_exceeds_the_exact_distance(oracle, case):
     x, q = list(_datasets())[case]
     d = x.shape[1]

@@ -115,12 +115,11 @@ def test_every_static_float_instantiation(svs, oracle, small_world, world128, me
 
 @pytest.mark.parametrize("metric", [L2, IP, COS])
 @pytest.mark.parametrize("d", [64, 100, 160, 200])
-def test_static_inline_record_instantiations(svs, oracle, metric, d, monkeypatch):
+def test_static_inline_record_instantiations(svs, oracle, metric, d):
     """the 32-byte inline-record kernels of the remaining static dimensions (96 / 128 are covered by the config tests)"""
-    monkeypatch.setenv("SVSX_RECORD_BYTES", "32")
     w = _world(oracle, d)
     idx = svs.VamanaIndex(w["graph"], w["x"], _fn(svs, metric), w["entry"])
-    idx.build_bound_codes(2)
+    idx.build_bound_codes(32)  # records of exactly 32 bytes, whatever the spectrum rule would pick
     res, st = idx.search(w["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(64), 1), stats=True)
     assert idx.last_kernel_info() == f"search_kernel<dt=0,metric={metric},qmode=0,ds={d},general=0,codes=2>"
     ids, dists, ost = oracle.search(metric, w["x"], w["graph"], w["entry"], w["q"], 10, 64, visited_set=True, stats=True)
@@ -185,6 +184,45 @@ def test_bound_code_instantiations_are_reported(svs, small_world, world128):
 
 
 # ---- config 5 on ONE GPU: four shards, global ids beyond 2^32 -------------------------------------------------------------
+@pytest.mark.parametrize("single_rank_comm", [False, True])
+def test_native_sharded_search_in_the_library(svs, oracle, single_rank_comm):
+    """svsx_sharded_* (SURVEY 8e behind the C ABI): three shards on this GPU, ids beyond 2^32 -- per-shard searches, local merge and (with
+    single_rank_comm) a real RCCL communicator of one rank with its ncclAllGather, against oracle searches merged by the stated rule
+    (ties -> lower shard, then position)."""
+    import torch
+
+    from oracle.oracle import merge_topk_ref
+    from scalablevectorsearch_amd.sharded import NativeShardedSearcher
+
+    S, n, d, nq, k = 3, 1500, 96, 48, 10
+    base = (1 << 32) + 777
+    q = deep_like(nq, d, 24, seed=98)
+    q[1] = q[0]
+    indexes, want_d, want_i = [], [], []
+    for s in range(S):
+        x = deep_like(n, d, 24, seed=300 + (s % 2))   # shards 0 and 2 hold the SAME vectors: every distance ties across shards
+        g, e = oracle.build_vamana(L2, x, R=24, L=40)
+        idx = svs.VamanaIndex(g, x, svs.DistanceL2(), e, id_offset=s * base)
+        if s == 1:
+            idx.build_bound_codes(2)
+        indexes.append(idx)
+        oi, od = oracle.search(L2, x, g, e, q, k, 48)
+        want_i.append(oi.astype(np.int64) + s * base)
+        want_d.append(od)
+    wd, wi = merge_topk_ref(L2, np.stack(want_d), np.stack(want_i), k)
+    ns = NativeShardedSearcher(indexes, single_rank_comm=single_rank_comm)
+    assert ns.info() == dict(local_shards=3, world=1, rank=0, communicator=single_rank_comm) and ns.shards_total == 3
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(48))
+    for _ in range(2):  # the second call reuses the staging buffers
+        md, mi = ns.search(torch.from_numpy(q).cuda(), k, sp)
+        torch.cuda.synchronize()
+        assert (mi.cpu().numpy() == wi).all() and (_bits(md.cpu().numpy()) == _bits(wd)).all()
+    assert int(mi.max()) > (1 << 32)
+    with pytest.raises(svs.SvsxError):
+        ns.search(torch.from_numpy(q[:3]).cuda(), 1, sp)   # nq * k odd: refused, the packed ids would be misaligned
+    ns.close()
+
+
 def test_config5_shards_with_64bit_offsets(svs, oracle):
     import torch
 
@@ -262,6 +300,87 @@ def test_config2_full_size_ids_identical_to_reference(svs, ref):
             torch.cuda.synchronize()
             assert (ids.cpu().numpy() == rid.astype(np.int64)).all(), (window, mode)
             assert (_bits(dist.cpu().numpy()) == _bits(rd)).all(), (window, mode)
+
+
+# ---- config 3 at full size against the reference's own code ------------------------------------------------------------------
+def test_config3_full_size_ids_identical_to_reference(svs, ref):
+    """BASELINE config 3: 1 000 000 x 128 float16 rows, float32 queries, inner product, GPU-built Vamana R = 64, 10 000 queries --
+    ids and distance bits from the HIP path (32-byte graph-inline records + visited filter, the instantiation the bench line's
+    other_configs.c3 point runs; and the plain kernel) identical to oracle/_ref (ConvertToFloat<16> f16 loads + IPFloatOp<16>,
+    simd_utils.h:262-301, inner_product.h:199-216) on every query."""
+    import os
+
+    import torch
+
+    from bench import deep_like_device
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
+
+    dev = torch.device("cuda", 0)
+    n, d, nq, k, R = 1_000_000, 128, 10_000, 10, 64
+    x = deep_like_device(n, d, 32, 31, dev, normalize=False).half()
+    q = deep_like_device(nq, d, 32, 32, dev, normalize=False)
+    graph, entry = build_vamana_device(x, n, d, svs.DistanceIP(), VamanaBuildParameters(alpha=0.95, graph_max_degree=R, window_size=2 * R, prune_to=R - 4),
+                                       data_dtype=np.float16, device=0)
+    idx = svs.VamanaIndex.from_device(graph, x, svs.DistanceIP(), torch.tensor([entry], dtype=torch.int32, device=dev), n, d, np.float16)
+    xh, qh, gh = x.cpu().numpy(), q.cpu().numpy(), device_graph_to_svs(graph, R)
+    eh = np.array([entry], np.uint32)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    threads = max(1, len(os.sched_getaffinity(0)))
+    window = 128
+    rid, rd = ref.search(IP, xh, gh, eh, qh, k, window, nthreads=min(threads, 32))
+    for mode, vis in ((0, 0), (2, 1)):
+        idx.build_bound_codes(mode)
+        st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
+        idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(window), vis), d_ids64=ids, d_dists=dist, d_stats=st)
+        torch.cuda.synchronize()
+        assert idx.last_kernel_info() == f"search_kernel<dt=1,metric=1,qmode=0,ds=128,general=0,codes={mode}>"
+        assert (ids.cpu().numpy() == rid.astype(np.int64)).all(), mode
+        assert (_bits(dist.cpu().numpy()) == _bits(rd)).all(), mode
+        if mode == 2:
+            assert int(st[:, 5].sum()) > 0.5 * int(st[:, 2].sum())  # the records really reject most candidates on this set
+
+
+# ---- config 4 at a size where the record-size rule decides as it does at 10 M ----------------------------------------------------
+def test_config4_large_sq_cosine_matches_oracle(svs, oracle):
+    """BASELINE config 4's row type at 1 000 000 x 768: scalar-quantized int8 codes (one global scale / bias, scalar.h:454-462),
+    float32 queries, cosine (CosineSimilarityCompressed, scalar.h:155-195), batch 4 096, windows 128 and 1 024 -- the spectrum rule
+    must pick the 128-byte records the 10 M-vector run uses (codes=4; window 1 024 = the big-buffer instantiation), and ids and
+    distance bits must equal the C oracle on a sample of the batch."""
+    import torch
+
+    from bench import deep_like_device
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
+
+    dev = torch.device("cuda", 0)
+    n, d, nq, k, R = 1_000_000, 768, 4096, 10, 64
+    xf = deep_like_device(n, d, 64, 1, dev, normalize=False)
+    q = deep_like_device(nq, d, 64, 2, dev, normalize=False)
+    mn, mx = float(xf.min()), float(xf.max())
+    scale = (mx - mn) / 255.0
+    bias = mn + 128.0 * scale
+    x = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8)
+    del xf
+    fn = svs.DistanceCosineSimilarity()
+    graph, entry = build_vamana_device(x, n, d, fn, VamanaBuildParameters(alpha=0.95, graph_max_degree=R, window_size=2 * R, prune_to=R - 4),
+                                       data_dtype=np.int8, sq=(scale, bias))
+    torch.cuda.empty_cache()
+    idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), n, d, np.int8, sq=(scale, bias))
+    idx.build_bound_codes(2)
+    xh, gh = x.cpu().numpy(), device_graph_to_svs(graph, R)
+    eh = np.array([entry], np.uint32)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    for window, sample in ((128, 256), (1024, 48)):
+        st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
+        idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(window), 1), d_ids64=ids, d_dists=dist, d_stats=st)
+        torch.cuda.synchronize()
+        assert idx.last_kernel_info() == "search_kernel<dt=2,metric=2,qmode=3,ds=768,general=0,codes=4>", idx.last_kernel_info()
+        qs = q[:sample].cpu().numpy()
+        oi, od = oracle.search(COS, xh, gh, eh, qs, k, window, visited_set=True, sq=(scale, bias))
+        assert (ids[:sample].cpu().numpy() == oi.astype(np.int64)).all(), window
+        assert (_bits(dist[:sample].cpu().numpy()) == _bits(od)).all(), window
+        assert int(st[:, 5].sum()) > 0.5 * int(st[:, 2].sum())
 
 
 # ---- cancellation (index/vamana/index.h:541-545,564-570; greedy_search.h:155; extensions.h:575-578) ---------------------------------

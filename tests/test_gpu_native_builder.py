@@ -1,5 +1,5 @@
-"""STAGED (move to tests/ once staging/r3/builder is applied): the in-library builder (svsx_vamana_build_device, csrc/svsx_builder.hip)
-against the round-2 torch-glue builder and the CPU oracle's builder.
+"""The in-library builder (svsx_vamana_build_device, csrc/svsx_builder.hip = scalablevectorsearch_amd.build.build_vamana_device)
+against the round-2 torch-glue builder (build_vamana_torch_glue, kept as the checker).
 
 Graph bytes are compared with the torch-glue builder when both start from the same entry point (same algorithm, same order: the only
 legitimate difference is the float32 rounding of neighbour distances, torch ops vs the row-group routines, which can reorder near-ties) --
@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import scalablevectorsearch_amd as svs
-from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, build_vamana_native
+from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, build_vamana_torch_glue
 
 pytestmark = pytest.mark.gpu
 
@@ -30,8 +30,8 @@ def test_native_builder_valid_graph_and_quality(metric):
     alpha = 1.2 if metric == "l2" else 0.95
     dx = torch.from_numpy(x).cuda()
     bp = VamanaBuildParameters(alpha=alpha, graph_max_degree=R, window_size=2 * R, prune_to=R - 4)
-    g_ref, e_ref = build_vamana_device(dx, n, d, fn, bp)
-    g_nat, e_nat = build_vamana_native(dx, n, d, fn, bp, entry_point=e_ref)
+    g_ref, e_ref = build_vamana_torch_glue(dx, n, d, fn, bp)
+    g_nat, e_nat = build_vamana_device(dx, n, d, fn, bp, entry_point=e_ref)
     gn = g_nat.cpu().numpy()
     # valid: ids in range, packed from slot 0, no self loops, no duplicates, padding beyond R untouched
     ids = gn[:, :R]
@@ -84,8 +84,8 @@ def test_native_builder_sq_and_small_batches():
     dx = torch.from_numpy(xq).cuda()
     bp = VamanaBuildParameters(alpha=0.95, graph_max_degree=R, window_size=2 * R, prune_to=R - 2)
     fn = svs.DistanceIP()
-    g_ref, e = build_vamana_device(dx, n, d, fn, bp, data_dtype=np.int8, sq=(scale, bias))
-    g_nat, _ = build_vamana_native(dx, n, d, fn, bp, data_dtype=np.int8, entry_point=e, sq=(scale, bias))
+    g_ref, e = build_vamana_torch_glue(dx, n, d, fn, bp, data_dtype=np.int8, sq=(scale, bias))
+    g_nat, _ = build_vamana_device(dx, n, d, fn, bp, data_dtype=np.int8, entry_point=e, sq=(scale, bias))
     gn = g_nat.cpu().numpy()[:, :R]
     assert ((gn >= -1) & (gn < n)).all() and (gn >= 0).sum(1).min() >= 1
     print("rows identical to the torch-glue builder:", float((g_nat == g_ref).all(1).float().mean()))

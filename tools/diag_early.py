@@ -44,6 +44,6 @@ for nq in [int(v) for v in a.nq.split(",")]:
         first = start < 20.0   # the first resident generation
         late = start > np.percentile(start, 90) if (~first).any() else first
         per = dur / np.maximum(nexp, 1)
-        print(json.dumps({"nq": nq, "window": w, "lds_request": int(req), "ms": ms, "kernel": idx.last_kernel_info(), "expansions": float(nexp.mean()), "early_share": float(early.sum() / max(nexp.sum(), 1)),
+        print(json.dumps({"nq": nq, "window": w, "lds_request": int(req), "ms": ms, "kernel": idx.last_kernel_info(), "expansions": float(nexp.mean()), "early_share": float(early.sum() / max(nexp.sum(), 1)), "kept_used_share": float(st[:, 2].sum() / max(nexp.sum(), 1)),
                           "first_generation": int(first.sum()), "us_per_expansion_first": float(per[first].mean()), "us_per_expansion_late": float(per[late].mean()),
                           "query_us_first": float(dur[first].mean()), "query_us_late": float(dur[late].mean()), "span_us": float((start + dur).max())}), flush=True)

@@ -15,9 +15,8 @@ g, e = build_vamana_device(x, n, d, fn, VamanaBuildParameters(alpha=0.95, graph_
 torch.cuda.empty_cache()
 idx = svs.VamanaIndex.from_device(g, x, fn, torch.tensor([e], dtype=torch.int32, device=dev), n, d, np.int8, sq=(scale, bias))
 ids = torch.empty((nq, k), dtype=torch.int64, device=dev); dist = torch.empty((nq, k), device=dev); st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
-for rb in ("32", "64", "128"):
-    os.environ["SVSX_RECORD_BYTES"] = rb
-    idx.build_bound_codes(0); idx.build_bound_codes(2)
+for rb in (32, 64, 128):
+    idx.build_bound_codes(rb)  # inline records of exactly this size
     for w in (128, 512):
         sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w), 1)
         idx.search_device(qf, k, sp, d_ids64=ids, d_dists=dist, d_stats=st); torch.cuda.synchronize()
