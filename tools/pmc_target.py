@@ -19,18 +19,33 @@ ap.add_argument("--matched", action="store_true", help="use the smallest window 
 ap.add_argument("--sid", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-d, k, R = 96, 10, a.degree
-x = deep_like_device(a.n, d, 24, seed=1 + 1000 * a.sid, device=dev)
-q = deep_like_device(a.nq, d, 24, seed=2, device=dev)
-cache = f"{a.graph_cache}.s{a.sid}.n{a.n}" if a.graph_cache else ""
-graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache)
-idx = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), torch.tensor([entry], dtype=torch.int32, device=dev), a.n, d, np.float32)
+k, R = 10, a.degree
+cache = f"{a.graph_cache}.{a.config}.s{a.sid}.n{a.n}" if a.graph_cache else ""
+if a.config == "c3":    # BASELINE config 3: sift-1M-like, float16 rows, float32 queries, inner product
+    d, fn, ddt, sq = 128, svs.DistanceIP(), np.float16, None
+    x = deep_like_device(a.n, d, 32, seed=31, device=dev, normalize=False).half()
+    q = deep_like_device(a.nq, d, 32, seed=32, device=dev, normalize=False)
+    graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache, distance=fn, alpha=0.95, data_dtype=ddt)
+elif a.config == "c4":  # BASELINE config 4's row type: scalar-quantized int8 codes, float32 queries, cosine
+    d, fn, ddt = 768, svs.DistanceCosineSimilarity(), np.int8
+    xf = deep_like_device(a.n, d, 64, seed=1, device=dev, normalize=False)
+    q = deep_like_device(a.nq, d, 64, seed=2, device=dev, normalize=False)
+    mn, mx = float(xf.min()), float(xf.max()); scale = (mx - mn) / 255.0; bias = mn + 128.0 * scale
+    x = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8); del xf
+    sq = (scale, bias)
+    graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache, distance=fn, alpha=0.95, data_dtype=ddt, sq=sq)
+else:
+    d, fn, ddt, sq = 96, svs.DistanceL2(), np.float32, None
+    x = deep_like_device(a.n, d, 24, seed=1 + 1000 * a.sid, device=dev)
+    q = deep_like_device(a.nq, d, 24, seed=2, device=dev)
+    graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache)
+idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), a.n, d, ddt, sq=sq)
 if a.codes:
     idx.build_bound_codes(a.codes)
 ids = torch.empty((a.nq, k), dtype=torch.int64, device=dev); dist = torch.empty((a.nq, k), device=dev)
 window = a.window
 if a.matched:
-    gt = brute_force_topk(x, q, k)
+    gt = idx.flat_search_device(q, k)[0] if a.config != "c2" and a.config != "c5" else brute_force_topk(x, q, k)
     lo, hi = k, a.window
     while lo < hi:
         mid = (lo + hi) // 2
@@ -52,7 +67,7 @@ e0.record()
 for _ in range(a.launches): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dist)
 e1.record(); torch.cuda.synchronize()
 rb = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(idx.last_kernel_info()[-8:], 32)
-lines = designed_lines(stats.to(torch.int64), (R + 15) // 16 * 16, d * 4, a.codes, d, k, rb)
+lines = designed_lines(stats.to(torch.int64), (R + 15) // 16 * 16, x.shape[1] * x.element_size(), a.codes, d, k, rb)
 print(json.dumps({"workload_key": f"{a.config}:n={a.n}:nq={a.nq}:window={window}:R={R}:visited={a.visited}:codes={a.codes}", "kernel_src_sha": kernel_src_sha(),
                   "window": window, "launches": a.launches, "designed_lines_per_launch": lines, "designed_bytes_per_launch": lines["total"] * LINE,
                   "kernel_ms_unprofiled_or_profiled": e0.elapsed_time(e1) / a.launches, "kernel": idx.last_kernel_info(),

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round-3 PMC evidence (one gpurun call): the three regimes of round 2 on the new kernel sources + configs 3 and 4.  Summaries afterwards, locally:
+#   for t in r03_c2_w128 r03_c2_matched r03_c5shard r03_c3_w128 r03_c4_w512; do python tools/summarize_pmc.py $t; done
+set -u
+tools/collect_pmc.sh r03_c2_w128 --n 1000000 --window 128 --codes 2
+tools/collect_pmc.sh r03_c2_matched --n 1000000 --window 128 --codes 2 --matched
+tools/collect_pmc.sh r03_c3_w128 --config c3 --n 1000000 --window 128 --codes 2
+tools/collect_pmc.sh r03_c4_w512 --config c4 --n 2000000 --nq 4096 --window 512 --codes 2
+tools/collect_pmc.sh r03_c5shard --config c5 --n 12500000 --window 128 --codes 2
+for t in r03_c2_w128 r03_c2_matched r03_c3_w128 r03_c4_w512 r03_c5shard; do echo "== $t"; cut -c1-400 gpurun_out/$t/target.json; tail -n 2 gpurun_out/$t/target.err | cut -c1-200; done
+du -sh gpurun_out
