@@ -1,5 +1,5 @@
 """The bench line contract (driver: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line): the committed
-evidence line of the final round-2 kernels must carry every field the contract names, with consistent values."""
+evidence line of the final round-3 kernels must carry every field the contract names, with consistent values."""
 import json
 import os
 import subprocess
@@ -9,20 +9,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    j = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_1gpu.json")))
+    j = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_1gpu.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in j, key
     assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic"
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_src_sha", "designed_bytes_per_launch", "reference_algorithmic_bytes_per_launch"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "frac_basis", "frac_designed", "achieved_designed", "traffic", "kernel_src_sha",
+                "designed_bytes_per_launch", "reference_algorithmic_bytes_per_launch"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert 0.0 < r["frac"] <= 1.0                       # a roofline FRACTION: designed bytes, never the reference-algorithmic ones
+    assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["frac_designed"] <= 1.0
     assert r["reference_algorithmic_bytes_per_launch"] > r["designed_bytes_per_launch"]
-    if r["traffic"] is not None:                        # only filled from a PMC summary of the same kernel sources
-        assert 0.5 < r["traffic"] / r["designed_bytes_per_launch"] < 1.3 and r["frac_traffic"] <= 1.0
+    # round 3: the headline fraction is the counter-based one (PMC traffic of THESE kernel sources / this run's kernel time)
+    assert r["traffic"] is not None and r["traffic_source"].startswith("profiles/r03_") and "PMC" in r["frac_basis"]
+    assert abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert 0.5 < r["traffic"] / r["designed_bytes_per_launch"] < 1.3 and r["frac"] <= r["frac_designed"] * 1.3
     # value = batch / step time; the kernel time measured with HIP events cannot exceed the step time by more than noise
     nq = 10000
     assert abs(j["value"] - nq / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
@@ -35,18 +38,29 @@ def test_committed_bench_line_has_the_contract_fields():
     assert m["recall_at_10"] >= 0.9 and m["ids_identical_on_sample"] is True and m["frac"] <= 1.0
     hp = j["config"]["host_pointer"]                    # SURVEY 8d wording: host pointers in / out, 1 warm-up + 5 timed
     assert hp["runs"] == 5 and hp["min_ms"] <= hp["median_ms"] <= hp["max_ms"] and hp["ids_equal_device_path"] is True
-    assert hp["qps_at_median"] < j["value"]
+    assert hp["qps_at_median"] < j["value"] and 0.6 < hp["over_device_resident"] < 1.0
+    sh = j["config"]["sharded_c5"]                      # SURVEY 8e in the same line: fixed 8 shards, RCCL communicator inside the library
+    assert sh["shards_total"] == 8 and sh["shards_per_gpu"] * sh["n_gpus"] == 8 and sh["rccl_communicator"] is True and sh["recall_at_10"] > 0.99
+    c3 = j["config"]["other_configs"]["c3"]
+    assert "codes=2>" in c3["kernel"] and c3["recall_at_10"] > 0.9
 
 
 def test_pmc_summaries_are_stamped_and_consistent():
-    """each committed round-2 PMC summary names its workload and the kernel sources it was measured on, and its traffic agrees with
+    """each committed round-3 PMC summary names its workload and the kernel sources it was measured on, and its traffic agrees with
     the designed bytes of the same launches (no wasted re-reads)"""
-    for tag in ("r02_c2_w128", "r02_c2_matched", "r02_c5shard"):
+    shas = set()
+    for tag in ("r03_c2_w128", "r03_c2_matched", "r03_c5shard", "r03_c3_w128", "r03_c4_w512"):
         j = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
         assert len(j["kernel_src_sha"]) == 16 and j["workload_key"].count(":") >= 6
+        shas.add(j["kernel_src_sha"])
         assert abs(j["fetch_size_calibration"]["factor"] - 2.0) < 0.01
         assert 0.5 < j["traffic_over_designed"] < 1.1
         assert j["frac_traffic_of_8TBs"] < 1.0 and j["kernel_trace"]["launches"] == j["launches"]
+    assert len(shas) == 1  # one set of kernel sources
+    sys.path.insert(0, ROOT)
+    from bench import kernel_src_sha
+
+    assert shas == {kernel_src_sha()}, "the committed PMC summaries belong to other kernel sources: re-collect (tools/r3_pmc.sh)"
 
 
 def test_counter_generator_is_reproducible():

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """A/B of two (or more) builds of libsvsx.so on the same workloads, one child process per library (SVSX_LIB):
-   python tools/ab_libs.py --libs prod=variants/prod/libsvsx.so,new= --script tools/ab_lookahead.py -- --policies off --nq 10000,20000 --windows 128,23
+   python tools/ab_libs.py --libs prod=variants/prod/libsvsx.so,new= --script tools/diag_early.py -- --nq 10000,20000 --windows 128,23
 (an empty path = the in-tree library).  The script must print JSON lines with an "ms" field; rows are matched on all other scalar fields.
 Each library runs `--repeat` times, alternating, and the table shows the median: clocks drift by a few per cent within one call."""
 import argparse, json, os, statistics, subprocess, sys
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--libs", required=True); ap.add_argument("--script", default="tools/ab_lookahead.py"); ap.add_argument("--repeat", type=int, default=2)
+ap.add_argument("--libs", required=True); ap.add_argument("--script", default="tools/diag_early.py"); ap.add_argument("--repeat", type=int, default=2)
 ap.add_argument("rest", nargs=argparse.REMAINDER)
 a = ap.parse_args()
 libs = [tuple(x.split("=", 1)) for x in a.libs.split(",")]
