@@ -271,13 +271,21 @@ int svsx_iterator_state(const svsx_batch_iterator* it, uint32_t* meta);
 
 /* Batch search with an id filter: the runtime's VamanaIndex::search(n, x, k, distances, labels, params, IDFilter* filter)
  * (bindings/cpp/include/svs/runtime/vamana_index.h:75-83; algorithm bindings/cpp/src/vamana_index_impl.h:140-218 with
- * filter_estimate_batch = false).  id_bitmap: bit i of the (n + 63) / 64 words = IDFilter::is_member(i), local ids.
+ * filter_estimate_batch = false; the runtime's default, true, is svsx_search_filtered_ex below).  id_bitmap: bit i of the (n + 63) / 64 words = IDFilter::is_member(i), local ids.
  * filter_stop: give up on a query (all-padding row) once its observed hit rate falls below it; 0 = never
  * (SearchParams::filter_stop, api_defs.h).  Per query the answer equals the reference's iterator loop: adaptive batches from
  * a BatchIterator until k members are found or the iterator is exhausted.  Host pointers, synchronous. */
 int svsx_search_filtered(
     const svsx_index* index, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     const uint64_t* id_bitmap, float filter_stop, uint64_t* ids64, float* dists
+);
+/* Same with SearchParams::filter_estimate_batch (api_defs.h; the runtime's default is TRUE): before any graph traversal the filter's hit
+ * rate is estimated on max(200, 1 / filter_stop) ids drawn by std::mt19937(42) (sample_filter_hits, svs_runtime_utils.h:445-471); a
+ * rate below filter_stop answers every query with padding (vamana_index_impl.h:163-166), otherwise it sets the first batch size of every
+ * query (predict_further_processing, :167-169).  filter_estimate_batch = 0 is svsx_search_filtered. */
+int svsx_search_filtered_ex(
+    const svsx_index* index, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    const uint64_t* id_bitmap, float filter_stop, int filter_estimate_batch, uint64_t* ids64, float* dists
 );
 
 /* Bound codes (no reference counterpart; result-neutral).  The search kernel turns them into a rigorous BOUND of the distance (lower

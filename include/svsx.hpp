@@ -158,15 +158,16 @@ template <typename T, typename Dist> class VamanaIndex {
     // bench.py), 32 / 64 / 128 = records of that size, 1 = one 128-byte code row per vector (float rows, L2, d = 96 / 128), 0 = off
     void build_bound_codes(int mode = 2) { check(svsx_index_build_bound_codes(h_, mode)); }
     // runtime VamanaIndex::search(n, x, k, distances, labels, params, IDFilter* filter) (bindings/cpp/include/svs/runtime/vamana_index.h:75-83):
-    // `is_member` = one bit per id ((size() + 63) / 64 words); unfilled result slots hold id all-ones / distance +inf
+    // `is_member` = one bit per id ((size() + 63) / 64 words); unfilled result slots hold id all-ones / distance +inf; filter_stop and
+    // filter_estimate_batch are SearchParams' fields of the same names (api_defs.h; the runtime defaults: 0 and true)
     template <typename Q>
     void search(QueryResultView<size_t> result, const Q* queries, const VamanaSearchParameters& sp, std::span<const uint64_t> is_member,
-                float filter_stop = 0.0f) const {
+                float filter_stop = 0.0f, bool filter_estimate_batch = true) const {
         svsx_search_params p{sp.buffer_config_.get_search_window_size(), sp.buffer_config_.get_total_capacity(),
                              sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
         if (is_member.size() * 64 < size()) throw ANNException(SVSX_INVALID_ARGUMENT, "is_member must hold one bit per vector");
-        check(svsx_search_filtered(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), &p, is_member.data(), filter_stop,
-                                   reinterpret_cast<uint64_t*>(result.indices), result.distances));
+        check(svsx_search_filtered_ex(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), &p, is_member.data(), filter_stop,
+                                      filter_estimate_batch ? 1 : 0, reinterpret_cast<uint64_t*>(result.indices), result.distances));
     }
     const svsx_index* handle() const { return h_; }
     size_t size() const { uint64_t info[6]; check(svsx_index_info(h_, info)); return info[0]; }

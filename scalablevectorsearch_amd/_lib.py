@@ -80,7 +80,7 @@ EXPORTS = [
     "svsx_distance_batch", "svsx_merge_topk_device", "svsx_prune_device", "svsx_flat_search_device", "svsx_index_info", "svsx_last_error", "svsx_version",
     "svsx_iterator_create", "svsx_iterator_destroy", "svsx_iterator_update", "svsx_iterator_restart_next_search", "svsx_iterator_next",
     "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
-    "svsx_last_kernel_info", "svsx_search_filtered", "svsx_vamana_build_device", "svsx_find_medoid_device",
+    "svsx_last_kernel_info", "svsx_search_filtered", "svsx_search_filtered_ex", "svsx_vamana_build_device", "svsx_find_medoid_device",
     "svsx_sharded_unique_id", "svsx_sharded_create", "svsx_sharded_create_with_comm", "svsx_sharded_destroy", "svsx_sharded_info",
     "svsx_sharded_search_device",
 ]
@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
         L.svsx_iterator_state.argtypes = [C.c_void_p, C.c_void_p]
         L.svsx_index_build_bound_codes.argtypes = [C.c_void_p, C.c_int]
         L.svsx_search_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        L.svsx_search_filtered_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         L.svsx_vamana_build_device.argtypes = [C.c_void_p, C.POINTER(BuildParams), C.c_void_p]
         L.svsx_find_medoid_device.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.svsx_sharded_unique_id.argtypes = [C.c_void_p]

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -1679,9 +1680,21 @@ int svsx_iterator_next(
 // filter_estimate_batch = false, helpers svs_runtime_utils.h:411-434).  Per query: pull adaptive batches from its
 // BatchIterator until k members of the filter are found, the iterator is done, or the observed hit rate falls below
 // filter_stop.  All queries advance together, one kernel launch per round (per-query batch sizes, finished queries skipped).
+extern "C" int svsx_search_filtered_ex(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    const uint64_t* id_bitmap, float filter_stop, int filter_estimate_batch, uint64_t* ids64, float* dists
+);
+
 extern "C" int svsx_search_filtered(
     const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     const uint64_t* id_bitmap, float filter_stop, uint64_t* ids64, float* dists
+) {
+    return svsx_search_filtered_ex(ix, queries, q_dtype, nq, k, params, id_bitmap, filter_stop, 0, ids64, dists);
+}
+
+extern "C" int svsx_search_filtered_ex(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
+    const uint64_t* id_bitmap, float filter_stop, int filter_estimate_batch, uint64_t* ids64, float* dists
 ) {
     if (int rc = check_search_args(ix, queries, q_dtype, nq, k)) return rc;
     if (!id_bitmap || !ids64 || !dists) return fail(SVSX_INVALID_ARGUMENT, "null argument");
@@ -1693,6 +1706,30 @@ extern "C" int svsx_search_filtered(
     const size_t sws = params ? params->search_window_size : 0;
     const size_t max_batch = ix->n;
     const size_t q_row = ix->d * dtype_size(q_dtype);
+    size_t initial_batch = std::max(k, sws);
+    if (filter_estimate_batch) {
+        // Pre-search filter sampling (vamana_index_impl.h:153-175; sample_filter_hits, svs_runtime_utils.h:445-471): the hit rate of up to
+        // max(200, 1 / filter_stop) ids drawn by std::mt19937(42) through std::uniform_int_distribution<size_t>(0, n - 1) -- the standard
+        // library's own classes, so the draws are the reference's whenever both are built against the same libstdc++ -- decides whether to
+        // search at all and the first batch size of every query.
+        const size_t sample_size = filter_stop > 0.0f ? std::max<size_t>(200, static_cast<size_t>(1.0f / filter_stop)) : 200;
+        const size_t target = std::min(sample_size, static_cast<size_t>(ix->n));
+        std::mt19937 rng(42);
+        std::uniform_int_distribution<size_t> draw(0, ix->n - 1);
+        size_t hits = 0, checked = 0;
+        for (size_t tries = 0; checked < target && tries < target * 4; ++tries) {
+            const size_t id = draw(rng);
+            hits += (id_bitmap[id >> 6] >> (id & 63)) & 1ull;
+            ++checked;
+        }
+        if (filter_stop > 0.0f && checked != 0 && (hits == 0 || static_cast<float>(hits) / checked < filter_stop)) return SVSX_SUCCESS; // all padding
+        if (hits != 0 && hits < k) {
+            const float bs = static_cast<float>(k - hits) * checked / hits;
+            initial_batch = std::min(std::max(static_cast<size_t>(bs), size_t(1)), max_batch);
+        } else {
+            initial_batch = std::min(initial_batch, max_batch);
+        }
+    }
     auto predict = [](size_t processed, size_t hits, size_t goal, size_t hint, size_t max_value) -> size_t { // svs_runtime_utils.h:411-419
         if (hits == 0 || hits >= goal) return std::min(hint, max_value);
         const float bs = static_cast<float>(goal - hits) * processed / hits;
@@ -1709,7 +1746,7 @@ extern "C" int svsx_search_filtered(
         for (size_t i = 0; i < m; ++i) memcpy(&qbuf[i * q_row], static_cast<const unsigned char*>(queries) + qidx[i] * q_row, q_row);
         svsx_batch_iterator* it = nullptr;
         if (int rc = svsx_iterator_create(ix, qbuf.data(), q_dtype, m, ~size_t(0), &it)) return rc;
-        std::vector<size_t> found(m, 0), checked(m, 0), batch(m, std::max(k, sws)), grown(m, 0);
+        std::vector<size_t> found(m, 0), checked(m, 0), batch(m, initial_batch), grown(m, 0);
         std::vector<char> active(m, 1);
         std::vector<uint32_t> per_query(m), counts(m), meta(m * 8);
         std::vector<uint64_t> b_ids;

@@ -903,8 +903,14 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
         rank += kjl < mykey ? 1u : 0u; // new entries before mine: better, or equal and earlier in adjacency order
         // lane bl keeps its own count: one v_writelane instead of compare + select.  (inline asm: the compiler's hazard recogniser does not
         // look inside, so the wait states a lane select / source written by the scalar unit needs are spelled out)
-        // (the lane select goes through m0: one constant-bus operand per instruction on gfx9)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(oldle) : "s"(le), "s"(bl) : "m0");
+        // (the lane select goes through m0 -- one constant-bus operand per instruction on gfx9 -- which is saved and restored around it:
+        // m0 is a reserved register, a clobber on it would not be honoured)
+        {
+            uint32_t m0_save;
+            asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                         : "+v"(oldle), "=&s"(m0_save)
+                         : "s"(le), "s"(bl));
+        }
         minpos = le < minpos ? le : minpos;
     }
     // duplicates (search_buffer.h:377-389: same id at equal distance is not inserted): the same id gives the same distance bits, so a

@@ -817,6 +817,7 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
                                 merged = wave_merge_insert<GREATER, 16>(buf, cand, dist, cid, lane, n_ins, worst);
                             } else if constexpr (BIG == 1) {
                                 if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, cand, dist, cid, lane, n_ins, worst);
+                                else if (buf.capacity <= 384u) merged = wave_merge_insert<GREATER, 6>(buf, cand, dist, cid, lane, n_ins, worst);
                                 else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins, worst);
                             } else {
                                 merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins, worst);

@@ -200,7 +200,8 @@ class VamanaIndex:
         res = QueryResult(ids, dists)
         return (res, st) if stats else res
 
-    def search_filtered(self, queries, num_neighbors: int, is_member, search_parameters: VamanaSearchParameters | None = None, filter_stop: float = 0.0):
+    def search_filtered(self, queries, num_neighbors: int, is_member, search_parameters: VamanaSearchParameters | None = None, filter_stop: float = 0.0,
+                        filter_estimate_batch: bool = True):
         """Runtime VamanaIndex::search with an IDFilter (svsx_search_filtered; vamana_index_impl.h:140-218): `is_member` = boolean
         array over the ids.  Unfilled slots: id all-ones, distance +inf."""
         queries = np.ascontiguousarray(np.atleast_2d(queries))
@@ -214,8 +215,9 @@ class VamanaIndex:
         ids = np.empty((nq, num_neighbors), np.uint64)
         dists = np.empty((nq, num_neighbors), np.float32)
         sp = (search_parameters or self._params)._c()
-        _lib.check(_lib.lib().svsx_search_filtered(self._h, queries.ctypes.data, dtype_code(queries), nq, num_neighbors, C.byref(sp),
-                                                   bitmap.ctypes.data, float(filter_stop), ids.ctypes.data, dists.ctypes.data))
+        # filter_estimate_batch: SearchParams::filter_estimate_batch of the runtime (default true there and here)
+        _lib.check(_lib.lib().svsx_search_filtered_ex(self._h, queries.ctypes.data, dtype_code(queries), nq, num_neighbors, C.byref(sp),
+                                                      bitmap.ctypes.data, float(filter_stop), int(bool(filter_estimate_batch)), ids.ctypes.data, dists.ctypes.data))
         return QueryResult(ids, dists)
 
     def build_bound_codes(self, mode: int | bool = 1) -> None:

@@ -128,11 +128,76 @@ def should_stop_filtered_search(total_checked, found, filter_stop):
     return np.float32(found) / np.float32(total_checked) < np.float32(filter_stop)
 
 
+class _MT19937:
+    """std::mt19937 (the 32-bit Mersenne Twister with its standard seeding), for the mirror of sample_filter_hits below"""
+
+    def __init__(self, seed: int):
+        self.mt = [0] * 624
+        self.mt[0] = seed & 0xFFFFFFFF
+        for i in range(1, 624):
+            self.mt[i] = (1812433253 * (self.mt[i - 1] ^ (self.mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+        self.idx = 624
+
+    def __call__(self) -> int:
+        if self.idx >= 624:
+            mt = self.mt
+            for i in range(624):
+                y = (mt[i] & 0x80000000) | (mt[(i + 1) % 624] & 0x7FFFFFFF)
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+            self.idx = 0
+        y = self.mt[self.idx]
+        self.idx += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return y & 0xFFFFFFFF
+
+
+def _uniform_below(rng, n: int) -> int:
+    """std::uniform_int_distribution<size_t>(0, n - 1) over a 32-bit generator as libstdc++ >= 11 draws it for n <= 2^32 (bits/uniform_int_dist.h:
+    Lemire's nearly divisionless method on a 64-bit product) -- the library itself uses the std classes; tests/test_host_logic.py checks this
+    restatement against them"""
+    if n > (1 << 32):
+        raise NotImplementedError("more than 2^32 ids: not restated (the library uses the standard classes directly)")
+    if n == (1 << 32):
+        return rng()
+    product = rng() * n
+    low = product & 0xFFFFFFFF
+    if low < n:
+        threshold = ((1 << 32) - n) % n
+        while low < threshold:
+            product = rng() * n
+            low = product & 0xFFFFFFFF
+    return product >> 32
+
+
+def sample_filter_hits(member, total_ids: int, sample_size: int = 200):
+    """svs_runtime_utils.h:445-471 with is_valid == true: (checked, hits) over ids drawn by std::mt19937(42)"""
+    if total_ids == 0:
+        return 0, 0
+    target = min(sample_size, total_ids)
+    rng = _MT19937(42)
+    hits = checked = 0
+    for _ in range(target * 4):
+        if checked >= target:
+            break
+        hits += int(bool(member[_uniform_below(rng, total_ids)]))
+        checked += 1
+    return checked, hits
+
+
+def sample_size_for_filter_stop(filter_stop: float) -> int:
+    """svs_runtime_utils.h:477-482"""
+    return 200 if filter_stop <= 0 else max(200, int(np.float32(1.0) / np.float32(filter_stop)))
+
+
 def filtered_search(index, queries, k: int, is_member, search_parameters: VamanaSearchParameters | None = None,
-                    filter_stop: float = 0.0, extra_search_buffer_capacity: int | None = None, make_iterator=None) -> QueryResult:
-    """Runtime VamanaIndex::search with an IDFilter (vamana_index_impl.h:140-218) with filter_estimate_batch = false:
-    per query, pull adaptive batches from the iterator until k members of the filter are found.
-    `is_member`: boolean array over ids.  Unfilled slots: id all-ones, distance +inf."""
+                    filter_stop: float = 0.0, extra_search_buffer_capacity: int | None = None, make_iterator=None,
+                    filter_estimate_batch: bool = False) -> QueryResult:
+    """Runtime VamanaIndex::search with an IDFilter (vamana_index_impl.h:140-218): per query, pull adaptive batches from the iterator until
+    k members of the filter are found.  filter_estimate_batch (the runtime's default is True): the sampled hit rate decides whether to search at
+    all and the first batch size (:153-175).  `is_member`: boolean array over ids.  Unfilled slots: id all-ones, distance +inf."""
     queries = np.ascontiguousarray(np.atleast_2d(queries))
     nq = queries.shape[0]
     member = np.asarray(is_member, dtype=bool)
@@ -144,7 +209,13 @@ def filtered_search(index, queries, k: int, is_member, search_parameters: Vamana
     dists = np.full((nq, k), np.inf, np.float32)
     found = np.zeros(nq, np.int64)
     checked = np.zeros(nq, np.int64)
-    batch = np.full(nq, max(k, sws), np.int64)
+    initial = max(k, sws)
+    if filter_estimate_batch:
+        sampled, sample_hits = sample_filter_hits(member, max_batch, sample_size_for_filter_stop(filter_stop))
+        if should_stop_filtered_search(sampled, sample_hits, filter_stop):
+            return QueryResult(ids, dists)
+        initial = predict_further_processing(sampled, sample_hits, k, initial, max_batch)
+    batch = np.full(nq, initial, np.int64)
     active = np.ones(nq, bool)
     while active.any():
         for i in np.flatnonzero(active):

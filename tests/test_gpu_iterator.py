@@ -230,15 +230,23 @@ def test_range_and_filtered_search_on_gpu(svs, oracle, small_world):
         b = svs.filtered_search(fake, q, k, member, filter_stop=stop, make_iterator=_OracleBatchIterator)
         assert (a.indices == b.indices).all() and (_bits(a.distances) == _bits(b.distances)).all()
         # the same loop inside the library (svsx_search_filtered: the IDFilter argument of the runtime's batch operator)
-        c = idx.search_filtered(q, k, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), filter_stop=stop)
+        c = idx.search_filtered(q, k, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), filter_stop=stop, filter_estimate_batch=False)
         assert (c.indices == b.indices).all() and (_bits(c.distances) == _bits(b.distances)).all()
+    # SearchParams::filter_estimate_batch = true, the runtime's default (vamana_index_impl.h:153-175): the sampled hit rate (std::mt19937(42))
+    # sets the first batch size -- or answers everything with padding when it falls below filter_stop
+    sparse = (np.arange(sw["x"].shape[0]) % 40) == 0    # ~2.5 % of the ids: the estimate asks for a first batch of hundreds
+    for mem, k, stop in ((member, 10, 0.0), (sparse, 10, 0.0), (sparse, 5, 0.01), (sparse, 5, 0.2), (member, 25, 0.5)):
+        b = svs.filtered_search(fake, q, k, mem, filter_stop=stop, make_iterator=_OracleBatchIterator, filter_estimate_batch=True)
+        c = idx.search_filtered(q, k, mem, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), filter_stop=stop)   # default: estimate
+        assert (c.indices == b.indices).all() and (_bits(c.distances) == _bits(b.distances)).all(), (k, stop)
+    assert (c.indices == np.uint64(2**64 - 1)).all()     # 1/3 < 0.5: the sample alone stops the search
     # a filter nothing passes: every row padded; a filter with a handful of members: found through growing batches
     none = idx.search_filtered(q, 5, np.zeros(sw["x"].shape[0], bool), svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
     assert (none.indices == np.uint64(2**64 - 1)).all() and np.isposinf(none.distances).all()
     few = np.zeros(sw["x"].shape[0], bool)
     few[[3, 500, 900, 1400]] = True
     a = svs.filtered_search(idx, q, 3, few)
-    c = idx.search_filtered(q, 3, few, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
+    c = idx.search_filtered(q, 3, few, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), filter_estimate_batch=False)
     assert (a.indices == c.indices).all() and (c.indices != np.uint64(2**64 - 1)).all()
 
 
@@ -268,6 +276,6 @@ def test_filtered_search_with_buffers_beyond_lds(svs, oracle):
     want = svs.filtered_search(fake, q, 3, member, make_iterator=_OracleBatchIterator)
     got = svs.filtered_search(idx, q, 3, member)
     assert (got.indices == want.indices).all() and (_bits(got.distances) == _bits(want.distances)).all()
-    lib = idx.search_filtered(q, 3, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(4000)))
+    lib = idx.search_filtered(q, 3, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(4000)), filter_estimate_batch=False)
     assert (lib.indices == want.indices).all() and (_bits(lib.distances) == _bits(want.distances)).all()
     assert (want.indices[0] != np.uint64(2**64 - 1)).all()  # found, through buffers far beyond the LDS budget

@@ -64,7 +64,7 @@ def _search_both(svs, oracle, metric, fn, x, graph, entry, q, k, w, c, sq=None):
 
 
 @pytest.mark.parametrize("w,c,k", [(10, 10, 10), (32, 32, 10), (20, 40, 10), (128, 128, 10), (5, 5, 10), (64, 64, 64), (1, 1, 1),
-                                   (129, 129, 10), (200, 256, 20), (300, 300, 10), (512, 512, 50), (513, 600, 10), (1000, 1024, 100), (1025, 1100, 10)])
+                                   (129, 129, 10), (200, 256, 20), (300, 300, 10), (384, 384, 10), (260, 385, 10), (512, 512, 50), (513, 600, 10), (1000, 1024, 100), (1025, 1100, 10)])
 def test_search_f32_l2_bit_exact(svs, oracle, small_world, w, c, k):
     sw = small_world
     res, st, ids, dists, ost = _search_both(svs, oracle, L2, svs.DistanceL2(), sw["x"], sw["graph"], sw["entry"], sw["q"], k, w, c)

@@ -127,3 +127,32 @@ def test_tool_scripts_compile():
     assert len(files) >= 10
     for f in files:
         ast.parse(open(f).read(), filename=f)
+
+
+def test_filter_sampling_restatement_equals_the_standard_library(tmp_path):
+    """sample_filter_hits (svs_runtime_utils.h:445-471) draws ids with std::mt19937(42) through std::uniform_int_distribution<size_t>;
+    libsvsx uses those classes, the Python mirror restates them (iterator.py): same draws for every range, and the (checked, hits) pair and
+    the first batch size that follow from them"""
+    import os
+    import subprocess
+
+    from scalablevectorsearch_amd.iterator import (_MT19937, _uniform_below, predict_further_processing, sample_filter_hits,
+                                                   sample_size_for_filter_stop)
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "filter_sample")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(root, "tests", "cpp", "filter_sample.cpp"), "-o", exe])
+    for n in (1, 2, 3, 7, 200, 1500, 65536, 1_000_000, 12_500_000, (1 << 31) - 1, 1 << 32):
+        want = [int(v) for v in subprocess.run([exe, str(n), "800"], capture_output=True, text=True, check=True).stdout.split()]
+        rng = _MT19937(42)
+        assert [_uniform_below(rng, n) for _ in range(800)] == want, n
+    n = 1500
+    member = np.zeros(n, bool)
+    member[::7] = True
+    draws = [int(v) for v in subprocess.run([exe, str(n), "200"], capture_output=True, text=True, check=True).stdout.split()]
+    assert sample_filter_hits(member, n) == (200, int(member[draws].sum()))
+    assert sample_size_for_filter_stop(0.0) == 200 and sample_size_for_filter_stop(0.5) == 200
+    assert sample_size_for_filter_stop(0.001) == 999                       # static_cast<size_t>(1.0f / 0.001f): float32 arithmetic, as there
+    assert sample_filter_hits(np.ones(50, bool), 50, 200) == (50, 50)     # fewer ids than samples
+    assert predict_further_processing(200, 29, 10, 20, n) == 20            # enough hits already: the hint
+    assert predict_further_processing(200, 4, 10, 20, n) == 300            # (10 - 4) * 200 / 4

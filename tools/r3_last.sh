@@ -1,13 +1,17 @@
 #!/bin/bash
-# Round-3 last call: rehearsal of bench.py's N > 1 control flow on one GPU (2 ranks, gloo, both on device 0), then the driver's N = 1 command.
+# Round-3 last call: the filtered-search / iterator tests, the driver's N = 1 bench command, K7 before / after (round-2 tree vs this tree, same graphs),
+# config 4 shape at the windows around the 6-entries-per-lane merge level.
 set -u
 OUT=gpurun_out/r03_last
 mkdir -p $OUT
-SVSX_BENCH_SINGLE_DEVICE=1 SVSX_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rehearsal_2ranks.json 2> $OUT/rehearsal.err
-echo "rehearsal rc=$?"; cut -c1-1500 $OUT/rehearsal_2ranks.json; grep -v "amdgpu.ids\|^$" $OUT/rehearsal.err | tail -n 8 | cut -c1-300
+timeout 300 python -m pytest tests/test_gpu_iterator.py tests/test_abi.py -m gpu -q --timeout 200 > $OUT/tests.log 2>&1
+grep -E "passed|failed|error" $OUT/tests.log | tail -n 3
 python bench.py > $OUT/bench_1gpu.json 2> $OUT/bench.err
 python - <<'PY'
 import json
 j=json.load(open('gpurun_out/r03_last/bench_1gpu.json'))
-print(j['value'], j['ms_per_step'], j['config']['host_pointer']['median_ms'], j['config']['host_pointer']['over_device_resident'], j['roofline']['frac'], j['cpu_baseline']['gpu_over_cpu'], j['cpu_baseline']['gpu_over_full_host_if_linear'])
+print(j['value'], j['ms_per_step'], j['config']['host_pointer']['median_ms'], j['config']['host_pointer']['over_device_resident'], j['roofline']['frac'], j['roofline']['kernel_src_sha'], j['cpu_baseline']['gpu_over_cpu'])
 PY
+echo "== K7, this tree"; timeout 200 python tools/k7_ab.py --graph-cache /tmp/k7g 2>&1 | grep -v amdgpu.ids | tee $OUT/k7_r03.txt
+echo "== K7, round-2 tree"; timeout 200 python tools/k7_ab.py --graph-cache /tmp/k7g --tree variants/r02tree 2>&1 | grep -v amdgpu.ids | tee $OUT/k7_r02.txt
+timeout 300 python tools/window_sweep.py --n 2000000 --d 768 --dtype sq8 --metric cos --nq 4096 --latent 64 --degree 128 --build-window 200 --windows 256,320,384,512 --modes 2 2>/dev/null | cut -c1-300 | tee $OUT/c4_epl6.txt

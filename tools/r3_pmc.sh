@@ -1,11 +1,15 @@
 #!/bin/bash
-# Round-3 PMC evidence (one gpurun call): the three regimes of round 2 on the new kernel sources + configs 3 and 4.  Summaries afterwards, locally:
+# Round-3 PMC evidence (one gpurun call): the three regimes of round 2 on the final kernel sources + configs 3 and 4.  Summaries afterwards, locally:
 #   for t in r03_c2_w128 r03_c2_matched r03_c5shard r03_c3_w128 r03_c4_w512; do python tools/summarize_pmc.py $t; done
 set -u
+if [ "${1:-}" = "tests" ]; then
+  mkdir -p gpurun_out/r03_pmc
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_bound_codes.py tests/test_gpu_configs.py tests/test_gpu_iterator.py -m gpu -q --timeout 400 > gpurun_out/r03_pmc/tests.log 2>&1
+  grep -E "passed|failed|error" gpurun_out/r03_pmc/tests.log | tail -n 3
+fi
 tools/collect_pmc.sh r03_c2_w128 --n 1000000 --window 128 --codes 2
 tools/collect_pmc.sh r03_c2_matched --n 1000000 --window 128 --codes 2 --matched
 tools/collect_pmc.sh r03_c3_w128 --config c3 --n 1000000 --window 128 --codes 2
 tools/collect_pmc.sh r03_c4_w512 --config c4 --n 2000000 --nq 4096 --window 512 --codes 2
 tools/collect_pmc.sh r03_c5shard --config c5 --n 12500000 --window 128 --codes 2
-for t in r03_c2_w128 r03_c2_matched r03_c3_w128 r03_c4_w512 r03_c5shard; do echo "== $t"; cut -c1-400 gpurun_out/$t/target.json; tail -n 2 gpurun_out/$t/target.err | cut -c1-200; done
-du -sh gpurun_out
+for t in r03_c2_w128 r03_c2_matched r03_c3_w128 r03_c4_w512 r03_c5shard; do echo "== $t"; cut -c1-200 gpurun_out/$t/target.json; done
