@@ -376,8 +376,10 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
             const float dd = l2_row_distance_two_phase<DT, (DS > 64 && DS <= 128 && (DS & 15) == 0) ? DS : 96>(row, active, qf, sub, thr, rejected);
             n_early += __popcll(__ballot(active && rejected && sub == 0));
             return dd;
-        } else if constexpr (QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && DS == 0) {
-            // runtime dimension: progressive partial-distance rejection after every 64-element block
+        } else if constexpr (QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && (DS == 0 || (CODES == 0 && DS > 64))) {
+            // runtime dimension, and the plain static kernels of more than one 64-block that the two-phase form does not cover (100, 160, 200,
+            // 512, 768: `d` is a compile-time constant there): progressive partial-distance rejection after every 64-element block.  Without
+            // it the static forms were 8-13 % slower than round 2's runtime-d kernel on the same graphs (profiles/r03_notes.md section 8)
             bool rejected = false;
             float_row_distance<DT, METRIC, 0, false, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm, thr, &rejected);
             n_early += __popcll(__ballot(active && rejected && sub == 0));
