@@ -8,10 +8,12 @@
 //   svs::distance::DistanceL2 / DistanceIP / DistanceCosineSimilarity      core/distance/*.h (compare, implicit_broadcast)
 //   svs::ANNException                                                      lib/exception.h
 //   svs::index::vamana::BatchIterator (one per query of a batch)           index/vamana/iterator.h:81-339
+//   VamanaIndex::calibrate (search-buffer part), file readers, recall      svsx_io.hpp (index/vamana/calibrate.h, core/io/*.h, core/recall.h)
 // so that a caller written against the reference reads the same:  index.search(result.view(), queries, params).
 #pragma once
 
 #include "svsx.h"
+#include "svsx_io.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -171,6 +173,28 @@ template <typename T, typename Dist> class VamanaIndex {
     }
     const svsx_index* handle() const { return h_; }
     size_t size() const { uint64_t info[6]; check(svsx_index_info(h_, info)); return info[0]; }
+
+    // VamanaIndex::calibrate for the search-buffer parameters (index/vamana/calibrate.h:249-343,478-559): tunes this index's default search
+    // parameters so that recall@k against `groundtruth` (row stride gt_stride) reaches target_recall, and returns them.  Each probe is one
+    // batch search on the GPU.
+    template <typename Q, typename G>
+    VamanaSearchParameters calibrate(const Q* queries, size_t nq, const G* groundtruth, size_t gt_stride, size_t k, double target_recall,
+                                     const CalibrationParameters& cp = {}) {
+        VamanaSearchParameters start = cp.use_existing_parameter_values_ ? defaults_ : VamanaSearchParameters{};
+        if (cp.search_buffer_optimization_ == CalibrationParameters::SearchBufferOptimization::Disable) return start;
+        QueryResult<size_t> result(nq, k);
+        auto compute_recall = [&](size_t window, size_t capacity) {
+            VamanaSearchParameters p = start;
+            p.buffer_config_ = SearchBufferConfig(window, capacity);
+            search(result.view(), queries, p);
+            return k_recall_at_n(groundtruth, gt_stride, result.view().indices, k, nq, k, k);
+        };
+        const BufferChoice best = optimize_search_buffer(cp, start.buffer_config_.get_search_window_size(), start.buffer_config_.get_total_capacity(),
+                                                         k, target_recall, compute_recall);
+        start.buffer_config_ = SearchBufferConfig(best.window, best.capacity);
+        defaults_ = start;
+        return start;
+    }
 };
 
 // svs::Neighbor<size_t> as yielded by the iterator (core/query_result.h / lib/neighbor.h)

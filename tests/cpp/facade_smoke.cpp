@@ -2,7 +2,9 @@
 // is present, runs a tiny search: ring graph of 8 points on a line; the nearest neighbours of q are known.
 #include "svsx.hpp"
 
+#include <algorithm>
 #include <cstdio>
+#include <utility>
 #include <vector>
 
 int main(int argc, char**) {
@@ -53,6 +55,21 @@ int main(int argc, char**) {
             index2.search(filtered.view(), q2.data(), sp2, std::span<const uint64_t>(even.data(), even.size()));
             std::printf("filtered: %zu %zu %zu %zu\n", filtered.index(0, 0), filtered.index(0, 1), filtered.index(0, 2), filtered.index(0, 3));
             if (!(filtered.index(0, 0) == 40 && filtered.index(0, 1) == 42 && filtered.index(0, 2) == 38 && filtered.index(0, 3) == 44)) return 13;
+            // VamanaIndex::calibrate (search-buffer part, calibrate.h:249-343): exact top-4 by brute force as the groundtruth, target recall 1
+            std::vector<std::pair<float, size_t>> all;
+            for (size_t i = 0; i < n2; ++i) {
+                float dd = 0.0f;
+                for (size_t j = 0; j < d2; ++j) dd += (data2[i * d2 + j] - q2[j]) * (data2[i * d2 + j] - q2[j]);
+                all.emplace_back(dd, i);
+            }
+            std::sort(all.begin(), all.end());
+            const size_t gt[4] = {all[0].second, all[1].second, all[2].second, all[3].second};
+            const auto tuned = index2.calibrate(q2.data(), 1, gt, 4, 4, 1.0);
+            svsx::QueryResult<size_t> again(1, 4);
+            index2.search(again.view(), q2.data(), index2.get_search_parameters());
+            std::printf("calibrated: %zu %zu recall %.2f\n", tuned.buffer_config_.get_search_window_size(), tuned.buffer_config_.get_total_capacity(),
+                        svsx::k_recall_at_n(gt, 4, again.view().indices, 4, 1, 4, 4));
+            if (svsx::k_recall_at_n(gt, 4, again.view().indices, 4, 1, 4, 4) != 1.0) return 14;
         }
         // BatchIterator: 8 points on a ring, batches of 3 -> 5 6 4 | 7 3 2 | 1 0 | (done)
         svsx::BatchIterator<float> it(index, q.data(), 1);

@@ -124,4 +124,48 @@ def test_cxx_facade_search_on_gpu(lib, tmp_path):
     lines = out.stdout.splitlines()
     assert lines[0].split() == ["5", "6", "4"]
     assert lines[1].split() == ["filtered:", "40", "42", "38", "44"]                        # IDFilter overload, inline-record index
-    assert [ln.split()[2] for ln in lines[2:]] == ["5", "6", "4", "7", "3", "2", "1", "0"]  # BatchIterator, batches of 3
+    assert lines[2].split()[0] == "calibrated:" and lines[2].split()[-1] == "1.00"          # VamanaIndex::calibrate reaches recall 1 on the ring
+    assert [ln.split()[2] for ln in lines[3:]] == ["5", "6", "4", "7", "3", "2", "1", "0"]  # BatchIterator, batches of 3
+
+
+def test_cxx_io_recall_calibration_header(tmp_path):
+    """include/svsx_io.hpp -- the C++ host side of SURVEY 8(f) ranks 2 and 3 (file readers, recall, search-buffer calibration) -- against the
+    reference's own data files and the Python mirror (io.py, calibrate.py); no GPU involved"""
+    import subprocess
+
+    import numpy as np
+
+    from scalablevectorsearch_amd import io
+
+    exe = str(tmp_path / "io_smoke")
+    subprocess.check_call(["g++", "-std=c++20", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "io_smoke.cpp"), "-o", exe])
+    fv, sv = os.path.join(ROOT, "tests", "golden", "known_f32.fvecs"), os.path.join(ROOT, "tests", "golden", "known_f32.svs")
+    out = subprocess.run([exe, fv, sv, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = dict((ln.split()[0], ln.split()[1:]) for ln in out.stdout.splitlines())
+    a, b = io.read_fvecs(fv), io.read_svs_native(sv, np.float32)
+    assert lines["fvecs"][:2] == [str(a.shape[0]), str(a.shape[1])] and abs(float(lines["fvecs"][2]) - float(a.astype(np.float64).sum())) < 1e-6
+    assert lines["svs"][:2] == [str(b.shape[0]), str(b.shape[1])] and abs(float(lines["svs"][2]) - float(b.astype(np.float64).sum())) < 1e-6
+    assert lines["roundtrip"] == ["1"] and lines["ivecs"] == ["2", "3", "6"] and lines["entry"] == ["4711"]
+    assert abs(float(lines["recall"][0]) - 5.0 / 6.0) < 1e-6
+    # the same expectations as tests/test_host_logic.py holds for the Python optimize_search_buffer
+    assert lines["cal1"] == ["20", "20", "1", "1"] and lines["cal2"] == ["29", "0"] and lines["cal3"] == ["5", "10", "1"] and lines["cal4"] == ["10", "10"]
+    assert (io.read_svs_native(str(tmp_path / "rt.svs"), np.float32) == a).all()   # what the C++ writer wrote, read by the Python reader
+
+
+def test_cxx_search_index_cli_builds_and_checks_its_arguments(lib, tmp_path):
+    """tools/search_index.cpp (utils/search_index.cpp:89-178 over the C ABI) links against libsvsx.so; wrong argument counts and unknown
+    distance / type names are refused before anything touches a GPU"""
+    import subprocess
+
+    exe = str(tmp_path / "search_index")
+    pkg = os.path.join(ROOT, "scalablevectorsearch_amd")
+    subprocess.check_call(["g++", "-std=c++20", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "search_index.cpp"),
+                           "-o", exe, "-L", pkg, "-lsvsx", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"])
+    bad = subprocess.run([exe, "float"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Expected 11 arguments" in bad.stdout
+    args = ["float", "float", "q.fvecs", "32", "10", "4", "cfg", "graph", "data", "res"]
+    bad = subprocess.run([exe] + args + ["Manhattan"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "Unsupported distance type" in bad.stderr
+    bad = subprocess.run([exe, "float16"] + args[1:] + ["L2"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "Unsupported Query and Data type pair" in bad.stderr

@@ -552,6 +552,15 @@ def test_search_index_cli_round_trip(svs, oracle, small_world, tmp_path):
     assert (got == ids).all()
     bad = subprocess.run([sys.executable, "-m", "scalablevectorsearch_amd.search_index", "float"], cwd=root, capture_output=True, text=True)
     assert bad.returncode == 1 and "Expected 11 arguments" in bad.stdout
+    # the same program in C++ over the C ABI and include/svsx_io.hpp (tools/search_index.cpp): the same answer file
+    exe = str(tmp_path / "search_index")
+    pkg = os.path.join(root, "scalablevectorsearch_amd")
+    subprocess.check_call(["g++", "-std=c++20", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "search_index.cpp"),
+                           "-o", exe, "-L", pkg, "-lsvsx", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, "float", "float", str(tmp_path / "q.fvecs"), "32", "10", "4", str(tmp_path / "config"), str(tmp_path / "graph"),
+                          str(tmp_path / "data"), str(tmp_path / "res_cxx"), "L2"], capture_output=True, text=True)
+    assert out.returncode == 0 and "Global search time" in out.stdout, out.stdout + out.stderr
+    assert (io.read_ivecs(str(tmp_path / "res_cxx_idx.ivecs")) == ids).all()
 
 
 def test_malformed_graph_is_rejected(svs):
