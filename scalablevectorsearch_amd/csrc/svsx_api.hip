@@ -237,7 +237,7 @@ int validate_common(int metric, int dtype, size_t n, size_t d) {
 extern "C" {
 
 const char* svsx_last_error(void) { return g_error.c_str(); }
-const char* svsx_version(void) { return "svsx 0.2.0 (gfx950)"; }
+const char* svsx_version(void) { return "svsx 0.3.0 (gfx950)"; }
 const char* svsx_last_kernel_info(void) { return last_search_instantiation(); }
 
 int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
