@@ -84,6 +84,31 @@ def test_no_silent_cpu_fallback(lib):
     assert ei.value.code == lib.RUNTIME_ERROR
 
 
+def test_round3_entry_points_check_their_arguments_before_any_device_work(lib):
+    """svsx_sharded_*, svsx_vamana_build_device / svsx_find_medoid_device, svsx_search_filtered_ex: null handles and inconsistent shapes are
+    refused with the runtime's error codes (api_defs.h:110-117) on a box without a GPU too"""
+    L = lib.lib()
+    h = C.c_void_p()
+    one = (C.c_void_p * 1)(None)
+    assert L.svsx_sharded_create(None, 0, None, 0, 1, C.byref(h)) == lib.INVALID_ARGUMENT             # no shards
+    assert L.svsx_sharded_create(one, 1, None, 0, 1, C.byref(h)) == lib.NOT_INITIALIZED               # a null shard
+    assert b"Index not initialized" in L.svsx_last_error()
+    assert L.svsx_sharded_create(one, 1, None, 3, 2, C.byref(h)) == lib.INVALID_ARGUMENT              # rank outside the world
+    assert L.svsx_sharded_create(one, 1, None, 0, 1, None) == lib.INVALID_ARGUMENT
+    assert L.svsx_sharded_search_device(None, None, 0, 1, 1, None, None, None, None) == lib.NOT_INITIALIZED
+    assert L.svsx_sharded_unique_id(None) == lib.INVALID_ARGUMENT
+    L.svsx_sharded_destroy(None)                                                                      # a no-op, like free(NULL)
+    bp = lib.BuildParams(1.2, 64, 128, 750, 60, 1)
+    assert L.svsx_vamana_build_device(None, C.byref(bp), None) == lib.NOT_INITIALIZED
+    m = C.c_uint32(0)
+    assert L.svsx_find_medoid_device(None, C.byref(m)) == lib.NOT_INITIALIZED
+    q = np.zeros((1, 4), np.float32)
+    ids = np.zeros((1, 1), np.uint64)
+    d = np.zeros((1, 1), np.float32)
+    assert L.svsx_search_filtered_ex(None, q.ctypes.data, 0, 1, 1, None, None, 0.0, 1, ids.ctypes.data, d.ctypes.data) == lib.NOT_INITIALIZED
+    assert L.svsx_version().startswith(b"svsx 0.3")
+
+
 def test_product_does_not_import_the_oracle():
     """The oracle is test infrastructure: nothing under scalablevectorsearch_amd/ may include, import, link or call it."""
     pkg = os.path.join(ROOT, "scalablevectorsearch_amd")
