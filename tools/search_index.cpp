@@ -14,20 +14,14 @@
 
 namespace {
 const char* HELP = R"(
-The required arguments are as follows:
-(1) Query Element Type (string). Options: (int8, uint8, float)
-(2) Data Element Type (string). Options: (int8, uint8, float, float16)
-(3) Query File Path (string). Supported extensions: (.fvecs, .bvecs, .ivecs)
-(4) Search Window Size (integer)
-(5) Number of neighbors to recall (integer)
-(6) Number of threads (integer; ignored: the batch runs on the GPU)
-(7) Config directory (string)
-(8) Graph directory (string)
-(9) Data directory (string)
-(10) Result prefix (string)
-(11) Distance type (string - distance type)
+  search_index <query type> <data type> <queries.[fbi]vecs> <search window size> <neighbours> <threads (ignored)>
+               <config dir | svs_config.toml> <graph dir | blob.svs> <data dir | blob.svs> <result prefix> <L2 | MIP | Cosine>
 
-Valid Distance Types: (L2, MIP, Cosine)
+  query type   int8 | uint8 | float            element type the queries are converted to
+  data type    int8 | uint8 | float | float16  element type of the saved dataset
+  config       where VamanaIndex::save put svs_config.toml (the entry point is read from it)
+  graph, data  SVS native v1 blobs (a directory is searched for its single *.svs file)
+  result       <prefix>_idx.ivecs receives one row of neighbour ids per query
 )";
 
 std::string blob(const std::string& path) {
