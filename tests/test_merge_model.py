@@ -57,7 +57,7 @@ def test_merge_equals_sequential_inserts_and_ties_cover_duplicates(oracle, seed)
         cands = []
         dup_used = False
         for _ in range(int(rng.integers(1, 9))):
-            if buf and rng.random() < 0.15:
+            if buf and rng.random() < 0.04:
                 e = buf[int(rng.integers(0, len(buf)))]
                 cands.append((e[0], e[1]))
                 dup_used = True
