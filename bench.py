@@ -120,7 +120,8 @@ def _emit(line: str):
 def kernel_src_sha() -> str:
     """Hash of the device-code sources: a PMC summary is only reused for the kernels it was measured on."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "scalablevectorsearch_amd", "csrc", "*.h*"))):
+    csrc = os.path.join(ROOT, "scalablevectorsearch_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):  # real sources only (no *.orig, *.o)
         if os.path.basename(f) != "svsx_api.hip":  # host-side C ABI: no device code
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -434,18 +435,18 @@ def main():
     import ctypes as C
 
     from scalablevectorsearch_amd import _lib
-    from scalablevectorsearch_amd.sharded import packed_views
+    from scalablevectorsearch_amd.sharded import packed_views, slot_words
 
     m = nq * k
+    sw = slot_words(nq, k)
     stats = torch.zeros((local_shards, nq, 6), dtype=torch.int32, device=device)
-    # per local shard one packed buffer [nq*k f32 distances | nq*k i64 ids]; the search kernel writes straight into it
-    shard_buf = torch.empty((local_shards, 3 * m), dtype=torch.int32, device=device)
+    # per local shard one packed buffer [nq*k i64 ids | nq*k f32 distances]; the search kernel writes straight into it
+    shard_buf = torch.zeros((local_shards, sw), dtype=torch.int32, device=device)
     sh_d, sh_i = packed_views(shard_buf, local_shards, nq, k)
-    loc_buf = torch.empty(3 * m, dtype=torch.int32, device=device) if local_shards > 1 else shard_buf[0]
-    loc_d = loc_buf[:m].view(torch.float32).view(nq, k)
-    loc_i = loc_buf[m:].view(torch.int64).view(nq, k)
+    loc_buf = torch.zeros(sw, dtype=torch.int32, device=device) if local_shards > 1 else shard_buf[0]
+    loc_d, loc_i = (v[0] for v in packed_views(loc_buf, 1, nq, k))
     if multi:
-        all_buf = torch.empty(world * 3 * m, dtype=torch.int32, device=device)
+        all_buf = torch.empty(world * sw, dtype=torch.int32, device=device)
         all_d, all_i = packed_views(all_buf, world, nq, k)
         out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=device)

@@ -178,12 +178,14 @@ int svsx_merge_topk_strided_device(
 /* Sharded search (new design -- the reference has no sharded mode, the closest anchor is its partition of the queries over
  * threads, index/vamana/index.h:571-574).  One object per process / GPU.  This rank's `n_local` shards are the global shards
  * rank * n_local + s in order (contiguous id ranges: svsx_index_desc.id_offset); every rank passes the same query batch.  Per call:
- * search every local shard, merge them locally, ONE ncclAllGather (RCCL over xGMI) of nq * k * 12 bytes per rank, world-way merge --
+ * search every local shard, merge them locally, ONE ncclAllGather (RCCL over xGMI) of nq * k * 12 bytes per rank (per chunk), world-way merge --
  * ties -> lower shard, then position, so the answer equals one merge over all shards in shard order and is identical on every rank.
  *   svsx_sharded_unique_id         ncclGetUniqueId (128 bytes): rank 0 makes it, the host program hands it to every rank
  *   svsx_sharded_create            joins the communicator (ncclCommInitRank; collective).  id128 == NULL with world == 1: no exchange step
  *   svsx_sharded_create_with_comm  for hosts that already own an ncclComm_t (not destroyed with the object)
- *   svsx_sharded_search_device     device pointers, enqueued on hip_stream; nq * k must be even
+ *   svsx_sharded_search_device     device pointers, enqueued on hip_stream (internal streams join it before the call's work ends); any nq, k.
+ *                                  Calls on one object are serialised and chained, whatever streams they are made on.  Batches of >= 8 192
+ *                                  queries are exchanged in two chunks: the all-gather + merge of the first runs under the second's search
  *   svsx_sharded_info              info[0] local shards, [1] world, [2] rank, [3] 1 when a communicator is attached
  * RCCL is loaded at run time (librccl.so.1); without it only world == 1 / id128 == NULL objects can be created. */
 typedef struct svsx_sharded svsx_sharded;
@@ -307,6 +309,14 @@ int svsx_index_build_bound_codes(svsx_index* index, int mode);
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),
  * [5]=data row stride (bytes). */
 int svsx_index_info(const svsx_index* index, uint64_t info[6]);
+
+/* Which search kernel serves eligible batches (no reference counterpart; result-neutral -- ids and distance bits are identical either way).
+ *   0  auto (default): two queries per wavefront for batches larger than one resident generation of the one-query kernel (6 144 queries)
+ *   1  always one query per wavefront
+ *   2  two queries per wavefront whenever the search is eligible: 32-byte inline records, float32 / float16 rows of d = 96 or 128 under
+ *      L2 / inner product, search buffers of <= 128 entries, max degree <= 64, at most 8 entry points, no history / cancel side channel
+ * svsx_last_kernel_info names the kernel that served the last call ("search_kernel_2q<...>" / "search_kernel<...>"). */
+int svsx_index_set_kernel_policy(svsx_index* index, int policy);
 
 /* Status::message() (api_defs.h:119-184): text of the last failure on this thread. */
 const char* svsx_last_error(void);

@@ -78,9 +78,10 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
 
 // BIG: search buffers of 129 .. 512 (BIG = 1) and 513 .. 1024 entries (BIG = 2) get their own instantiations, so that the 4- / 8- /
 // 16-entries-per-lane merge does not raise the register count (= lower the occupancy) of the common window <= 128 kernels
+// search_one: the search of ONE query by ONE wavefront, with `smem` the wave's LDS slice.  The kernel below calls it for query
+// blockIdx.x; the two-query kernel (svsx_search_2q.h) calls it for the rare query it hands back (non-finite distances).
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0>
-__global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const SearchArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t qi, unsigned char* smem) {
     constexpr bool GREATER = METRIC != M_L2;
     // CODES: 0 none, 1 128-byte code rows (svsx_distance.hip), 2 / 3 / 4 graph-inline records of 32 / 64 / 128 bytes (svsx_codes.hip)
     constexpr bool FAT = CODES >= 2;
@@ -92,7 +93,6 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     constexpr int RPP = 64 / G;                        // rows per pass
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t qi = blockIdx.x;
     const int d = DS > 0 ? DS : static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
 
@@ -499,6 +499,9 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
 
     // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
     int cancel_seen = 0;
+#if defined(SVSX_DIAG) && SVSX_DIAG == 3
+    const uint32_t diag_tloop = static_cast<uint32_t>(wall_clock64()); // tools/diag_prologue.py: where a query's time goes outside the expansions
+#endif
     while (!wave_done(buf)) {
         if (a.cancel != nullptr) { // greedy_search.h:155: `if (cancel()) return;` -- the word read here is consumed one expansion later
             if (cancel_seen != 0) break;
@@ -853,6 +856,9 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
         if constexpr (EARLY) asm volatile("" ::"v"(early_sink), "v"(early_sink2)); // keeps the request; vmcnt is in order, the rows requested later have arrived by now
     }
 
+#if defined(SVSX_DIAG) && SVSX_DIAG == 3
+    const uint32_t diag_tloop_end = static_cast<uint32_t>(wall_clock64());
+#endif
     if constexpr (GENERAL) {
         if (it_meta != nullptr) {
             // ---- save the buffer for the next call; copy_from_scratch (iterator.h:104-124): the best entries not yet
@@ -940,14 +946,67 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
 #if SVSX_DIAG == 2
             for (int i = 1; i <= 5; ++i) st[i] = ph_acc[i]; // [0] stays the expansion count; ph_acc[0] = between expansions (loop control)
 #endif
+#if SVSX_DIAG == 3
+            st[2] = diag_tloop;      // wall_clock64 (100 MHz) when the main loop starts / ends; [4] / [5] = wave start / end
+            st[3] = diag_tloop_end;
+            // where the wave ran: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [14:13] ...) | XCC_ID << 28
+            st[1] = (static_cast<uint32_t>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) & 0x0FFFFFFFu) | (static_cast<uint32_t>(__builtin_amdgcn_s_getreg((3 << 11) | 20)) << 28);
+#endif
 #endif
         }
         if (a.history_len != nullptr) a.history_len[qi] = n_exp;
     }
 }
 
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0>
+__global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const SearchArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    search_one<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>(a, blockIdx.x, smem);
+}
+
+} // namespace svsx
+
+#include "svsx_search_2q.h"
+
+namespace svsx {
+
 // ---------------------------------------------------------------------------------------------------------------
 char* last_search_instantiation_buffer(); // thread-local, 96 bytes (svsx_search.hip)
+
+// The two-query kernel (svsx_search_2q.h) serves: 32-byte inline records, float rows of d = 96 / 128 under L2 / inner product, buffers of
+// <= 128 entries, one adjacency chunk, 1..8 entry points (all of them kept by push_back), no side channels.  kernel_policy (svsx.h:
+// svsx_index_set_kernel_policy): 0 = batches that do not fit one resident generation of the one-query kernel, 1 = never, 2 = whenever eligible.
+constexpr uint32_t kOneQueryResident = 6144; // 256 CUs x 4 SIMDs x 6 waves of the one-query inline-record kernels (profiles/r03_notes.md section 3)
+static inline bool twoq_eligible(const SearchArgs& a) {
+    if (a.kernel_policy == 1u) return false;
+    if (a.fat == nullptr || a.fat_rb != 32u || a.general != 0u) return false;
+    if (a.capacity > 128u || a.gstride > 64u || a.n_entry == 0u || a.n_entry > 8u || a.n_entry > a.capacity) return false;
+    if (a.history_ids != nullptr || a.history_dists != nullptr || a.history_len != nullptr || a.cancel != nullptr || a.q_ready != nullptr || a.it_meta != nullptr) return false;
+    return a.kernel_policy == 2u || a.nq > kOneQueryResident;
+}
+
+// default visited filter of the two-query kernel: 1 024 exact 16-bit tags (2 KB) per query -- what keeps two queries of d <= 128 within the
+// 7 680 bytes of LDS that let 20 waves = 40 queries share a CU; grown while the tags would not identify the id.  An explicit size is kept.
+static inline uint32_t twoq_filter_entries(const SearchArgs& a) {
+    if (a.filter_entries == 0u || a.filter_auto == 0u) return a.filter_entries;
+    uint32_t fe = 1024u;
+    while (fe <= 16384u && (a.n >> __builtin_ctz(fe)) >= 0xFFFFu) fe <<= 1;
+    return fe <= 16384u ? fe : 0u;
+}
+
+template <int DT, int METRIC, int DS> static hipError_t launch_2q(const SearchArgs& a0, hipStream_t stream) {
+    SearchArgs a = a0;
+    a.filter_entries = twoq_filter_entries(a0);
+    a.filter_tag8 = 0u;
+    const int epl = a.capacity <= 32u ? 1 : a.capacity <= 64u ? 2 : 4;
+    const size_t lds = 2u * static_cast<size_t>(twoq_half_bytes(epl, DS, a.filter_entries));
+    snprintf(last_search_instantiation_buffer(), 96, "search_kernel_2q<dt=%d,metric=%d,qmode=0,ds=%d,epl=%d,general=0,codes=2>", DT, METRIC, DS, epl);
+    const dim3 grid((a.nq + 1u) / 2u), block(64);
+    if (epl == 1) hipLaunchKernelGGL((search_kernel_2q<DT, METRIC, DS, 1>), grid, block, lds, stream, a);
+    else if (epl == 2) hipLaunchKernelGGL((search_kernel_2q<DT, METRIC, DS, 2>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((search_kernel_2q<DT, METRIC, DS, 4>), grid, block, lds, stream, a);
+    return hipGetLastError();
+}
 
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
     if constexpr (!GENERAL && BIG == 0) {
@@ -986,6 +1045,12 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
     if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
+    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && (METRIC == M_L2 || METRIC == M_IP)) {
+        if ((a.d == 96u || a.d == 128u) && twoq_eligible(a)) {
+            if (2u * static_cast<size_t>(twoq_half_bytes(a.capacity <= 32u ? 1u : a.capacity <= 64u ? 2u : 4u, a.d, twoq_filter_entries(a))) <= 64u * 1024u) // else: an explicit filter size too large for two queries
+                return a.d == 96u ? launch_2q<DT, METRIC, 96>(a, stream) : launch_2q<DT, METRIC, 128>(a, stream);
+        }
+    }
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         // static dimensions: the reference's list (distance_core.h:31-32: 64, 96, 100, 128, 160, 200, 512, 768, Dynamic)
         if (a.fat != nullptr && a.fat_rb == 32) {

@@ -3,11 +3,17 @@
 // the QUERIES over threads, index/vamana/index.h:571-574); a C++ host needs nothing but libsvsx.so and an RCCL communicator.
 //
 // One object per process / GPU.  This rank's shards are global shards rank * n_local + s (contiguous id ranges, svsx_index_desc.id_offset).
-//   1. svsx_search_device on every local shard, writing (distances | 64-bit global ids) straight into its slot of the packed send buffer
-//   2. n_local > 1: local merge (ties -> lower shard, then position) into the rank's slot        svsx::merge_kernel
-//   3. world > 1: ONE ncclAllGather of nq * k * 12 bytes per rank (1.2 MB at 10 000 x 10: latency-bound, no ring tuning)
+// Per chunk of the query batch (one chunk, or two for batches of >= 8 192 queries when an exchange follows):
+//   1. svsx_search_device on every local shard, writing (64-bit global ids | distances) straight into its slot of the packed buffer;
+//      several local shards alternate between two internal streams, so the drain of one shard's launch overlaps the start of the next
+//   2. n_local > 1: local merge (ties -> lower shard, then position) into the rank's send slot   svsx::merge_kernel
+//   3. world > 1: ONE ncclAllGather of the chunk's slot per rank (1.2 MB at 10 000 x 10: latency-bound, no ring tuning)
 //   4. world-way merge with the same tie rule = one global merge over all shards in shard order  svsx::merge_kernel
-// all on the caller's stream.  RCCL is resolved at run time (dlopen "librccl.so.1": inside a PyTorch process that is the copy torch
+// Steps 3-4 of a chunk run on an internal stream while the caller's stream searches the next chunk; the caller's stream joins at the end,
+// so the call is still "enqueued on hip_stream".  Slot layout [m u64 ids | m f32 distances], padded to 16 bytes: any nq * k.
+// The staging buffers belong to the object: calls are serialised by a mutex and chained through an event, so calls on different
+// streams (or a reallocation) never touch staging an earlier call still uses.
+// RCCL is resolved at run time (dlopen "librccl.so.1": inside a PyTorch process that is the copy torch
 // already loaded), so libsvsx.so itself has no link-time dependency on it and single-GPU users never load it.
 #include "../../include/svsx.h"
 
@@ -24,7 +30,7 @@
 
 namespace svsx {
 int set_error(int code, const char* fmt, ...);                      // svsx_api.hip: thread-local text behind svsx_last_error
-void index_facts(const svsx_index* ix, int* metric, int* device);   // svsx_api.hip
+void index_facts(const svsx_index* ix, int* metric, int* device, size_t* d); // svsx_api.hip
 } // namespace svsx
 
 namespace {
@@ -67,24 +73,52 @@ constexpr int kNcclChar = 0; // ncclInt8 / ncclChar (rccl.h ncclDataType_t)
 
 } // namespace
 
+constexpr int kMaxChunks = 2;
+
 struct svsx_sharded {
     std::vector<const svsx_index*> shards;
     int metric = 0, device = 0, rank = 0, world = 1;
+    size_t d = 0;
     void* comm = nullptr;   // ncclComm_t
     bool owns_comm = false;
-    // packed staging, grown on demand: per slot [nq * k f32 | nq * k u64]
-    void* d_local = nullptr;  size_t local_cap = 0;   // n_local slots (only when n_local > 1)
-    void* d_send = nullptr;   size_t send_cap = 0;    // 1 slot
-    void* d_recv = nullptr;   size_t recv_cap = 0;    // world slots
+    // packed staging, grown on demand: per slot [m u64 | m f32] (16-byte padded), one region per chunk
+    void* d_local = nullptr;  size_t local_cap = 0;   // n_local slots per chunk (only when n_local > 1)
+    void* d_send = nullptr;   size_t send_cap = 0;    // 1 slot per chunk
+    void* d_recv = nullptr;   size_t recv_cap = 0;    // world slots per chunk
+    // serialisation of calls and the internal streams / events of the pipeline
+    std::mutex mu;
+    hipStream_t side[2] = {nullptr, nullptr};  // local shard searches alternate between them; side[0] also carries a chunk's exchange
+    hipEvent_t ev_start = nullptr, ev_join[2] = {nullptr, nullptr}, ev_ready[kMaxChunks] = {nullptr, nullptr}, ev_done[kMaxChunks] = {nullptr, nullptr};
+    hipEvent_t ev_last = nullptr;              // end of the previous call (staging reuse across streams)
+    bool have_last = false;
 };
 
 namespace {
 
-int grow(void*& p, size_t& cap, size_t want) {
+int grow(svsx_sharded* s, void*& p, size_t& cap, size_t want) {
     if (want <= cap) return SVSX_SUCCESS;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (p) {
+        if (s->have_last) (void)hipEventSynchronize(s->ev_last); // an earlier call may still be reading the old buffer
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
     if (hipMalloc(&p, want) != hipSuccess) return svsx::set_error(SVSX_RUNTIME_ERROR, "hipMalloc(%zu) for the shard lists failed", want);
     cap = want;
+    return SVSX_SUCCESS;
+}
+
+int make_pipeline(svsx_sharded* s) {
+    if (s->ev_last) return SVSX_SUCCESS;
+    bool ok = true;
+    for (hipStream_t& st : s->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    auto ev = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+    ev(s->ev_start);
+    for (hipEvent_t& e : s->ev_join) ev(e);
+    for (hipEvent_t& e : s->ev_ready) ev(e);
+    for (hipEvent_t& e : s->ev_done) ev(e);
+    ev(s->ev_last);
+    if (!ok) return svsx::set_error(SVSX_RUNTIME_ERROR, "could not create the streams / events of the sharded search");
     return SVSX_SUCCESS;
 }
 
@@ -99,9 +133,10 @@ int create_common(const svsx_index* const* local_shards, size_t n_local, int ran
     for (size_t i = 0; i < n_local; ++i) {
         if (!local_shards[i]) { delete s; return svsx::set_error(SVSX_NOT_INITIALIZED, "shard %zu: Index not initialized", i); }
         int metric = 0, device = 0;
-        svsx::index_facts(local_shards[i], &metric, &device);
-        if (i == 0) { s->metric = metric; s->device = device; }
-        else if (metric != s->metric || device != s->device) { delete s; return svsx::set_error(SVSX_INVALID_ARGUMENT, "the shards of a rank share one metric and one device"); }
+        size_t d = 0;
+        svsx::index_facts(local_shards[i], &metric, &device, &d);
+        if (i == 0) { s->metric = metric; s->device = device; s->d = d; }
+        else if (metric != s->metric || device != s->device || d != s->d) { delete s; return svsx::set_error(SVSX_INVALID_ARGUMENT, "the shards of a rank share one metric, one dimension and one device"); }
         s->shards.push_back(local_shards[i]);
     }
     s->rank = rank;
@@ -159,6 +194,8 @@ void svsx_sharded_destroy(svsx_sharded* s) {
     if (s->d_local) (void)hipFree(s->d_local);
     if (s->d_send) (void)hipFree(s->d_send);
     if (s->d_recv) (void)hipFree(s->d_recv);
+    for (hipStream_t st : s->side) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : {s->ev_start, s->ev_join[0], s->ev_join[1], s->ev_ready[0], s->ev_ready[1], s->ev_done[0], s->ev_done[1], s->ev_last}) if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -179,34 +216,89 @@ int svsx_sharded_search_device(
     if (k == 0) return svsx::set_error(SVSX_INVALID_ARGUMENT, "k must be greater than 0");
     if (nq == 0) return SVSX_SUCCESS;
     if (!d_queries || !d_ids64 || !d_dists) return svsx::set_error(SVSX_INVALID_ARGUMENT, "null argument");
-    if ((nq * k) % 2 != 0) return svsx::set_error(SVSX_INVALID_ARGUMENT, "nq * k must be even (8-byte alignment of the packed ids)");
+    static const size_t esize[4] = {4, 2, 1, 1};
+    if (q_dtype < 0 || q_dtype > 3) return svsx::set_error(SVSX_INVALID_ARGUMENT, "unknown query dtype %d", q_dtype);
     if (hipSetDevice(s->device) != hipSuccess) return svsx::set_error(SVSX_RUNTIME_ERROR, "hipSetDevice(%d) failed", s->device);
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (int rc = make_pipeline(s)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const size_t m = nq * k, slot = m * 12; // [m f32 | m u64]
     const size_t n_local = s->shards.size();
     const bool exchange = s->world > 1 || s->comm != nullptr;
-    auto dist_of = [&](void* base, size_t i) { return reinterpret_cast<float*>(static_cast<unsigned char*>(base) + slot * i); };
-    auto ids_of = [&](void* base, size_t i) { return reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(base) + slot * i + m * 4); };
-    // where this rank's merged list goes: the send slot when an exchange follows, else straight to the caller
+    const size_t q_row = s->d * esize[q_dtype];
+    // chunks of the batch: the exchange + world merge of chunk c runs under the searches of chunk c + 1
+    const int nchunk = (exchange && nq >= 8192) ? 2 : 1;
+    size_t lo[kMaxChunks + 1], slot[kMaxChunks], off[kMaxChunks + 1];
+    off[0] = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        lo[c] = nq * static_cast<size_t>(c) / nchunk;
+        lo[c + 1] = nq * static_cast<size_t>(c + 1) / nchunk;
+        slot[c] = ((lo[c + 1] - lo[c]) * k * 12 + 15) & ~size_t(15); // [m u64 | m f32]
+        off[c + 1] = off[c] + slot[c];
+    }
+    const size_t all = off[nchunk];
     if (exchange) {
-        if (int rc = grow(s->d_send, s->send_cap, slot)) return rc;
-        if (int rc = grow(s->d_recv, s->recv_cap, slot * static_cast<size_t>(s->world))) return rc;
+        if (int rc = grow(s, s->d_send, s->send_cap, all)) return rc;
+        if (int rc = grow(s, s->d_recv, s->recv_cap, all * static_cast<size_t>(s->world))) return rc;
     }
-    float* own_d = exchange ? dist_of(s->d_send, 0) : d_dists;
-    uint64_t* own_i = exchange ? ids_of(s->d_send, 0) : d_ids64;
-    if (n_local == 1) {
-        if (int rc = svsx_search_device(s->shards[0], d_queries, q_dtype, nq, k, params, own_i, nullptr, own_d, nullptr, stream)) return rc;
-    } else {
-        if (int rc = grow(s->d_local, s->local_cap, slot * n_local)) return rc;
-        for (size_t i = 0; i < n_local; ++i)
-            if (int rc = svsx_search_device(s->shards[i], d_queries, q_dtype, nq, k, params, ids_of(s->d_local, i), nullptr, dist_of(s->d_local, i), nullptr, stream)) return rc;
-        if (int rc = svsx_merge_topk_strided_device(s->metric, n_local, nq, k, dist_of(s->d_local, 0), slot / 4, ids_of(s->d_local, 0), slot / 8, own_d, own_i, stream)) return rc;
+    if (n_local > 1)
+        if (int rc = grow(s, s->d_local, s->local_cap, all * n_local)) return rc;
+#define SH_TRY(expr)                                                                                                         \
+    do {                                                                                                                     \
+        hipError_t e_ = (expr);                                                                                              \
+        if (e_ != hipSuccess) return svsx::set_error(SVSX_RUNTIME_ERROR, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+    // the staging may still be in use by the previous call (made on another stream): chain behind it
+    if (s->have_last) SH_TRY(hipStreamWaitEvent(stream, s->ev_last, 0));
+    const bool fan_out = n_local > 1;
+    if (fan_out || nchunk > 1) {
+        SH_TRY(hipEventRecord(s->ev_start, stream));
+        for (hipStream_t st : s->side) SH_TRY(hipStreamWaitEvent(st, s->ev_start, 0));
     }
-    if (!exchange) return SVSX_SUCCESS;
     Rccl& r = rccl();
-    const int rc = r.AllGather(s->d_send, s->d_recv, slot, kNcclChar, s->comm, stream);
-    if (rc != 0) return svsx::set_error(SVSX_RUNTIME_ERROR, "ncclAllGather failed: %s", r.GetErrorString(rc));
-    return svsx_merge_topk_strided_device(s->metric, static_cast<size_t>(s->world), nq, k, dist_of(s->d_recv, 0), slot / 4, ids_of(s->d_recv, 0), slot / 8, d_dists, d_ids64, stream);
+    for (int c = 0; c < nchunk; ++c) {
+        const size_t rows = lo[c + 1] - lo[c], m = rows * k;
+        const unsigned char* q = static_cast<const unsigned char*>(d_queries) + lo[c] * q_row;
+        auto ids_of = [&](void* base, size_t region_slots, size_t i) {  // slot i of chunk c in a staging buffer holding `region_slots` slots per chunk
+            return reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(base) + off[c] * region_slots + slot[c] * i);
+        };
+        auto dist_of = [&](void* base, size_t region_slots, size_t i) { return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ids_of(base, region_slots, i)) + m * 8); };
+        // where this rank's merged list of the chunk goes: the send slot when an exchange follows, else straight to the caller's rows
+        uint64_t* own_i = exchange ? ids_of(s->d_send, 1, 0) : d_ids64 + lo[c] * k;
+        float* own_d = exchange ? dist_of(s->d_send, 1, 0) : d_dists + lo[c] * k;
+        if (!fan_out) {
+            if (int rc = svsx_search_device(s->shards[0], q, q_dtype, rows, k, params, own_i, nullptr, own_d, nullptr, stream)) return rc;
+        } else {
+            for (size_t i = 0; i < n_local; ++i)
+                if (int rc = svsx_search_device(s->shards[i], q, q_dtype, rows, k, params, ids_of(s->d_local, n_local, i), nullptr, dist_of(s->d_local, n_local, i), nullptr, s->side[i & 1])) return rc;
+            for (int j = 0; j < 2; ++j) {
+                SH_TRY(hipEventRecord(s->ev_join[j], s->side[j]));
+                SH_TRY(hipStreamWaitEvent(stream, s->ev_join[j], 0));
+            }
+            if (int rc = svsx_merge_topk_strided_device(s->metric, n_local, rows, k, dist_of(s->d_local, n_local, 0), slot[c] / 4, ids_of(s->d_local, n_local, 0), slot[c] / 8, own_d, own_i, stream)) return rc;
+        }
+        if (!exchange) continue;
+        // exchange + world-way merge.  One local shard, two chunks: on an internal stream, so that the caller's stream goes straight on to the
+        // search of the next chunk.  With local fan-out the searches already run on the internal streams (the next chunk's are not held up
+        // by anything queued here), so the exchange stays on the caller's stream.
+        hipStream_t xs = stream;
+        if (nchunk > 1 && !fan_out) {
+            xs = s->side[0];
+            SH_TRY(hipEventRecord(s->ev_ready[c], stream));
+            SH_TRY(hipStreamWaitEvent(xs, s->ev_ready[c], 0));
+        }
+        const int rc = r.AllGather(ids_of(s->d_send, 1, 0), ids_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c], kNcclChar, s->comm, xs);
+        if (rc != 0) return svsx::set_error(SVSX_RUNTIME_ERROR, "ncclAllGather failed: %s", r.GetErrorString(rc));
+        if (int rc2 = svsx_merge_topk_strided_device(s->metric, static_cast<size_t>(s->world), rows, k, dist_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c] / 4,
+                                                     ids_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c] / 8, d_dists + lo[c] * k, d_ids64 + lo[c] * k, xs))
+            return rc2;
+        if (xs != stream) SH_TRY(hipEventRecord(s->ev_done[c], xs));
+    }
+    if (exchange && nchunk > 1 && !fan_out) // the caller's stream joins the exchanges only now: every search is already queued in front
+        for (int c = 0; c < nchunk; ++c) SH_TRY(hipStreamWaitEvent(stream, s->ev_done[c], 0));
+    SH_TRY(hipEventRecord(s->ev_last, stream));
+    s->have_last = true;
+#undef SH_TRY
+    return SVSX_SUCCESS;
 }
 
 } // extern "C"

@@ -44,14 +44,19 @@ def hip_merge(metric: int, gathered_d, gathered_i, k: int):
     return out_d, out_i
 
 
+def slot_words(nq: int, k: int) -> int:
+    """int32 words of one packed shard list [nq*k i64 ids | nq*k f32 distances], padded to 8 bytes (any nq * k; the layout svsx_sharded.hip uses)."""
+    return (3 * nq * k + 1) & ~1
+
+
 def packed_views(buf, world: int, nq: int, k: int):
-    """Views into a packed (distances | ids) buffer of `world` shards: int32 [world, 3*nq*k] -> (f32 [world,nq,k], i64 [world,nq,k])."""
+    """Views into a packed (ids | distances) buffer of `world` shards: int32 [world * slot_words] -> (f32 [world,nq,k], i64 [world,nq,k])."""
     import torch
 
     m = nq * k
-    b = buf.view(world, 3 * m)
-    d = b[:, :m].view(torch.float32).view(world, nq, k)
-    i = b[:, m:].view(torch.int64).view(world, nq, k)
+    b = buf.view(world, slot_words(nq, k))
+    i = b[:, : 2 * m].view(torch.int64).view(world, nq, k)
+    d = b[:, 2 * m : 3 * m].view(torch.float32).view(world, nq, k)
     return d, i
 
 
@@ -80,14 +85,13 @@ class ShardedSearcher:
         if self.world == 1:
             return self.merge(self.metric, d_local[None], i_local[None], k)
         nq = d_local.shape[0]
-        m = nq * k
-        if (m * 4) % 8:
-            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "nq * k must be even (8-byte alignment of the packed ids)")
-        # one packed buffer per shard -> ONE collective: [nq*k f32 distances | nq*k i64 ids] as 3*nq*k int32 words
-        loc = torch.empty(3 * m, dtype=torch.int32, device=d_local.device)
-        loc[:m].view(torch.float32).copy_(d_local.reshape(-1))
-        loc[m:].view(torch.int64).copy_(i_local.reshape(-1))
-        allb = torch.empty(self.world * 3 * m, dtype=torch.int32, device=d_local.device)
+        # one packed buffer per shard -> ONE collective: [nq*k i64 ids | nq*k f32 distances] (+ padding to 8 bytes) as int32 words
+        w = slot_words(nq, k)
+        loc = torch.zeros(w, dtype=torch.int32, device=d_local.device)
+        loc_d, loc_i = packed_views(loc, 1, nq, k)
+        loc_d[0].copy_(d_local)
+        loc_i[0].copy_(i_local)
+        allb = torch.empty(self.world * w, dtype=torch.int32, device=d_local.device)
         dist.all_gather_into_tensor(allb, loc, group=self.group)
         all_d, all_i = packed_views(allb, self.world, nq, k)
         return self.merge(self.metric, all_d, all_i, k)
@@ -131,15 +135,13 @@ class PipelinedShardSearch:
         import torch
         import torch.distributed as dist
 
-        if (nq * k * 4) % 8:
-            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, "nq * k must be even (8-byte alignment of the packed ids)")
         self.index, self.metric, self.nq, self.k, self.group = index, int(metric), nq, k, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = dist.is_initialized()
-        m = nq * k
+        w = slot_words(nq, k)
         self.depth = depth
-        self.loc = [torch.empty(3 * m, dtype=torch.int32, device=device) for _ in range(depth)]
-        self.allb = [torch.empty(self.world * 3 * m, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.loc = [torch.zeros(w, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.allb = [torch.empty(self.world * w, dtype=torch.int32, device=device) for _ in range(depth)]
         self.out_d = [torch.empty((nq, k), dtype=torch.float32, device=device) for _ in range(depth)]
         self.out_i = [torch.empty((nq, k), dtype=torch.int64, device=device) for _ in range(depth)]
         self.s_merge = torch.cuda.Stream(device=device)
@@ -153,15 +155,14 @@ class PipelinedShardSearch:
 
         slot = self.n % self.depth
         self.n += 1
-        m = self.nq * self.k
         cur = torch.cuda.current_stream(d_queries.device)
         if self.used[slot]:
             cur.wait_event(self.ev_done[slot])  # the merge that last read this buffer set has finished
         loc = self.loc[slot]
         if events is not None:
             events[0].record(cur)
-        self.index.search_device(d_queries, self.k, search_parameters, d_ids64=loc[m:].view(torch.int64).view(self.nq, self.k),
-                                 d_dists=loc[:m].view(torch.float32).view(self.nq, self.k))
+        loc_d, loc_i = packed_views(loc, 1, self.nq, self.k)
+        self.index.search_device(d_queries, self.k, search_parameters, d_ids64=loc_i[0], d_dists=loc_d[0])
         if events is not None:
             events[1].record(cur)
         self.ev_search[slot].record(cur)

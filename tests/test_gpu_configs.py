@@ -198,10 +198,11 @@ def test_native_sharded_search_in_the_library(svs, oracle, single_rank_comm):
     base = (1 << 32) + 777
     q = deep_like(nq, d, 24, seed=98)
     q[1] = q[0]
-    indexes, want_d, want_i = [], [], []
+    indexes, want_d, want_i, shard_inputs = [], [], [], []
     for s in range(S):
         x = deep_like(n, d, 24, seed=300 + (s % 2))   # shards 0 and 2 hold the SAME vectors: every distance ties across shards
         g, e = oracle.build_vamana(L2, x, R=24, L=40)
+        shard_inputs.append((x, g, e))
         idx = svs.VamanaIndex(g, x, svs.DistanceL2(), e, id_offset=s * base)
         if s == 1:
             idx.build_bound_codes(2)
@@ -218,8 +219,20 @@ def test_native_sharded_search_in_the_library(svs, oracle, single_rank_comm):
         torch.cuda.synchronize()
         assert (mi.cpu().numpy() == wi).all() and (_bits(md.cpu().numpy()) == _bits(wd)).all()
     assert int(mi.max()) > (1 << 32)
-    with pytest.raises(svs.SvsxError):
-        ns.search(torch.from_numpy(q[:3]).cuda(), 1, sp)   # nq * k odd: refused, the packed ids would be misaligned
+    # odd nq * k (the slot layout is [ids | distances] padded to 16 bytes: nothing is refused), on another stream than the call before,
+    # then a batch that grows the staging while the previous call may still be in flight
+    side = torch.cuda.Stream()
+    for rows, kk in ((3, 1), (5, 3), (len(q), 7)):
+        oi_, od_ = [], []
+        for s in range(S):
+            x_, g_, e_ = shard_inputs[s]
+            a_i, a_d = oracle.search(L2, x_, g_, e_, q[:rows], kk, 48)
+            oi_.append(a_i.astype(np.int64) + s * base)
+            od_.append(a_d)
+        wd2, wi2 = merge_topk_ref(L2, np.stack(od_), np.stack(oi_), kk)
+        md, mi = ns.search(torch.from_numpy(q[:rows]).cuda(), kk, sp, stream=side.cuda_stream)
+        side.synchronize()
+        assert (mi.cpu().numpy() == wi2).all() and (_bits(md.cpu().numpy()) == _bits(wd2)).all(), (rows, kk)
     ns.close()
 
 
