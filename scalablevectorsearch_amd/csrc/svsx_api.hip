@@ -386,7 +386,7 @@ int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
 
 int svsx_index_set_kernel_policy(svsx_index* ix, int policy) {
     if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
-    if (policy < 0 || policy > 2) return fail(SVSX_INVALID_ARGUMENT, "kernel policy %d: 0 auto, 1 one query per wave, 2 two queries per wave", policy);
+    if (policy < 0 || policy > 3) return fail(SVSX_INVALID_ARGUMENT, "kernel policy %d: 0 auto, 1 one query per wave, 2 two queries per wave (SIMT halves), 3 two queries per wave (interleaved)", policy);
     ix->kernel_policy.store(policy, std::memory_order_relaxed);
     return SVSX_SUCCESS;
 }

@@ -1,4 +1,5 @@
-"""The two-queries-per-wavefront kernel (csrc/svsx_search_2q.h; svsx_index_set_kernel_policy): ids, distance bits and the tracker counts
+"""The two-queries-per-wavefront kernels (csrc/svsx_search_x2.h: interleaved, policy 3 and the auto policy's choice for large batches;
+csrc/svsx_search_2q.h: SIMT halves, policy 2; svsx_index_set_kernel_policy): ids, distance bits and the tracker counts
 (expansions, neighbour slots) must equal the oracle's and the one-query kernel's on everything the kernel is eligible for -- every buffer
 level (1 / 2 / 4 entries per lane), split buffers, both filter settings, odd batches, half-filled adjacency rows, several entry
 points, exact ties and duplicate vectors, and non-finite distances (which hand the query back to the one-query routine)."""
@@ -40,10 +41,12 @@ def _check(svs, oracle, metric, x, graph, entry, q, configs=CONFIGS, expect_2q=T
     for w, c, k, vis in configs:
         sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis)
         ids, dists, ost = oracle.search(metric, x, graph, entry, q, k, w, c, visited_set=bool(vis), stats=True)
-        for policy in (2, 1):
+        for policy in (3, 2, 1):
             idx.set_kernel_policy(policy)
             res, st = idx.search(q, k, sp, stats=True)
             info = idx.last_kernel_info()
+            if policy == 3:  # the interleaved kernel takes everything the SIMT form takes, and any number (<= 16) of entry points
+                assert info.startswith("search_kernel_x2<") and info.endswith("codes=2>"), info
             if policy == 2 and expect_2q:
                 assert info.startswith("search_kernel_2q<") and info.endswith("codes=2>"), info
                 n2q += 1
@@ -173,7 +176,7 @@ def test_auto_policy_picks_two_query_kernel_for_large_batches(svs, oracle, small
         idx.search_device(dq, 10, sp, d_ids64=ids, d_dists=dd)
         torch.cuda.synchronize()
         out[policy] = (ids.cpu().numpy(), dd.cpu().numpy(), idx.last_kernel_info())
-    assert out[0][2].startswith("search_kernel_2q<") and out[1][2].startswith("search_kernel<"), (out[0][2], out[1][2])
+    assert out[0][2].startswith("search_kernel_x2<") and out[1][2].startswith("search_kernel<"), (out[0][2], out[1][2])
     assert (out[0][0] == out[1][0]).all() and (_bits(out[0][1]) == _bits(out[1][1])).all()
     oi, od = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], q[:300], 10, 64, 64, visited_set=True)
     assert (out[0][0][:300] == oi.astype(np.int64)).all() and (_bits(out[0][1][:300]) == _bits(od)).all()
