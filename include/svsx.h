@@ -310,17 +310,6 @@ int svsx_index_build_bound_codes(svsx_index* index, int mode);
  * [5]=data row stride (bytes). */
 int svsx_index_info(const svsx_index* index, uint64_t info[6]);
 
-/* Which search kernel serves eligible batches (no reference counterpart; result-neutral -- ids and distance bits are identical either way).
- * Eligible: 32-byte inline records, float32 / float16 rows of d = 96 or 128 under L2 / inner product, search buffers of <= 128 entries, max
- * degree <= 64, no history / cancel side channel.
- *   0  auto (default): two interleaved queries per wavefront for batches larger than one resident generation of the one-query kernel
- *      (6 144 queries), one query per wavefront otherwise
- *   1  always one query per wavefront
- *   2  two queries per wavefront as 32-lane halves (SIMT form; at most 8 entry points; slower -- kept as a measured experiment)
- *   3  two interleaved queries per wavefront whenever the search is eligible
- * svsx_last_kernel_info names the kernel that served the last call ("search_kernel_x2<...>" / "search_kernel_2q<...>" / "search_kernel<...>"). */
-int svsx_index_set_kernel_policy(svsx_index* index, int policy);
-
 /* Status::message() (api_defs.h:119-184): text of the last failure on this thread. */
 const char* svsx_last_error(void);
 

@@ -53,8 +53,6 @@ struct svsx_index {
     uint32_t fat_rb = 32;
     float* d_pca = nullptr;      // [32][dpad] leading directions (float32, row-major, zero padded) | [dpad] mean | [32] bias
     float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_delta = 0.0f, pca_eq_abs = 0.0f, pca_ref_extra = 0.0f;
-    // svsx_index_set_kernel_policy: 0 auto, 1 one query per wave, 2 two queries per wave whenever the search is eligible
-    std::atomic<int> kernel_policy{0};
     // host-pointer calls (svsx_search): persistent staging contexts, one per concurrent caller (HostCallContext below)
     mutable std::mutex ctx_mutex;
     mutable std::vector<struct HostCallContext*> ctx_free;
@@ -381,13 +379,6 @@ int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
     info[3] = ix->gstride * ix->n * sizeof(uint32_t);
     info[4] = ix->gstride;
     info[5] = ix->row_bytes;
-    return SVSX_SUCCESS;
-}
-
-int svsx_index_set_kernel_policy(svsx_index* ix, int policy) {
-    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
-    if (policy < 0 || policy > 3) return fail(SVSX_INVALID_ARGUMENT, "kernel policy %d: 0 auto, 1 one query per wave, 2 two queries per wave (SIMT halves), 3 two queries per wave (interleaved)", policy);
-    ix->kernel_policy.store(policy, std::memory_order_relaxed);
     return SVSX_SUCCESS;
 }
 
@@ -788,7 +779,6 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     a.q_row_bytes = q_row_bytes;
     a.nq = static_cast<uint32_t>(nq);
     a.general = ix->n_entry > 16 ? 1u : 0u; // std::sort of > 16 entry points is not a stable insertion sort
-    a.kernel_policy = static_cast<uint32_t>(ix->kernel_policy.load(std::memory_order_relaxed));
     if (ix->d_codes && !a.general) { // result-neutral lower-bound rejection (float queries on float32 L2 rows)
         a.codes = static_cast<const unsigned char*>(ix->d_codes);
         a.code_scale = ix->code_scale;
@@ -864,7 +854,6 @@ static int search_common(
         }
         // tags must identify the id exactly: grow the table until (n >> log2 entries) < 0xFFFF, else stay off
         default_filter(ix, a, fe);
-        a.filter_auto = params->visited_set == 1 ? 1u : 0u;
     }
     a.ids64 = d_ids64;
     a.ids32 = d_ids32;

@@ -526,101 +526,6 @@ __device__ __forceinline__ void float_row_distance_bc(
     else out_nrm = 0.0f;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The same two row routines cut in two -- row_issue requests every byte of the lane's share of a row, row_finish does the arithmetic --
-// for the kernel that keeps the rows of TWO queries in flight (svsx_search_x2.h): between the halves the wave works on the other query.
-// Static dimension, whole 16-blocks, L2 / inner product.  The arithmetic is float_row_distance's (f32 rows, slot-cyclic) and
-// float_row_distance_bc's (f16 rows, block-cyclic) operation for operation, so the distance bits are the same.
-template <int DT, int DS> struct RowData;
-template <int DS> struct RowData<DT_F32, DS> { float4 x[DS >> 4]; };  // block i: this lane's four lane-slots
-template <int DS> struct RowData<DT_F16, DS> {
-    static constexpr int N64 = DS >> 6, NT = (DS >> 4) - 4 * (DS >> 6);
-    BlockRaw<DT_F16> blk[N64 > 0 ? N64 : 1];  // blocks 4 t + sub
-    BlockRaw<DT_F16> tail[NT > 0 ? NT : 1];   // the remaining full blocks, read by all four lanes of the group
-};
-
-template <int DT, int DS> __device__ __forceinline__ void row_issue(const unsigned char* __restrict__ row, int sub, RowData<DT, DS>& r) {
-    static_assert(DS > 0 && (DS & 15) == 0, "static dimension, whole 16-blocks");
-    if constexpr (DT == DT_F32) {
-#pragma unroll
-        for (int i = 0; i < (DS >> 4); ++i) r.x[i] = *reinterpret_cast<const float4*>(row + sub * 16 + i * 64);
-    } else {
-        static_assert(DT == DT_F16, "row_issue: f32 / f16 rows");
-        constexpr int N64 = DS >> 6, NB = DS >> 4;
-#pragma unroll
-        for (int t = 0; t < N64; ++t) {
-            r.blk[t].v[0] = *reinterpret_cast<const uint4*>(row + 32 * (4 * t + sub));
-            r.blk[t].v[1] = *reinterpret_cast<const uint4*>(row + 32 * (4 * t + sub) + 16);
-        }
-#pragma unroll
-        for (int b = 4 * N64; b < NB; ++b) {
-            r.tail[b - 4 * N64].v[0] = *reinterpret_cast<const uint4*>(row + 32 * b);
-            r.tail[b - 4 * N64].v[1] = *reinterpret_cast<const uint4*>(row + 32 * b + 16);
-        }
-    }
-}
-
-template <int DT, int METRIC, int DS>
-__device__ __forceinline__ float row_finish(const RowData<DT, DS>& r, const float* __restrict__ qf, int sub) {
-    static_assert(METRIC == M_L2 || METRIC == M_IP, "row_finish: L2 / inner product");
-    float unused = 0.0f;
-    if constexpr (DT == DT_F32) { // float_row_distance<DT_F32, METRIC, DS, false>, static-dimension branch
-        constexpr int SB64 = (DS >> 6) * 4, SB1 = DS >> 4;
-        const float* lane_q = qf + sub * 4;
-        float s[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) zero_chunk<4>(s[j]);
-        auto step = [&](int i, float (&acc)[4]) {
-            const float4 q = *reinterpret_cast<const float4*>(lane_q + i * 16);
-            acc_step<METRIC>(acc[0], unused, q.x, r.x[i].x);
-            acc_step<METRIC>(acc[1], unused, q.y, r.x[i].y);
-            acc_step<METRIC>(acc[2], unused, q.z, r.x[i].z);
-            acc_step<METRIC>(acc[3], unused, q.w, r.x[i].w);
-        };
-        if constexpr (SB64 > 0) {
-#pragma unroll
-            for (int i = 0; i < SB64; ++i) step(i, s[i & 3]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[0][e] = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
-        }
-#pragma unroll
-        for (int i = SB64; i < SB1; ++i) step(i, s[0]);
-        return reduce_slots<4>(s[0]);
-    } else { // float_row_distance_bc<DT_F16, METRIC, DS, false>, static-dimension branch
-        constexpr int N64 = DS >> 6, NB = DS >> 4;
-        float s[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.0f;
-        auto accumulate = [&](int c, const BlockRaw<DT_F16>& raw) {
-            float x[16];
-            block_to_float<DT_F16>(raw, x);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 qv = *reinterpret_cast<const float4*>(qf + 16 * c + 4 * g4);
-                const float q[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc_step<METRIC>(s[4 * g4 + b], unused, q[b], x[4 * g4 + b]);
-            }
-        };
-        if constexpr (N64 > 0) {
-#pragma unroll
-            for (int t = 0; t < N64; ++t) accumulate(4 * t + sub, r.blk[t]);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = add_xor2f(add_xor1f(s[e]));
-        }
-#pragma unroll
-        for (int b = 4 * N64; b < NB; ++b) accumulate(b, r.tail[b - 4 * N64]);
-        float t[8], u[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = s[j + 8] + s[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] = t[j + 4] + t[j];
-        const float w0 = u[0] + u[2];
-        const float w1 = u[1] + u[3];
-        return w0 + w1;
-    }
-}
-
 #ifndef SVSX_F16_BLOCK_CYCLIC
 #define SVSX_F16_BLOCK_CYCLIC 1
 #endif

@@ -28,8 +28,6 @@ struct SearchArgs {
     uint32_t window, capacity, k;
     uint32_t filter_entries;  // 0 = no visited filter; else power of two (exact-tag direct-mapped filter in LDS)
     uint32_t filter_tag8;     // 1: 8-bit tags (host guarantees (n >> log2 entries) < 255), 0: 16-bit tags
-    uint32_t filter_auto;     // 1: the caller asked for "the default filter": a kernel may substitute its own default size (result-neutral)
-    uint32_t kernel_policy;   // svsx_index_set_kernel_policy: 0 auto, 1 one query per wave, 2 two queries per wave whenever eligible
     // outputs
     uint64_t* ids64;
     uint32_t* ids32;

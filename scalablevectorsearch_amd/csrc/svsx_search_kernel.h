@@ -78,8 +78,8 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
 
 // BIG: search buffers of 129 .. 512 (BIG = 1) and 513 .. 1024 entries (BIG = 2) get their own instantiations, so that the 4- / 8- /
 // 16-entries-per-lane merge does not raise the register count (= lower the occupancy) of the common window <= 128 kernels
-// search_one: the search of ONE query by ONE wavefront, with `smem` the wave's LDS slice.  The kernel below calls it for query
-// blockIdx.x; the two-query kernel (svsx_search_2q.h) calls it for the rare query it hands back (non-finite distances).
+// search_one: the search of ONE query by ONE wavefront, with `smem` the wave's LDS slice (the kernel below calls it for query blockIdx.x;
+// the two-queries-per-wave experiments of round 4, experiments/r4_two_queries_per_wave/, called it for queries they handed back).
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0>
 __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t qi, unsigned char* smem) {
     constexpr bool GREATER = METRIC != M_L2;
@@ -964,64 +964,8 @@ __global__ __launch_bounds__(64) SVSX_KERNEL_ATTR void search_kernel(const Searc
     search_one<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>(a, blockIdx.x, smem);
 }
 
-} // namespace svsx
-
-#include "svsx_search_2q.h"
-#include "svsx_search_x2.h"
-
-namespace svsx {
-
 // ---------------------------------------------------------------------------------------------------------------
 char* last_search_instantiation_buffer(); // thread-local, 96 bytes (svsx_search.hip)
-
-// The two-query kernel (svsx_search_2q.h) serves: 32-byte inline records, float rows of d = 96 / 128 under L2 / inner product, buffers of
-// <= 128 entries, one adjacency chunk, 1..8 entry points (all of them kept by push_back), no side channels.  kernel_policy (svsx.h:
-// svsx_index_set_kernel_policy): 0 = batches that do not fit one resident generation of the one-query kernel, 1 = never, 2 = whenever eligible.
-constexpr uint32_t kOneQueryResident = 6144; // 256 CUs x 4 SIMDs x 6 waves of the one-query inline-record kernels (profiles/r03_notes.md section 3)
-// what both two-query kernels need: 32-byte inline records, buffers of <= 128 entries, one adjacency chunk, no side channels
-static inline bool pair_eligible(const SearchArgs& a) {
-    if (a.fat == nullptr || a.fat_rb != 32u || a.general != 0u) return false;
-    if (a.capacity > 128u || a.gstride > 64u || a.n_entry == 0u) return false;
-    if (a.history_ids != nullptr || a.history_dists != nullptr || a.history_len != nullptr || a.cancel != nullptr || a.q_ready != nullptr || a.it_meta != nullptr) return false;
-    return true;
-}
-// the SIMT form (svsx_search_2q.h; policy 2 only -- measured slower than the one-query kernel, kept as the record of that experiment)
-static inline bool twoq_eligible(const SearchArgs& a) { return a.kernel_policy == 2u && pair_eligible(a) && a.n_entry <= 8u && a.n_entry <= a.capacity; }
-// the interleaved form (svsx_search_x2.h): policy 3 always, policy 0 for batches that do not fit one resident generation of the one-query kernel
-static inline bool x2_eligible(const SearchArgs& a) { return pair_eligible(a) && (a.kernel_policy == 3u || (a.kernel_policy == 0u && a.nq > kOneQueryResident)); }
-
-// default visited filter of the two-query kernel: 1 024 exact 16-bit tags (2 KB) per query -- what keeps two queries of d <= 128 within the
-// 7 680 bytes of LDS that let 20 waves = 40 queries share a CU; grown while the tags would not identify the id.  An explicit size is kept.
-static inline uint32_t twoq_filter_entries(const SearchArgs& a) {
-    if (a.filter_entries == 0u || a.filter_auto == 0u) return a.filter_entries;
-    uint32_t fe = 1024u;
-    while (fe <= 16384u && (a.n >> __builtin_ctz(fe)) >= 0xFFFFu) fe <<= 1;
-    return fe <= 16384u ? fe : 0u;
-}
-
-template <int DT, int METRIC, int DS> static hipError_t launch_2q(const SearchArgs& a0, hipStream_t stream) {
-    SearchArgs a = a0;
-    a.filter_entries = twoq_filter_entries(a0);
-    a.filter_tag8 = 0u;
-    const int epl = a.capacity <= 32u ? 1 : a.capacity <= 64u ? 2 : 4;
-    const size_t lds = 2u * static_cast<size_t>(twoq_half_bytes(epl, DS, a.filter_entries));
-    snprintf(last_search_instantiation_buffer(), 96, "search_kernel_2q<dt=%d,metric=%d,qmode=0,ds=%d,epl=%d,general=0,codes=2>", DT, METRIC, DS, epl);
-    const dim3 grid((a.nq + 1u) / 2u), block(64);
-    if (epl == 1) hipLaunchKernelGGL((search_kernel_2q<DT, METRIC, DS, 1>), grid, block, lds, stream, a);
-    else if (epl == 2) hipLaunchKernelGGL((search_kernel_2q<DT, METRIC, DS, 2>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((search_kernel_2q<DT, METRIC, DS, 4>), grid, block, lds, stream, a);
-    return hipGetLastError();
-}
-
-template <int DT, int METRIC, int DS> static hipError_t launch_x2(const SearchArgs& a0, hipStream_t stream) {
-    SearchArgs a = a0;
-    a.filter_entries = twoq_filter_entries(a0);
-    a.filter_tag8 = 0u;
-    const size_t lds = 2u * static_cast<size_t>(x2_query_bytes(DS, a.filter_entries));
-    snprintf(last_search_instantiation_buffer(), 96, "search_kernel_x2<dt=%d,metric=%d,qmode=0,ds=%d,general=0,codes=2>", DT, METRIC, DS);
-    hipLaunchKernelGGL((search_kernel_x2<DT, METRIC, DS>), dim3((a.nq + 1u) / 2u), dim3(64), lds, stream, a);
-    return hipGetLastError();
-}
 
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0> static hipError_t launch_one(const SearchArgs& a, hipStream_t stream) {
     if constexpr (!GENERAL && BIG == 0) {
@@ -1060,14 +1004,6 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
     if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
-    if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16) && (METRIC == M_L2 || METRIC == M_IP)) {
-        if ((a.d == 96u || a.d == 128u) && x2_eligible(a) && 2u * static_cast<size_t>(x2_query_bytes(a.d, twoq_filter_entries(a))) <= 64u * 1024u)
-            return a.d == 96u ? launch_x2<DT, METRIC, 96>(a, stream) : launch_x2<DT, METRIC, 128>(a, stream);
-        if ((a.d == 96u || a.d == 128u) && twoq_eligible(a)) {
-            if (2u * static_cast<size_t>(twoq_half_bytes(a.capacity <= 32u ? 1u : a.capacity <= 64u ? 2u : 4u, a.d, twoq_filter_entries(a))) <= 64u * 1024u) // else: an explicit filter size too large for two queries
-                return a.d == 96u ? launch_2q<DT, METRIC, 96>(a, stream) : launch_2q<DT, METRIC, 128>(a, stream);
-        }
-    }
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         // static dimensions: the reference's list (distance_core.h:31-32: 64, 96, 100, 128, 160, 200, 512, 768, Dynamic)
         if (a.fat != nullptr && a.fat_rb == 32) {

@@ -226,11 +226,6 @@ class VamanaIndex:
         record size; mode 1 (True): 128-byte code row per vector (float rows, L2, d = 96 / 128); 0 (False): off."""
         _lib.check(_lib.lib().svsx_index_build_bound_codes(self._h, int(mode)))
 
-    def set_kernel_policy(self, policy: int) -> None:
-        """svsx_index_set_kernel_policy: 0 auto, 1 one query per wavefront, 2 two queries per wavefront whenever the search is eligible
-        (result-neutral: ids and distance bits are the same either way)."""
-        _lib.check(_lib.lib().svsx_index_set_kernel_policy(self._h, int(policy)))
-
     def last_kernel_info(self) -> str:
         """svsx_last_kernel_info: which search-kernel instantiation the last search on this thread launched."""
         return _lib.lib().svsx_last_kernel_info().decode()

@@ -18,7 +18,6 @@ x = deep_like_device(a.n, d, 24, 1, dev)
 graph, entry = build_vamana_device(x, a.n, d, svs.DistanceL2(), VamanaBuildParameters(alpha=1.2, graph_max_degree=R, window_size=2 * R, prune_to=R - 4))
 idx = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), torch.tensor([entry], dtype=torch.int32, device=dev), a.n, d, np.float32)
 idx.build_bound_codes(2)
-idx.set_kernel_policy(1)
 for nq in [int(v) for v in a.nq.split(",")]:
     q = deep_like_device(nq, d, 24, 2, dev)
     ids = torch.empty((nq, k), dtype=torch.int64, device=dev); dists = torch.empty((nq, k), device=dev); stats = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
