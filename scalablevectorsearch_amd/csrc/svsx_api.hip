@@ -37,6 +37,7 @@ struct svsx_index {
     size_t n_entry = 0;
     int sq_enabled = 0;
     float sq_scale = 1.0f, sq_bias = 0.0f;
+    float* d_sq_row_norm = nullptr; // scalar-quantized rows under cosine: sqrtf(||decompressed row||^2), reference order (launch_sq_row_norms)
     int device = 0;
     uint64_t id_offset = 0;
     bool owns = true;
@@ -242,6 +243,18 @@ const char* svsx_last_error(void) { return g_error.c_str(); }
 const char* svsx_version(void) { return "svsx 0.3.0 (gfx950)"; }
 const char* svsx_last_kernel_info(void) { return last_search_instantiation(); }
 
+// CosineSimilarityCompressed divides by the norm of the decompressed row (scalar.h:175-184, cosine.h:334-335): a property of the row alone,
+// computed once here by the search kernel's own accumulation routine (same bits) instead of once per candidate and query
+static int build_sq_row_norms(svsx_index* ix) {
+    if (!ix->sq_enabled || ix->metric != M_COS || ix->n == 0) return SVSX_SUCCESS;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_sq_row_norm), ix->n * sizeof(float)));
+    hipError_t e = launch_sq_row_norms(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), ix->sq_scale, ix->sq_bias,
+                                       ix->d_sq_row_norm, nullptr);
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "row-norm kernel failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipDeviceSynchronize());
+    return SVSX_SUCCESS;
+}
+
 int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
     if (!desc || !out) return fail(SVSX_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
@@ -288,6 +301,7 @@ int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
     if (hipMemcpy2D(ix->d_data, ix->row_bytes, desc->data, src_stride, desc->d * es, desc->n, hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail(SVSX_RUNTIME_ERROR, "copying data to the device failed"));
 
+    if (int rc = build_sq_row_norms(ix)) return cleanup(rc);
     if (flat_only) {
         *out = ix;
         return SVSX_SUCCESS;
@@ -350,6 +364,8 @@ int svsx_index_create_device_view(const svsx_device_index_desc* desc, svsx_index
     ix->device = desc->device;
     ix->id_offset = desc->id_offset;
     ix->owns = false;
+    if (hipSetDevice(ix->device) != hipSuccess) { delete ix; return fail(SVSX_RUNTIME_ERROR, "hipSetDevice(%d) failed", desc->device); }
+    if (int rc = build_sq_row_norms(ix)) { svsx_index_destroy(ix); return rc; }
     *out = ix;
     return SVSX_SUCCESS;
 }
@@ -362,6 +378,7 @@ void svsx_index_destroy(svsx_index* ix) {
         if (ix->d_graph) (void)hipFree(ix->d_graph);
         if (ix->d_entry) (void)hipFree(ix->d_entry);
     }
+    if (ix->d_sq_row_norm) (void)hipFree(ix->d_sq_row_norm);
     if (ix->d_half) (void)hipFree(ix->d_half);
     if (ix->d_norm2) (void)hipFree(ix->d_norm2);
     if (ix->d_codes) (void)hipFree(ix->d_codes);
@@ -773,6 +790,7 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     a.n_entry = static_cast<uint32_t>(ix->n_entry);
     a.sq_scale = ix->sq_scale;
     a.sq_bias = ix->sq_bias;
+    a.sq_row_norm = ix->d_sq_row_norm;
     a.id_offset = ix->id_offset;
     a.queries = d_queries;
     a.q_dtype = q_dtype;

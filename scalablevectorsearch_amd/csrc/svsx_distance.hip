@@ -76,6 +76,45 @@ hipError_t launch_distance(int b_dtype, int metric, int qmode, const DistanceArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Norm of every scalar-quantized row as CosineSimilarityCompressed sees it (quantization/scalar/scalar.h:175-184 decompresses
+// scale * float(v) + bias, cosine.h:224-256 accumulates x * x in the 16-lane tree, :334-335 takes sqrtf): the accumulator chain never sees
+// the query, so it is run ONCE per row here -- the same device routine as the search kernel, hence the same bits -- and the search kernel
+// reads sqrtf(sum) instead of repeating 2 d operations and a correctly rounded square root per candidate.
+template <int DT, int DS> __global__ __launch_bounds__(64) void sq_row_norm_kernel(const void* data, size_t row_bytes, uint32_t n, uint32_t d_runtime, float scale, float bias, float* out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x;
+    const int d = DS > 0 ? DS : static_cast<int>(d_runtime);
+    const int dpad = (d + 15) & ~15;
+    float* qf = reinterpret_cast<float*>(smem); // the routine wants a query: zeros (the dot product is discarded)
+    for (int i = static_cast<int>(lane); i < dpad; i += 64) qf[i] = 0.0f;
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    const int sub = static_cast<int>(lane) & 3;
+    const uint32_t grp = lane / 4;
+    for (uint32_t j0 = blockIdx.x * 16u; j0 < n; j0 += gridDim.x * 16u) {
+        const uint32_t j = j0 + grp;
+        const bool act = j < n;
+        const unsigned char* row = static_cast<const unsigned char*>(data) + static_cast<size_t>(act ? j : 0u) * row_bytes;
+        float fmain = 0.0f, fnrm = 0.0f;
+        float_row_distance_bc<DT, M_COS, DS, true>(row, act, qf, d, sub, scale, bias, fmain, fnrm);
+        if (act && sub == 0) out[j] = sqrtf(fnrm);
+    }
+}
+
+hipError_t launch_sq_row_norms(int dtype, const void* d_data, size_t row_bytes, uint32_t n, uint32_t d, float scale, float bias, float* d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t lds = static_cast<size_t>((d + 15) & ~15u) * 4;
+    uint32_t blocks = (n + 15) / 16;
+    if (blocks > 8192) blocks = 8192;
+    // the instantiation the search kernel would pick for these rows (launch_dim: static 768, runtime dimension otherwise): same arithmetic either way
+    if (dtype == DT_I8 && d == 768) hipLaunchKernelGGL((sq_row_norm_kernel<DT_I8, 768>), dim3(blocks), dim3(64), lds, stream, d_data, row_bytes, n, d, scale, bias, d_out);
+    else if (dtype == DT_U8 && d == 768) hipLaunchKernelGGL((sq_row_norm_kernel<DT_U8, 768>), dim3(blocks), dim3(64), lds, stream, d_data, row_bytes, n, d, scale, bias, d_out);
+    else if (dtype == DT_I8) hipLaunchKernelGGL((sq_row_norm_kernel<DT_I8, 0>), dim3(blocks), dim3(64), lds, stream, d_data, row_bytes, n, d, scale, bias, d_out);
+    else if (dtype == DT_U8) hipLaunchKernelGGL((sq_row_norm_kernel<DT_U8, 0>), dim3(blocks), dim3(64), lds, stream, d_data, row_bytes, n, d, scale, bias, d_out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // One wave per query, lane s = cursor of shard s (S <= 64): every step is a wave-wide arg-best over the list heads,
 // ties -> lowest shard (then position, the lists being sorted); the winning lane emits its head and advances.
 template <bool GREATER> __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a) {

@@ -18,6 +18,7 @@ struct SearchArgs {
     const uint32_t* entry;
     uint32_t n_entry;
     float sq_scale, sq_bias;
+    const float* sq_row_norm;  // scalar-quantized rows under cosine: sqrtf(||decompressed row||^2) per row, computed once at index creation
     uint64_t id_offset;
     // queries
     const void* queries;
@@ -88,6 +89,8 @@ struct DistanceArgs {
     float* out;         // na x nb
 };
 hipError_t launch_distance(int b_dtype, int metric, int qmode, const DistanceArgs& a, hipStream_t stream);
+// sqrtf of the reference-order sum of squares of every DECOMPRESSED scalar-quantized row (what CosineSimilarityCompressed divides by)
+hipError_t launch_sq_row_norms(int dtype, const void* d_data, size_t row_bytes, uint32_t n, uint32_t d, float scale, float bias, float* d_out, hipStream_t stream);
 
 struct MergeArgs {
     const float* dists;     // [S][nq][k]

@@ -41,6 +41,10 @@
 #ifndef SVSX_MERGE_V2
 #define SVSX_MERGE_V2 0
 #endif
+// waves per SIMD asked of the scalar-quantized cosine kernels of d = 768 (config 4): 5 spills 28-40 bytes at windows > 128 (A/B: profiles/r04_notes.md)
+#ifndef SVSX_SQCOS_FLOOR
+#define SVSX_SQCOS_FLOOR 4
+#endif
 
 namespace svsx {
 
@@ -61,7 +65,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
     if (DS == 768 && BIG == 2 && CODES == 4 && (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS)) return 3;
     if (DS == 768 && BIG <= 1) { // config 4 and its inner-product sibling
         if (QMODE == QM_SQ_IP) return BIG == 1 ? 4 : 5;
-        if (QMODE == QM_SQ_COS) return 4;
+        if (QMODE == QM_SQ_COS) return SVSX_SQCOS_FLOOR;
     }
     return 0;
 }
@@ -386,6 +390,13 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             return fmain;
         } else if constexpr (INTPATH) {
             int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
+        } else if constexpr (B8 && QMODE == QM_SQ_COS) {
+            // CosineSimilarityCompressed (scalar.h:155-195): the row's own norm does not depend on the query -- svsx_index_create ran the same
+            // accumulator chain once per row and stored its square root (sq_row_norm_kernel), so only the dot product is accumulated here:
+            // a sixth fewer vector instructions per element and no correctly rounded sqrt per candidate; same bits.
+            const float bn = a.sq_row_norm[active ? cid : 0u]; // requested with the row
+            float_row_distance_bc<DT, M_IP, DS, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+            return fmain / (bn * fx.norm); // cosine.h:334-335
         } else if constexpr (B8) {
             float_row_distance_bc<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         } else {

@@ -28,7 +28,7 @@ for rep in range(a.repeat):
                 j = json.loads(line)
             except ValueError:
                 continue
-            key = tuple((k, v) for k, v in sorted(j.items()) if k not in ("ms", "qps", "kernel", "ids_identical") and not isinstance(v, (list, dict)))
+            key = tuple((k, v) for k, v in sorted(j.items()) if k not in ("ms", "qps", "kernel", "ids_identical", "ms_per_batch", "min_ms", "build_s") and not isinstance(v, (list, dict)))
             rows.setdefault(key, {}).setdefault(name, []).append(j["ms"])
 base = libs[0][0]
 for key, by in rows.items():

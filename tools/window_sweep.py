@@ -57,6 +57,6 @@ for mode in [int(m) for m in a.modes.split(",")]:
         same = None
         if mode == 0: base = base or {}; base[w] = ids.clone()
         elif base and w in base: same = bool((base[w] == ids).all())
-        print(json.dumps({"n": a.n, "d": a.d, "dtype": a.dtype, "metric": a.metric, "build_s": t_build, "build_window": L, "mode": mode, "window": w, "recall_at_10": rec, "ms_per_batch": ms,
+        print(json.dumps({"n": a.n, "d": a.d, "dtype": a.dtype, "metric": a.metric, "build_s": t_build, "build_window": L, "mode": mode, "window": w, "recall_at_10": rec, "ms_per_batch": ms, "ms": ms, "ids_checksum": int(ids.sum().item()),
                           "qps": a.nq / ms * 1e3, "evals": float(stats[:, 2].sum()) / a.nq, "bound_rejects": float(stats[:, 5].sum()) / a.nq, "expansions": float(stats[:, 0].sum()) / a.nq,
                           "kernel": idx.last_kernel_info(), "ids_equal_mode0": same}), flush=True)
