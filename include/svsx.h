@@ -104,9 +104,16 @@ typedef struct {
  *                the GreedySearchTracker counts of greedy_search.h:165 / search_tracker.h:29-62
  *   history_*    per query, the expanded nodes in order (id, distance) -- the builder's
  *                use_full_search_history pool (vamana_build.h:54-91); history_len may exceed history_cap. */
+/* ABI version of this header = the number in the library's SONAME (libsvsx.so.3).  It changes whenever a struct below changes layout --
+ * version 3 is the one in which svsx_search_aux gained its leading struct_size -- so a program built against an older header cannot bind to
+ * this library by accident; svsx_abi_version() lets a dlopen / ctypes host check the same thing. */
+#define SVSX_ABI_VERSION 3
+int svsx_abi_version(void);
+
 typedef struct {
-    size_t struct_size;             /* sizeof(svsx_search_aux) as the CALLER compiled it (0 = this version's): fields beyond it read as 0,
-                                       so the struct can grow at its end without breaking callers built against an older header */
+    size_t struct_size;             /* sizeof(svsx_search_aux) as the CALLER compiled it; fields beyond it read as 0, so the struct can grow at
+                                       its END without breaking callers built against an older version-3 header.  0 means "the ABI-3 size"
+                                       (64 bytes: the fields below), never "whatever the library was built with" */
     uint32_t* stats;
     uint32_t* history_ids;
     float* history_dists;

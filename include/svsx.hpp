@@ -116,6 +116,27 @@ template <typename T, typename Dist> class VamanaIndex {
     VamanaSearchParameters get_search_parameters() const { return defaults_; }
     void set_search_parameters(const VamanaSearchParameters& p) { defaults_ = p; }
 
+    // auto_assemble (index/vamana/index.h:1017-1046) for what VamanaIndex::save wrote (:825-840): svs_config.toml + the native v1 blobs of
+    // graph and dataset.  Like the reference's loader it restores the saved DEFAULT SEARCH PARAMETERS (index.h:141-170,318) next to the entry
+    // point; the saved build parameters are returned through `config` for callers that want them.
+    static VamanaIndex assemble(const std::string& config_toml, const std::string& graph_blob, const std::string& data_blob, Dist dist = {}, int device = 0,
+                                io::IndexConfig* config = nullptr) {
+        const io::IndexConfig cfg = io::read_index_config(config_toml);
+        const auto graph = io::read_svs_native<uint32_t>(graph_blob);
+        const auto data = io::read_svs_native<T>(data_blob);
+        if (graph.n != data.n) throw ANNException(SVSX_INVALID_ARGUMENT, "Wrong sizes!"); // index.h:420-422
+        const uint32_t entry[1] = {cfg.entry_point};
+        VamanaIndex index(graph.values.data(), graph.d, data.values.data(), data.n, data.d, std::span<const uint32_t>(entry, 1), dist, device);
+        if (cfg.has_search) {
+            index.defaults_.buffer_config_ = SearchBufferConfig(cfg.search_window_size, cfg.search_buffer_capacity);
+            index.defaults_.search_buffer_visited_set_ = cfg.search_buffer_visited_set;
+            index.defaults_.prefetch_lookahead_ = cfg.prefetch_lookahead;
+            index.defaults_.prefetch_step_ = cfg.prefetch_step;
+        }
+        if (config) *config = cfg;
+        return index;
+    }
+
     // index/vamana/index.h:564-611.  Without a predicate the batch is simply enqueued.  With one, `cancel` (thread-safe by the
     // reference's contract, index.h:541-545) is polled from a helper thread while the batch runs; once it returns true the
     // library raises the device word the kernel polls at every hop (greedy_search.h:155) and the call returns early.

@@ -108,7 +108,90 @@ template <typename T> void write_svs_native(const std::string& path, const T* va
     f.write(reinterpret_cast<const char*>(values), static_cast<std::streamsize>(n * d * sizeof(T)));
 }
 
-// The one key this path needs from svs_config.toml (index/vamana/index.h:88-97): `entry_point = <integer>`, wherever the saved object nests it.
+// svs_config.toml as VamanaIndex::save writes it (index/vamana/index.h:88-97,141-170,825-840): the `vamana_index_parameters` object with its
+// entry point, the build parameters (build_params.h:88-101) and the DEFAULT SEARCH PARAMETERS the index is reloaded with (search_params.h:79-126,
+// index.h:318) -- plus the flat legacy layout of versions <= v0.0.2 (index.h:107-150: max_out_degree, construction_window_size, max_candidates,
+// default_search_window_size, visited_set).  A scanner for the TOML subset the reference emits (tables, integer / float / boolean / quoted-string
+// values, comments), not a general TOML parser.
+struct IndexConfig {
+    uint32_t entry_point = 0;
+    bool has_build = false, has_search = false;
+    // VamanaBuildParameters
+    float alpha = 1.2f;
+    size_t graph_max_degree = 0, window_size = 0, max_candidate_pool_size = 0, prune_to = 0;
+    bool use_full_search_history = true;
+    // VamanaSearchParameters
+    size_t search_window_size = 0, search_buffer_capacity = 0, prefetch_lookahead = 4, prefetch_step = 1;
+    bool search_buffer_visited_set = false;
+};
+
+inline IndexConfig read_index_config(const std::string& config_path) {
+    std::ifstream f(config_path);
+    if (!f) throw std::runtime_error(config_path + ": cannot open");
+    auto trim = [](std::string v) {
+        const size_t a = v.find_first_not_of(" \t\r"), b = v.find_last_not_of(" \t\r");
+        return a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+    };
+    IndexConfig c;
+    std::string line, table;
+    bool have_entry = false, legacy_window = false;
+    size_t legacy_w = 0;
+    while (std::getline(f, line)) {
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.erase(hash);
+        line = trim(line);
+        if (line.empty()) continue;
+        if (line.front() == '[') { // [object.build_parameters]
+            const size_t close = line.find(']');
+            table = close == std::string::npos ? std::string() : trim(line.substr(1, close - 1));
+            continue;
+        }
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string key = trim(line.substr(0, eq));
+        std::string val = trim(line.substr(eq + 1));
+        if (!val.empty() && (val.front() == '\'' || val.front() == '"')) continue; // strings (names, schemas, versions) are not needed
+        const bool truth = val == "true";
+        auto as_size = [&] { return static_cast<size_t>(std::stoull(val)); };
+        const bool in_build = table.size() >= 16 && table.compare(table.size() - 16, 16, "build_parameters") == 0;
+        const bool in_search = table.size() >= 17 && table.compare(table.size() - 17, 17, "search_parameters") == 0;
+        if (in_build) {
+            c.has_build = true;
+            if (key == "alpha") c.alpha = std::stof(val);
+            else if (key == "graph_max_degree") c.graph_max_degree = as_size();
+            else if (key == "window_size") c.window_size = as_size();
+            else if (key == "max_candidate_pool_size") c.max_candidate_pool_size = as_size();
+            else if (key == "prune_to") c.prune_to = as_size();
+            else if (key == "use_full_search_history") c.use_full_search_history = truth;
+        } else if (in_search) {
+            c.has_search = true;
+            if (key == "search_window_size") c.search_window_size = as_size();
+            else if (key == "search_buffer_capacity") c.search_buffer_capacity = as_size();
+            else if (key == "search_buffer_visited_set") c.search_buffer_visited_set = truth;
+            else if (key == "prefetch_lookahead") c.prefetch_lookahead = as_size();
+            else if (key == "prefetch_step") c.prefetch_step = as_size();
+        } else { // the index object itself, and the flat legacy layout
+            if (key == "entry_point") { c.entry_point = static_cast<uint32_t>(std::stoull(val)); have_entry = true; }
+            else if (key == "alpha") { c.alpha = std::stof(val); c.has_build = true; }
+            else if (key == "max_out_degree") { c.graph_max_degree = as_size(); c.has_build = true; if (c.prune_to == 0) c.prune_to = c.graph_max_degree; }
+            else if (key == "construction_window_size") c.window_size = as_size();
+            else if (key == "max_candidates") c.max_candidate_pool_size = as_size();
+            else if (key == "prune_to") c.prune_to = as_size();
+            else if (key == "use_full_search_history") c.use_full_search_history = truth;
+            else if (key == "default_search_window_size") { legacy_w = as_size(); legacy_window = true; }
+            else if (key == "visited_set") { c.search_buffer_visited_set = truth; c.has_search = true; }
+        }
+    }
+    if (!have_entry) throw std::runtime_error(config_path + ": no entry_point key");
+    if (legacy_window) { // load_legacy (index.h:107-150): SearchBufferConfig{default_search_window_size}, prefetch (4, 1)
+        c.has_search = true;
+        c.search_window_size = c.search_buffer_capacity = legacy_w;
+    }
+    if (c.search_window_size > c.search_buffer_capacity) throw std::runtime_error(config_path + ": search window larger than the buffer capacity (search_buffer.h:84-93)");
+    return c;
+}
+
+// The one key the search_index CLI needs from svs_config.toml (index/vamana/index.h:88-97): `entry_point = <integer>`, wherever the saved object nests it.
 // A line scanner, not a TOML parser: comments and other keys are skipped; a missing key throws.
 inline uint32_t read_entry_point(const std::string& config_path) {
     std::ifstream f(config_path);

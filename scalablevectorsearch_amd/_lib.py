@@ -82,7 +82,7 @@ EXPORTS = [
     "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
     "svsx_last_kernel_info", "svsx_search_filtered", "svsx_search_filtered_ex", "svsx_vamana_build_device", "svsx_find_medoid_device",
     "svsx_sharded_unique_id", "svsx_sharded_create", "svsx_sharded_create_with_comm", "svsx_sharded_destroy", "svsx_sharded_info",
-    "svsx_sharded_search_device",
+    "svsx_sharded_search_device", "svsx_abi_version",
 ]
 
 _lib = None
@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
         L.svsx_last_error.restype = C.c_char_p
         L.svsx_version.restype = C.c_char_p
         L.svsx_last_kernel_info.restype = C.c_char_p
+        if L.svsx_abi_version() != 3:  # include/svsx.h SVSX_ABI_VERSION: the structures below are laid out for ABI 3
+            raise ImportError(f"{LIB_PATH} speaks ABI {L.svsx_abi_version()}, this binding ABI 3")
         L.svsx_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_create_device_view.argtypes = [C.POINTER(DeviceIndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_destroy.argtypes = [C.c_void_p]

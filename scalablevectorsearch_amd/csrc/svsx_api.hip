@@ -163,18 +163,26 @@ struct HostCallContext {
     void* d_out = nullptr;  size_t d_out_cap = 0;   // ids64 | ids32 | dists | stats | history ids | history dists | history len
     void* h_in = nullptr;   size_t h_in_cap = 0;    // page-locked mirrors of the two
     void* h_out = nullptr;  size_t h_out_cap = 0;
-    uint32_t* h_flags = nullptr;                    // kFlagWords "chunk has arrived" words, page-locked (queries read in place)
-    uint32_t* d_flags = nullptr;                    // the same in HBM (queries DMA'd; written by hipStreamWriteValue32 behind each chunk's copy)
-    uint32_t epoch = 0;                             // value that means "arrived" for the current call
-    static constexpr size_t kFlagWords = 1024;
+    bool dirty = false;                             // an error return left work in flight on the streams: drained before the context is reused
+    static constexpr size_t kKeepBytes = size_t(64) << 20; // staging beyond this is given back when a call that needed it has returned
     ~HostCallContext() {
-        if (h_flags) (void)hipHostFree(h_flags);
-        if (d_flags) (void)hipFree(d_flags);
         for (auto st : streams) if (st) (void)hipStreamDestroy(st);
+        release();
+    }
+    void release() {
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
         if (h_in) (void)hipHostFree(h_in);
         if (h_out) (void)hipHostFree(h_out);
+        d_in = d_out = h_in = h_out = nullptr;
+        d_in_cap = d_out_cap = h_in_cap = h_out_cap = 0;
+    }
+    void drain() { // every stream idle: nothing reads or writes the staging any more
+        for (auto st : streams) if (st) (void)hipStreamSynchronize(st);
+        dirty = false;
+    }
+    void trim() {  // one huge batch must not pin gigabytes of page-locked memory for the life of the index
+        if (d_in_cap + d_out_cap > 2 * kKeepBytes) { drain(); release(); }
     }
     hipError_t reserve(size_t in_bytes, size_t out_bytes, int n_streams) {
         for (int i = 0; i < n_streams; ++i)
@@ -183,25 +191,14 @@ struct HostCallContext {
             if (want <= cap) return hipSuccess;
             if (p) { (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; cap = 0; }
             const size_t bytes = want + want / 4 + 4096;
-            hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocCoherent) : hipMalloc(&p, bytes); // coherent: the kernel reads / writes it in place (zero-copy path)
+            hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
             if (e == hipSuccess) cap = bytes;
             return e;
         };
-        hipError_t e = hipSuccess;
-        if (n_streams > 0) { // DMA path: device staging next to the page-locked mirrors
-            e = grow(d_in, d_in_cap, in_bytes, false);
-            if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes, false);
-        }
+        hipError_t e = grow(d_in, d_in_cap, in_bytes, false);
+        if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes, false);
         if (e == hipSuccess) e = grow(h_in, h_in_cap, in_bytes, true);
         if (e == hipSuccess) e = grow(h_out, h_out_cap, out_bytes, true);
-        if (e == hipSuccess && !h_flags) {
-            e = hipHostMalloc(reinterpret_cast<void**>(&h_flags), kFlagWords * sizeof(uint32_t), hipHostMallocCoherent);
-            if (e == hipSuccess) memset(h_flags, 0, kFlagWords * sizeof(uint32_t));
-        }
-        if (e == hipSuccess && !d_flags) {
-            e = hipMalloc(reinterpret_cast<void**>(&d_flags), kFlagWords * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemset(d_flags, 0, kFlagWords * sizeof(uint32_t));
-        }
         return e;
     }
     hipError_t stream0() { return streams[0] ? hipSuccess : hipStreamCreateWithFlags(&streams[0], hipStreamNonBlocking); }
@@ -219,9 +216,12 @@ struct ContextLease {
             if (!ix->ctx_free.empty()) { c = ix->ctx_free.back(); ix->ctx_free.pop_back(); }
         }
         if (!c) c = new (std::nothrow) HostCallContext();
+        if (c && c->dirty) c->drain();
     }
     ~ContextLease() {
         if (!c) return;
+        if (c->dirty) c->drain(); // an early return with copies / kernels still in flight: the next caller must not find an active DMA on the staging
+        c->trim();
         std::lock_guard<std::mutex> lock(ix->ctx_mutex);
         ix->ctx_free.push_back(c);
     }
@@ -240,7 +240,8 @@ int validate_common(int metric, int dtype, size_t n, size_t d) {
 extern "C" {
 
 const char* svsx_last_error(void) { return g_error.c_str(); }
-const char* svsx_version(void) { return "svsx 0.3.0 (gfx950)"; }
+const char* svsx_version(void) { return "svsx 0.4.0 (gfx950)"; }
+int svsx_abi_version(void) { return SVSX_ABI_VERSION; }
 const char* svsx_last_kernel_info(void) { return last_search_instantiation(); }
 
 // CosineSimilarityCompressed divides by the norm of the decompressed row (scalar.h:175-184, cosine.h:334-335): a property of the row alone,
@@ -829,8 +830,65 @@ static void default_filter(const svsx_index* ix, SearchArgs& a, uint32_t fe) {
     if (a.fat != nullptr) a.filter_tag8 = 0; // the inline-record kernel keeps only fetched rows in the filter: 16-bit tags, no variant
 }
 
-static thread_local const uint32_t* g_host_flags = nullptr; // set by search_host_zero_copy around its search_common call
-static thread_local uint32_t g_host_flag_shift = 0, g_host_flag_epoch = 0;
+// Search buffers beyond what a wave's LDS holds (16 000 entries).  The reference only asks for window <= capacity (search_buffer.h:84-93), so
+// nothing is refused: the buffers live in HBM, one row of a state table per query, and the GENERAL kernel variant works on them in place
+// exactly as it does for a BatchIterator whose buffer has outgrown LDS (svsx_iterator_next_device) -- a plain search is one iterator step
+// that starts from the entry points with (window - k, capacity - k) + a batch of k.  Queries run in groups that keep the table under 2 GB.
+__global__ void fill_spill_meta_kernel(uint32_t* meta, uint32_t nq, uint32_t window_minus_k, uint32_t capacity_minus_k) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint32_t* m = meta + static_cast<size_t>(q) * 8;
+    m[0] = 0u; m[1] = 0u; m[2] = window_minus_k; m[3] = capacity_minus_k; m[4] = 0u; m[5] = 0u; m[6] = 1u /* start from the entry points */; m[7] = 0u;
+}
+
+static int search_spilled(const svsx_index* ix, int qmode, const SearchArgs& plain, hipStream_t stream) {
+    const size_t nq = plain.nq, k = plain.k, estride = (static_cast<size_t>(plain.capacity) + 1 + 1) & ~size_t(1);
+    size_t group = (size_t(2) << 30) / (estride * sizeof(uint2));
+    if (group == 0) group = 1;
+    if (group > nq) group = nq;
+    StreamBuffer entries, meta, yielded, out_i, out_d, counts;
+    HIP_TRY(entries.alloc(group * estride * sizeof(uint2), stream));
+    HIP_TRY(meta.alloc(group * 8 * sizeof(uint32_t), stream));
+    HIP_TRY(yielded.alloc(group * k * sizeof(uint32_t), stream));
+    HIP_TRY(out_i.alloc(group * k * sizeof(uint64_t), stream));
+    HIP_TRY(out_d.alloc(group * k * sizeof(float), stream));
+    HIP_TRY(counts.alloc(group * sizeof(uint32_t), stream));
+    for (size_t lo = 0; lo < nq; lo += group) {
+        const size_t cnt = nq - lo < group ? nq - lo : group;
+        SearchArgs a = plain;
+        a.queries = static_cast<const unsigned char*>(plain.queries) + lo * plain.q_row_bytes;
+        a.nq = static_cast<uint32_t>(cnt);
+        if (plain.ids64) a.ids64 = plain.ids64 + lo * k;
+        if (plain.ids32) a.ids32 = plain.ids32 + lo * k;
+        if (plain.dists) a.dists = plain.dists + lo * k;
+        if (plain.stats) a.stats = plain.stats + lo * 6;
+        if (plain.history_ids) a.history_ids = plain.history_ids + lo * plain.history_cap;
+        if (plain.history_dists) a.history_dists = plain.history_dists + lo * plain.history_cap;
+        if (plain.history_len) a.history_len = plain.history_len + lo;
+        a.general = 1;
+        a.codes = nullptr;
+        a.fat = nullptr;
+        a.filter_tag8 = (a.filter_entries && (ix->n >> __builtin_ctz(a.filter_entries)) < 0xFFu) ? 1u : 0u;
+        hipLaunchKernelGGL(fill_spill_meta_kernel, dim3(static_cast<uint32_t>((cnt + 255) / 256)), dim3(256), 0, stream, static_cast<uint32_t*>(meta.p), static_cast<uint32_t>(cnt),
+                           plain.window - static_cast<uint32_t>(k), plain.capacity - static_cast<uint32_t>(k));
+        a.window = 1;   // per-query values come from the state table; these only size the (unused) LDS buffer
+        a.capacity = 1;
+        a.it_spill = 1u;
+        a.it_entries = static_cast<uint2*>(entries.p);
+        a.it_estride = static_cast<uint32_t>(estride);
+        a.it_meta = static_cast<uint32_t*>(meta.p);
+        a.it_yielded = static_cast<uint32_t*>(yielded.p);
+        a.it_ystride = static_cast<uint32_t>(k);
+        a.it_batch_sizes = nullptr;
+        a.it_batch = static_cast<uint32_t>(k);
+        a.it_out_ids = static_cast<uint64_t*>(out_i.p);
+        a.it_out_dists = static_cast<float*>(out_d.p);
+        a.it_counts = static_cast<uint32_t*>(counts.p);
+        hipError_t e = launch_search(ix->data_dtype, ix->metric, qmode, a, stream);
+        if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "search kernel launch failed: %s", hipGetErrorString(e));
+    }
+    return SVSX_SUCCESS;
+}
 
 static int search_common(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
@@ -848,7 +906,7 @@ static int search_common(
     if (capacity == 0) return fail(SVSX_INVALID_ARGUMENT, "search window size must be positive");
     if (d_ids32 != nullptr && ix->id_offset + ix->n > (uint64_t(1) << 32))
         return fail(SVSX_INVALID_ARGUMENT, "32-bit ids cannot hold id_offset + n = %llu: ask for 64-bit ids", static_cast<unsigned long long>(ix->id_offset + ix->n));
-    if (capacity > 16000) return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu exceeds the LDS budget of one wave", capacity);
+    if (capacity > (size_t(1) << 27)) return fail(SVSX_INVALID_ARGUMENT, "search buffer capacity %zu is out of range", capacity);
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0)
         return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d%s) pair", q_dtype, ix->data_dtype, ix->sq_enabled ? ", SQ" : "");
@@ -884,9 +942,7 @@ static int search_common(
         a.history_cap = static_cast<uint32_t>(aux->history_cap);
         a.cancel = const_cast<const int*>(aux->cancel_flag); // device word here (svsx_search mirrors the caller's host word into one)
     }
-    a.q_ready = g_host_flags;
-    a.q_ready_shift = g_host_flag_shift;
-    a.q_ready_epoch = g_host_flag_epoch;
+    if (capacity > 16000) return search_spilled(ix, qmode, a, stream);
     hipError_t e = launch_search(ix->data_dtype, ix->metric, qmode, a, stream);
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "search kernel launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
@@ -903,11 +959,14 @@ static int check_search_args(const svsx_index* ix, const void* queries, int q_dt
 }
 
 // the caller's aux through the size it was compiled with (svsx.h: struct_size)
+constexpr size_t kAuxSizeAbi3 = 64; // struct_size, four pointers, two sizes, the cancel word: the struct as ABI 3 introduced it
+static_assert(sizeof(svsx_search_aux) >= kAuxSizeAbi3, "svsx_search_aux only grows at its end");
 static const svsx_search_aux* normalise_aux(const svsx_search_aux* in, svsx_search_aux& store) {
     if (!in) return nullptr;
-    if (in->struct_size == 0 || in->struct_size >= sizeof(svsx_search_aux)) return in;
+    const size_t have = in->struct_size == 0 ? kAuxSizeAbi3 : in->struct_size; // 0 = the ABI-3 size, a constant (not sizeof of this build)
+    if (have >= sizeof(svsx_search_aux)) return in;
     memset(&store, 0, sizeof(store));
-    memcpy(&store, in, in->struct_size < sizeof(size_t) ? sizeof(size_t) : in->struct_size);
+    memcpy(&store, in, have < sizeof(size_t) ? sizeof(size_t) : have);
     return &store;
 }
 
@@ -923,63 +982,10 @@ int svsx_search_device(
     return search_common(ix, d_queries, q_dtype, nq, k, params, d_ids64, d_ids32, d_dists, d_aux, static_cast<hipStream_t>(hip_stream));
 }
 
-#ifdef SVSX_DIAG
-// Experimental (DIAG builds, SVSX_HOST_IN=1): ONE launch that starts before the queries have left the caller's buffer.  The kernel reads
-// them from page-locked HOST memory the calling thread fills chunk by chunk while the kernel runs; a wave polls the "arrived" word of its own
-// query's chunk (relaxed, system scope; the words hold a per-call epoch, nothing is reset).  Results: D2H copy behind the kernel (out 0) or
-// written by the kernel straight to page-locked host memory (out 1).  The flags are written by the HOST THREAD, never by a stream operation:
-// a kernel must not wait for work queued on another stream -- streams share hardware queues, and the round-3 variant that waited for
-// hipStreamWriteValue32 behind an H2D copy dead-locked under test_concurrent_host_callers.  Measurements: profiles/r03_notes.md.
-enum HostMode { kHostDma = 0, kHostZeroCopy = 1 };
-static int search_host_single_launch(
-    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
-    uint64_t* ids64, uint32_t* ids32, float* dists, size_t q_stride, int out_mode
-) {
-    ContextLease lease(ix);
-    HostCallContext* c = lease.c;
-    if (!c) return fail(SVSX_RUNTIME_ERROR, "out of host memory");
-    const size_t o64 = 0, o32 = ids64 ? ((nq * k * 8 + 255) & ~size_t(255)) : 0;
-    const size_t odd = o32 + (ids32 ? ((nq * k * 4 + 255) & ~size_t(255)) : 0);
-    const size_t out_bytes = odd + (dists ? nq * k * 4 : 0);
-    HIP_TRY(c->reserve(q_stride * nq, out_bytes, 2));
-    // chunks of 2^shift queries, at most kFlagWords of them
-    uint32_t shift = 9; // 512 queries = 196 KB of float32 d = 96 rows: a few microseconds per chunk
-    while ((nq >> shift) + 1 > HostCallContext::kFlagWords) ++shift;
-    const size_t per = size_t(1) << shift, nchunks = (nq + per - 1) / per;
-    c->epoch = c->epoch + 1u ? c->epoch + 1u : 1u;
-    const uint32_t epoch = c->epoch;
-    hipStream_t sk = c->streams[0];
-    svsx_search_aux daux;
-    memset(&daux, 0, sizeof(daux));
-    daux.query_row_stride_bytes = q_stride;
-    unsigned char* out = static_cast<unsigned char*>(out_mode == kHostZeroCopy ? c->h_out : c->d_out);
-    g_host_flags = c->h_flags;
-    g_host_flag_shift = shift;
-    g_host_flag_epoch = epoch;
-    const int rc = search_common(ix, c->h_in, q_dtype, nq, k, params, ids64 ? reinterpret_cast<uint64_t*>(out + o64) : nullptr,
-                                 ids32 ? reinterpret_cast<uint32_t*>(out + o32) : nullptr, dists ? reinterpret_cast<float*>(out + odd) : nullptr, &daux, sk);
-    g_host_flags = nullptr;
-    if (rc != SVSX_SUCCESS) return rc;
-    if (out_mode == kHostDma) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, sk)); // behind the kernel
-    // the launch is on its way: now feed it
-    for (size_t i = 0; i < nchunks; ++i) {
-        const size_t lo = i * per, cnt = (lo + per <= nq) ? per : nq - lo;
-        unsigned char* hq = static_cast<unsigned char*>(c->h_in) + q_stride * lo;
-        memcpy(hq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * cnt);
-        __atomic_store_n(&c->h_flags[i], epoch, __ATOMIC_RELEASE);
-    }
-    HIP_TRY(hipStreamSynchronize(sk));
-    const unsigned char* res = static_cast<const unsigned char*>(c->h_out);
-    if (ids64) memcpy(ids64, res + o64, nq * k * 8);
-    if (ids32) memcpy(ids32, res + o32, nq * k * 4);
-    if (dists) memcpy(dists, res + odd, nq * k * 4);
-    return SVSX_SUCCESS;
-}
-#endif // SVSX_DIAG
 
 // Host pointers in, host results out (SURVEY 8d's QPS definition; benchmark/include/svs-benchmark/search.h:209-219 times exactly this call).
 // The form that also serves the side outputs (statistics, search history): page-locked mirror -> H2D -> kernel -> D2H on one stream with
-// persistent staging.  (DIAG builds can cut the batch into chunks on separate streams for A/B: measured slower than one launch.)
+// persistent staging, in two chunks on two streams (below).
 static int search_host_pipelined(
     const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux, size_t q_stride
@@ -995,9 +1001,6 @@ static int search_host_pipelined(
     // run.  More chunks lose: a later launch only gets compute units when an earlier one has drained, so every extra launch adds a drain
     // (five chunks: 1.43-1.50 ms against 1.15 ms for the kernel alone; profiles/r03_notes.md).
     size_t first = nq > 4096 ? 4096 : nq;
-#ifdef SVSX_DIAG
-    if (const char* e = getenv("SVSX_HOST_SPLIT")) first = std::min<size_t>(nq, std::max<size_t>(1, static_cast<size_t>(atol(e))));
-#endif
     if (first < nq) {
         nc = 2;
         bounds[1] = first;
@@ -1022,21 +1025,15 @@ static int search_host_pipelined(
     const int rhi = add_region(aux ? aux->history_ids : nullptr, hcap * 4), rhd = add_region(aux ? aux->history_dists : nullptr, hcap * 4);
     const int rhl = add_region(aux ? aux->history_len : nullptr, 4);
     HIP_TRY(c->reserve(q_stride * nq, out_bytes, nc));
-#ifdef SVSX_DIAG
-    const auto diag_t0 = std::chrono::steady_clock::now();
-    auto diag_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - diag_t0).count(); };
-    double diag_in[HostCallContext::kMaxChunks] = {}, diag_enq[HostCallContext::kMaxChunks] = {}, diag_sync[HostCallContext::kMaxChunks] = {}, diag_out[HostCallContext::kMaxChunks] = {};
-#endif
+    const size_t q_row = ix->d * dtype_size(q_dtype);
+    c->dirty = true; // from here on an early return leaves copies / kernels in flight: the lease drains the streams before the context is reused
     auto dptr = [&](int r, size_t row) -> void* { return r < 0 ? nullptr : static_cast<unsigned char*>(c->d_out) + regions[r].offset + regions[r].row_bytes * row; };
     for (int i = 0; i < nc; ++i) {
         const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
         if (cnt == 0) continue;
         hipStream_t st = c->streams[i];
         unsigned char* hq = static_cast<unsigned char*>(c->h_in) + q_stride * lo;
-        memcpy(hq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * cnt);
-#ifdef SVSX_DIAG
-        diag_in[i] = diag_us();
-#endif
+        memcpy(hq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * (cnt - 1) + q_row); // never past the caller's last row
         void* dq = static_cast<unsigned char*>(c->d_in) + q_stride * lo;
         HIP_TRY(hipMemcpyAsync(dq, hq, q_stride * cnt, hipMemcpyHostToDevice, st));
         svsx_search_aux daux;
@@ -1056,31 +1053,16 @@ static int search_host_pipelined(
             const size_t off = regions[r].offset + regions[r].row_bytes * lo;
             HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(c->h_out) + off, static_cast<unsigned char*>(c->d_out) + off, regions[r].row_bytes * cnt, hipMemcpyDeviceToHost, st));
         }
-#ifdef SVSX_DIAG
-        diag_enq[i] = diag_us();
-#endif
     }
     for (int i = 0; i < nc; ++i) {
         const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
         if (cnt == 0) continue;
         HIP_TRY(hipStreamSynchronize(c->streams[i]));
-#ifdef SVSX_DIAG
-        diag_sync[i] = diag_us();
-#endif
         for (int r = 0; r < nr; ++r)
             memcpy(static_cast<unsigned char*>(regions[r].host) + regions[r].row_bytes * lo,
                    static_cast<const unsigned char*>(c->h_out) + regions[r].offset + regions[r].row_bytes * lo, regions[r].row_bytes * cnt);
-#ifdef SVSX_DIAG
-        diag_out[i] = diag_us();
-#endif
     }
-#ifdef SVSX_DIAG
-    if (getenv("SVSX_HOST_TIMELINE")) {
-        fprintf(stderr, "[svsx host timeline, us] chunks %d:", nc);
-        for (int i = 0; i < nc; ++i) fprintf(stderr, "  #%d(%zu) in %.0f enq %.0f sync %.0f out %.0f", i, bounds[i + 1] - bounds[i], diag_in[i], diag_enq[i], diag_sync[i], diag_out[i]);
-        fprintf(stderr, "\n");
-    }
-#endif
+    c->dirty = false; // every stream has been synchronised
     return SVSX_SUCCESS;
 }
 
@@ -1101,13 +1083,6 @@ int svsx_search(
     if (nq == 0) return SVSX_SUCCESS;
     HIP_TRY(hipSetDevice(ix->device));
     const size_t q_stride = (aux && aux->query_row_stride_bytes) ? aux->query_row_stride_bytes : ix->d * dtype_size(q_dtype);
-#ifdef SVSX_DIAG
-    const bool side_outputs = aux && (aux->stats || aux->history_ids || aux->history_dists || aux->history_len);
-    if (!(aux && aux->cancel_flag) && !side_outputs) {
-        if (const char* e = getenv("SVSX_HOST_IN"))
-            if (atoi(e) == 1) return search_host_single_launch(ix, queries, q_dtype, nq, k, params, ids64, ids32, dists, q_stride, getenv("SVSX_HOST_OUT") ? atoi(getenv("SVSX_HOST_OUT")) : 0);
-    }
-#endif
     if (!(aux && aux->cancel_flag)) return search_host_pipelined(ix, queries, q_dtype, nq, k, params, ids64, ids32, dists, aux, q_stride);
     // ---- with a cancel word: one chunk on one stream, the host thread polls the caller's word while the stream drains -------------------
     CallStream cs;
@@ -1283,7 +1258,10 @@ int svsx_flat_search_device(
     // threshold -- which at least kk rows of the next level satisfy, because the samples are nested.  The last level is
     // the full set; its lists (>= kk rows, ~16 kk expected) are re-ranked exactly.  Queries whose lists overflow
     // (unrepresentative samples) are recomputed by the full shortlist kernel, gated per 64-query block.
-    const bool thresh_path = dpad <= 128 && ix->n >= 65536 && nq <= 65536 && !getenv("SVSX_FLAT_SHORTLIST_ONLY");
+    bool thresh_path = dpad <= 128 && ix->n >= 65536 && nq <= 65536;
+#ifdef SVSX_DIAG
+    if (getenv("SVSX_FLAT_SHORTLIST_ONLY")) thresh_path = false; // A/B builds only
+#endif
     StreamBuffer bcand, bkeys, bcnt, bgate, btau_a, btau_b;
     if (thresh_path) {
         const size_t tiles = (ix->n + 31) / 32;

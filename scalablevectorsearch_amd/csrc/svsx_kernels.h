@@ -56,11 +56,6 @@ struct SearchArgs {
     float pca_ref_extra;      // scalar-quantized inner product: 2 |bias| sqrt(d), enters the slack for the reference's own rounding
     // cancellation (index/vamana/index.h:541-545, greedy_search.h:155): device word polled once per expansion; non-zero = stop
     const int* cancel;
-    // host-pointer calls (svsx_search): the queries are still on their way while the kernel runs; q_ready[qi >> q_ready_shift] becomes
-    // q_ready_epoch (a per-call value: the words are never reset) once the chunk of query qi has arrived
-    const uint32_t* q_ready;
-    uint32_t q_ready_shift;
-    uint32_t q_ready_epoch;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
     uint32_t general;
     // BatchIterator (index/vamana/iterator.h): per-query state in HBM.  meta = 8 u32 per query:

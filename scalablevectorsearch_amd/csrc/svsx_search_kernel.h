@@ -156,13 +156,6 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     }
     if constexpr (!GENERAL) {
         if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return; // extensions.h:575-578
-        if (a.q_ready != nullptr) { // queries still arriving from the host (svsx_search): wait for this query's chunk
-            const uint32_t* flag = a.q_ready + (qi >> a.q_ready_shift);
-            // relaxed, system scope: the word and the queries live in fine-grained host memory, which the GPU never caches -- an ACQUIRE here
-            // would invalidate the L2 under every running wave (measured: +0.7 ms per 10 000-query launch)
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.q_ready_epoch) __builtin_amdgcn_s_sleep(16);
-            __atomic_signal_fence(__ATOMIC_SEQ_CST); // the query loads stay behind the poll (issue order = program order within a wave)
-        }
     }
     const uint32_t fmask = a.filter_entries - 1u;
     const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));

@@ -76,3 +76,39 @@ def write_svs_native(path, x):
     with open(path, "wb") as f:
         f.write(head)
         f.write(x.tobytes())
+
+
+def read_index_config(path):
+    """svs_config.toml as VamanaIndex::save writes it (index/vamana/index.h:88-97,141-170): entry point, build parameters (build_params.h:88-101)
+    and the DEFAULT SEARCH PARAMETERS the index is reloaded with (search_params.h:79-126); also the flat legacy layout of versions <= v0.0.2
+    (index.h:107-150).  Returns dict(entry_point, build=dict|None, search=dict|None)."""
+    import os
+
+    import tomli
+
+    if os.path.isdir(path):
+        path = os.path.join(path, "svs_config.toml")
+    with open(path, "rb") as f:
+        cfg = tomli.load(f)
+    obj = cfg.get("object", cfg)
+    out = dict(entry_point=int(obj["entry_point"]), build=None, search=None)
+    if "build_parameters" in obj or "search_parameters" in obj:
+        b, s_ = obj.get("build_parameters"), obj.get("search_parameters")
+        if b is not None:
+            out["build"] = dict(alpha=float(b["alpha"]), graph_max_degree=int(b["graph_max_degree"]), window_size=int(b["window_size"]),
+                                max_candidate_pool_size=int(b["max_candidate_pool_size"]), prune_to=int(b.get("prune_to", b["graph_max_degree"])),
+                                use_full_search_history=bool(b.get("use_full_search_history", True)))
+        if s_ is not None:
+            out["search"] = dict(search_window_size=int(s_["search_window_size"]), search_buffer_capacity=int(s_["search_buffer_capacity"]),
+                                 search_buffer_visited_set=bool(s_["search_buffer_visited_set"]), prefetch_lookahead=int(s_.get("prefetch_lookahead", 4)),
+                                 prefetch_step=int(s_.get("prefetch_step", 1)))
+    elif "max_out_degree" in obj:  # load_legacy: prune_to defaults to the degree, full search history to true, prefetch to (4, 1)
+        r = int(obj["max_out_degree"])
+        out["build"] = dict(alpha=float(obj["alpha"]), graph_max_degree=r, window_size=int(obj["construction_window_size"]),
+                            max_candidate_pool_size=int(obj["max_candidates"]), prune_to=int(obj.get("prune_to", r)),
+                            use_full_search_history=bool(obj.get("use_full_search_history", True)))
+        w = int(obj["default_search_window_size"])
+        out["search"] = dict(search_window_size=w, search_buffer_capacity=w, search_buffer_visited_set=bool(obj["visited_set"]), prefetch_lookahead=4, prefetch_step=1)
+    if out["search"] and out["search"]["search_window_size"] > out["search"]["search_buffer_capacity"]:
+        raise ValueError(f"{path}: search window larger than the buffer capacity (search_buffer.h:84-93)")
+    return out

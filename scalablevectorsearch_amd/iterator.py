@@ -194,9 +194,9 @@ def sample_size_for_filter_stop(filter_stop: float) -> int:
 
 def filtered_search(index, queries, k: int, is_member, search_parameters: VamanaSearchParameters | None = None,
                     filter_stop: float = 0.0, extra_search_buffer_capacity: int | None = None, make_iterator=None,
-                    filter_estimate_batch: bool = False) -> QueryResult:
+                    filter_estimate_batch: bool = True) -> QueryResult:
     """Runtime VamanaIndex::search with an IDFilter (vamana_index_impl.h:140-218): per query, pull adaptive batches from the iterator until
-    k members of the filter are found.  filter_estimate_batch (the runtime's default is True): the sampled hit rate decides whether to search at
+    k members of the filter are found.  filter_estimate_batch (default True, like the runtime, VamanaIndex.search_filtered and the C++ facade): the sampled hit rate decides whether to search at
     all and the first batch size (:153-175).  `is_member`: boolean array over ids.  Unfilled slots: id all-ones, distance +inf."""
     queries = np.ascontiguousarray(np.atleast_2d(queries))
     nq = queries.shape[0]

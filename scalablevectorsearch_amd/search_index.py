@@ -34,11 +34,21 @@ def _blob(path: str) -> str:
 
 
 def _entry_point(config_dir: str) -> int:
-    import tomli
+    return io.read_index_config(config_dir)["entry_point"]
 
-    cfg = tomli.load(open(os.path.join(config_dir, "svs_config.toml") if os.path.isdir(config_dir) else config_dir, "rb"))
-    obj = cfg.get("object", cfg)
-    return int(obj["entry_point"])
+
+def load_index(config: str, graph_path: str, data_path: str, distance, data_dtype=np.float32, device: int = 0) -> VamanaIndex:
+    """auto_assemble (index/vamana/index.h:1017-1046) for what VamanaIndex::save wrote: svs_config.toml + the native blobs of graph and dataset.
+    Like the reference's loader it restores the saved default search parameters (index.h:141-170,318) next to the entry point."""
+    cfg = io.read_index_config(config)
+    data = io.read_svs_native(_blob(data_path), data_dtype)
+    graph = io.read_svs_native(_blob(graph_path), np.uint32)
+    index = VamanaIndex(graph, data, distance, [cfg["entry_point"]], device=device)
+    sp = cfg["search"]
+    if sp is not None:
+        index.set_search_parameters(VamanaSearchParameters(SearchBufferConfig(sp["search_window_size"], sp["search_buffer_capacity"]), sp["search_buffer_visited_set"],
+                                                           sp["prefetch_lookahead"], sp["prefetch_step"]))
+    return index
 
 
 def _load_queries(path: str, dtype):

@@ -197,7 +197,7 @@ class NativeShardedSearcher:
     reference would call; `torch.distributed` is only used here to hand rank 0's 128-byte unique id to the other ranks.
 
     indexes: this rank's VamanaIndex objects, global shards rank * len(indexes) + s (their id_offset makes the ids global).
-    use_rccl: None = whenever the process group's backend is nccl or the world has one rank and `single_rank_comm` is set."""
+    single_rank_comm: join a real one-rank RCCL communicator also when the world has one rank (exercises ncclAllGather on one GPU)"""
 
     def __init__(self, indexes, group=None, single_rank_comm: bool = False):
         import torch

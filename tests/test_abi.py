@@ -106,7 +106,7 @@ def test_round3_entry_points_check_their_arguments_before_any_device_work(lib):
     ids = np.zeros((1, 1), np.uint64)
     d = np.zeros((1, 1), np.float32)
     assert L.svsx_search_filtered_ex(None, q.ctypes.data, 0, 1, 1, None, None, 0.0, 1, ids.ctypes.data, d.ctypes.data) == lib.NOT_INITIALIZED
-    assert L.svsx_version().startswith(b"svsx 0.3")
+    assert L.svsx_version().startswith(b"svsx 0.4") and L.svsx_abi_version() == 3
 
 
 def test_product_does_not_import_the_oracle():

@@ -613,3 +613,21 @@ def test_flat_search_threshold_overflow_falls_back(svs, oracle):
     res2 = idx2.search(q2, 10)
     ids2, dists2 = oracle.flat_search(L2, x2, q2, 10)
     assert (res2.indices == ids2.astype(np.uint64)).all() and (res2.distances.view(np.uint32) == dists2.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("w,c,k,vis", [(17000, 17000, 10, 0), (100, 20000, 10, 1), (16001, 16001, 200, 0), (5, 40000, 10, 0)])
+def test_search_buffers_beyond_one_waves_lds(svs, oracle, small_world, w, c, k, vis):
+    """plain searches whose buffer exceeds 16 000 entries work on a state table in HBM (svsx_api.hip search_spilled): the reference only
+    requires window <= capacity (search_buffer.h:84-93).  ids, distance bits and the tracker counts equal the oracle's; inline records are
+    simply not used there."""
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    for mode in (0, 2):
+        if mode:
+            idx.build_bound_codes(mode)
+        res, st = idx.search(sw["q"][:9], k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
+        ids, dists, ost = oracle.search(L2, sw["x"], sw["graph"], sw["entry"], sw["q"][:9], k, w, c, visited_set=bool(vis), stats=True)
+        assert (res.indices == ids.astype(np.uint64)).all(), (w, c, k, mode)
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all(), (w, c, k, mode)
+        assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
+        assert "general=1" in idx.last_kernel_info(), idx.last_kernel_info()

@@ -1,8 +1,12 @@
 """Host-side mirror of the reference interface: parameter objects, recall, error behaviour.  No GPU needed."""
+import os
+
 import numpy as np
 import pytest
 
 import scalablevectorsearch_amd as svs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_search_buffer_config_mirror():
@@ -156,3 +160,60 @@ def test_filter_sampling_restatement_equals_the_standard_library(tmp_path):
     assert sample_filter_hits(np.ones(50, bool), 50, 200) == (50, 50)     # fewer ids than samples
     assert predict_further_processing(200, 29, 10, 20, n) == 20            # enough hits already: the hint
     assert predict_further_processing(200, 4, 10, 20, n) == 300            # (10 - 4) * 200 / 4
+
+
+LEGACY_CONFIG = """
+__version__ = 'v0.0.2'
+
+[object]
+__version__ = 'v0.0.2'
+name = 'vamana config parameters'
+alpha = 0.949999988079071
+max_out_degree = 64   # no prune_to key: defaults to the degree (index.h:128-132)
+construction_window_size = 128
+max_candidates = 750
+entry_point = 77
+default_search_window_size = 33
+visited_set = true
+"""
+
+
+def test_saved_index_config_readers(tmp_path):
+    """svs_config.toml (index/vamana/index.h:88-97,141-170): entry point, build parameters and the default search parameters the reference
+    restores on load -- the reference's own data/test_dataset/vamana_config.toml (tests/golden/), a search-parameter variant, and the flat legacy
+    layout; the Python reader and the C++ header (include/svsx_io.hpp, compiled here) must agree."""
+    import subprocess
+
+    from scalablevectorsearch_amd.io import read_index_config
+
+    golden = os.path.join(ROOT, "tests", "golden", "vamana_config.toml")
+    cfg = read_index_config(golden)
+    assert cfg["entry_point"] == 9426
+    assert cfg["build"] == dict(alpha=1.2000000476837158, graph_max_degree=128, window_size=200, max_candidate_pool_size=1000, prune_to=128, use_full_search_history=True)
+    assert cfg["search"] == dict(search_window_size=0, search_buffer_capacity=0, search_buffer_visited_set=False, prefetch_lookahead=0, prefetch_step=0)
+    tuned = tmp_path / "svs_config.toml"
+    tuned.write_text(open(golden).read().replace("search_buffer_capacity = 0", "search_buffer_capacity = 48").replace("search_window_size = 0", "search_window_size = 24")
+                     .replace("search_buffer_visited_set = false", "search_buffer_visited_set = true"))
+    assert read_index_config(str(tmp_path))["search"]["search_window_size"] == 24  # a directory: svs_config.toml inside it
+    legacy = tmp_path / "legacy.toml"
+    legacy.write_text(LEGACY_CONFIG)
+    lc = read_index_config(str(legacy))
+    assert lc["entry_point"] == 77 and lc["build"]["prune_to"] == 64 and lc["build"]["use_full_search_history"] is True
+    assert lc["search"] == dict(search_window_size=33, search_buffer_capacity=33, search_buffer_visited_set=True, prefetch_lookahead=4, prefetch_step=1)
+    bad = tmp_path / "bad.toml"
+    bad.write_text(open(golden).read().replace("search_window_size = 0", "search_window_size = 9"))
+    with pytest.raises(ValueError):
+        read_index_config(str(bad))
+    # the C++ reader prints the same facts
+    src = tmp_path / "cfg.cpp"
+    src.write_text('#include "svsx_io.hpp"\n#include <cstdio>\nint main(int c, char** v) { try { auto g = svsx::io::read_index_config(v[1]);\n'
+                   'std::printf("%u %d %d %.10g %zu %zu %zu %zu %d %zu %zu %d %zu %zu\\n", g.entry_point, g.has_build, g.has_search, g.alpha, g.graph_max_degree, g.window_size,'
+                   ' g.max_candidate_pool_size, g.prune_to, g.use_full_search_history, g.search_window_size, g.search_buffer_capacity, g.search_buffer_visited_set,'
+                   ' g.prefetch_lookahead, g.prefetch_step); } catch (const std::exception& e) { std::printf("error %s\\n", e.what()); return 1; } return 0; }\n')
+    exe = str(tmp_path / "cfg")
+    subprocess.check_call(["g++", "-std=c++20", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    run = lambda p: subprocess.run([exe, str(p)], capture_output=True, text=True)
+    assert run(golden).stdout.split() == ["9426", "1", "1", "1.200000048", "128", "200", "1000", "128", "1", "0", "0", "0", "0", "0"]
+    assert run(tuned).stdout.split()[9:12] == ["24", "48", "1"]
+    assert run(legacy).stdout.split() == ["77", "1", "1", "0.9499999881", "64", "128", "750", "64", "1", "33", "33", "1", "4", "1"]
+    assert run(bad).returncode == 1 and "search window larger" in run(bad).stdout
