@@ -429,6 +429,47 @@ class Ref:
     def buffer(self, window, capacity, greater=False, visited_set=False):
         return RefBuffer(self, window, capacity, greater, visited_set)
 
+    def flat_search(self, metric, data, queries, k):
+        """FlatIndex::search's loop around the reference's own BulkInserter / HeapInserter (index/flat/inserters.h) and distance kernels:
+        ids (u64) and distances in the order std::sort_heap leaves them."""
+        data = np.ascontiguousarray(data)
+        queries = np.ascontiguousarray(queries)
+        nq = queries.shape[0]
+        ids = np.empty((nq, k), np.uint64)
+        dists = np.empty((nq, k), np.float32)
+        self.lib.svsref_flat_search.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        rc = self.lib.svsref_flat_search(metric, _ptr(data), dtype_code(data), data.shape[0], _ptr(queries), dtype_code(queries), nq, data.shape[1], k, _ptr(ids), _ptr(dists))
+        if rc:
+            raise ValueError(f"svsref_flat_search rc={rc}")
+        return ids, dists
+
+    def vecs_dims(self, path, elsize_hint=0):
+        """svs::io::vecs::get_dims (core/io/vecs.h:97-124): (vectors, dimensions), or None where the reference throws."""
+        n, d = C.c_size_t(), C.c_size_t()
+        self.lib.svsref_vecs_dims.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        rc = self.lib.svsref_vecs_dims(os.fsencode(path), elsize_hint, C.byref(n), C.byref(d))
+        return None if rc else (n.value, d.value)
+
+    def vecs_read(self, path, dtype):
+        """VecsReader<T> (core/io/vecs.h:140-190): the whole file as an [n, d] array of `dtype` (4-byte or 1-byte elements)."""
+        dt = np.dtype(dtype)
+        nd = self.vecs_dims(path, dt.itemsize)
+        if nd is None:
+            raise ValueError(f"{path}: the reference's reader rejects it")
+        out = np.empty(nd, np.uint32 if dt.itemsize == 4 else np.uint8)
+        self.lib.svsref_vecs_read.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
+        rc = self.lib.svsref_vecs_read(os.fsencode(path), dt.itemsize, _ptr(out), out.size)
+        if rc:
+            raise ValueError(f"svsref_vecs_read rc={rc}")
+        return out.view(dt)
+
+    def vecs_write_u32(self, path, rows):
+        """VecsWriter<uint32_t> (core/io/vecs.h:196-222); float rows go through as their bit patterns."""
+        rows = np.ascontiguousarray(rows).view(np.uint32)
+        self.lib.svsref_vecs_write_u32.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        if self.lib.svsref_vecs_write_u32(os.fsencode(path), _ptr(rows), rows.shape[0], rows.shape[1]):
+            raise ValueError("svsref_vecs_write_u32 failed")
+
 
 class RefBuffer:
     def __init__(self, ref, window, capacity, greater, visited_set):

@@ -12,6 +12,8 @@
 //   * svs::simd::generic_simd_op, ConvertToFloat<16>, ConvertForVNNI<int16_t,32>, create_mask
 //                                                core/distance/simd_utils.h:204-456
 //   * svs::Float16                               lib/float16.h
+//   * svs::index::flat::BulkInserter / HeapInserter (what FlatIndex::search keeps its k best in)   index/flat/inserters.h:76-235
+//   * svs::io::vecs::get_dims, VecsReader, VecsWriter ([fbi]vecs files)                            core/io/vecs.h:97-229
 //
 // What is NOT buildable in this image and therefore restated below in this file (third-party toml++ /
 // robin-map headers are absent; core/distance/{euclidean,inner_product,cosine}.h include lib/saveload.h ->
@@ -22,11 +24,15 @@
 //      inner_product.h:222-267, cosine.h:261-326).  They are a handful of intrinsics each.
 //   * dataset / graph containers (trivial row views satisfying concepts/data.h, concepts/graph.h).
 //   * the batch loop of VamanaIndex::search (index/vamana/index.h:564-611): static partition over threads.
+//   * the loop of FlatIndex::search (index/flat/flat.h:322-460: data indices ascending, every query's distance inserted into ITS heap,
+//     cleanup = sort_heap, copy out) around the real BulkInserter -- flat.h itself includes core/data.h -> toml++.
 //
 #include "svs/concepts/data.h"
 #include "svs/concepts/distance.h"
 #include "svs/concepts/graph.h"
 #include "svs/core/distance/simd_utils.h"
+#include "svs/core/io/vecs.h"
+#include "svs/index/flat/inserters.h"
 #include "svs/index/vamana/filter.h"
 #include "svs/index/vamana/greedy_search.h"
 #include "svs/index/vamana/search_buffer.h"
@@ -443,6 +449,87 @@ int svsref_distance_batch(int metric, const void* a, int adt, size_t na, const v
         }
     }
     return 0;
+}
+
+// FlatIndex::search (index/flat/flat.h:322-460) with the reference's own sorter_type = BulkInserter<Neighbor<size_t>, compare> (flat.h:173):
+// data indices ascending (search_patch :437-457), one HeapInserter per query (std::pop_heap / push_heap, a candidate EQUAL to the heap's
+// top still replaces it), scratch.cleanup() = std::sort_heap, results copied out in that order.  What ties do is therefore whatever
+// libstdc++'s heap leaves -- this function is the pin for it.
+extern "C++" {
+template <typename Cmp>
+int flat_typed(int metric, const void* data, int ddt, size_t n, const void* queries, int qdt, size_t nq, size_t d, size_t k, uint64_t* ids, float* dists) {
+    using N = svs::Neighbor<size_t>;
+    svs::index::flat::BulkInserter<N, Cmp> scratch{nq, k, Cmp{}};
+    scratch.prepare();
+    const size_t sq = qdt == F32 ? 4 : qdt == F16 ? 2 : 1, sd = ddt == F32 ? 4 : ddt == F16 ? 2 : 1;
+    std::vector<float> norms(nq, 0.0f);
+    for (size_t i = 0; i < nq; ++i)
+        if (metric == COS) norms[i] = svsref_norm(static_cast<const char*>(queries) + i * d * sq, qdt, d);
+    for (size_t j = 0; j < n; ++j) {
+        const char* row = static_cast<const char*>(data) + j * d * sd;
+        for (size_t i = 0; i < nq; ++i) {
+            const float dist = svsref_distance(metric, static_cast<const char*>(queries) + i * d * sq, qdt, row, ddt, d, norms[i]);
+            scratch.insert(i, N{j, dist});
+        }
+    }
+    scratch.cleanup();
+    for (size_t i = 0; i < nq; ++i) {
+        const auto r = scratch.result(i);
+        for (size_t j = 0; j < k; ++j) {
+            ids[i * k + j] = r[j].id();
+            dists[i * k + j] = r[j].distance();
+        }
+    }
+    return 0;
+}
+} // extern "C++"
+
+int svsref_flat_search(int metric, const void* data, int ddt, size_t n, const void* queries, int qdt, size_t nq, size_t d, size_t k, uint64_t* ids, float* dists) {
+    if (metric == L2) return flat_typed<std::less<>>(metric, data, ddt, n, queries, qdt, nq, d, k, ids, dists);
+    return flat_typed<std::greater<>>(metric, data, ddt, n, queries, qdt, nq, d, k, ids, dists);
+}
+
+// core/io/vecs.h: shape of a [fbi]vecs file (get_dims :97-124 with its element-size deduction) and its contents through VecsReader<T>
+// (:140-190); returns 0, or -1 with nothing written when the reference throws.  VecsWriter<T> (:196-222) for the other direction.
+int svsref_vecs_dims(const char* path, size_t elsize_hint, size_t* nvec, size_t* dims) {
+    try {
+        const auto nd = svs::io::vecs::get_dims(std::filesystem::path(path), elsize_hint);
+        *nvec = nd.first;
+        *dims = nd.second;
+        return 0;
+    } catch (const std::exception&) { return -1; }
+}
+
+extern "C++" {
+template <typename T> int vecs_read_typed(const char* path, void* out, size_t capacity_elems) {
+    try {
+        svs::io::vecs::VecsReader<T> reader{std::string(path)};
+        T* dst = static_cast<T*>(out);
+        size_t at = 0;
+        for (auto it = reader.begin(); it != reader.end(); ++it) {
+            const auto v = *it;
+            if (at + v.size() > capacity_elems) return -2;
+            std::copy(v.begin(), v.end(), dst + at);
+            at += v.size();
+        }
+        return 0;
+    } catch (const std::exception&) { return -1; }
+}
+} // extern "C++"
+
+int svsref_vecs_read(const char* path, int elsize, void* out, size_t capacity_elems) {
+    if (elsize == 4) return vecs_read_typed<uint32_t>(path, out, capacity_elems); // fvecs / ivecs rows move as 32-bit words
+    if (elsize == 1) return vecs_read_typed<uint8_t>(path, out, capacity_elems);
+    return -3;
+}
+
+int svsref_vecs_write_u32(const char* path, const uint32_t* rows, size_t n, size_t d) {
+    try {
+        svs::io::vecs::VecsWriter<uint32_t> w{std::string(path), d};
+        for (size_t i = 0; i < n; ++i) w.append(std::span<const uint32_t>(rows + i * d, d));
+        w.flush();
+        return 0;
+    } catch (const std::exception&) { return -1; }
 }
 
 // Batch search through the reference's greedy_search/SearchBuffer.  stats (optional): 2 u64 per query

@@ -77,9 +77,40 @@ def make_iterator_golden():
     print("iterator.npz", os.path.getsize(os.path.join(HERE, "iterator.npz")))
 
 
+def make_flat_golden():
+    """flat.npz: exhaustive search through the reference's own BulkInserter / HeapInserter (index/flat/inserters.h; oracle/_ref svsref_flat_search):
+    a tie-free set (THE top-k: ids and distance bits are the answer) for three metrics / several type pairs, k up to 100 like the reference's
+    groundtruth_*.ivecs, and a set in which every vector occurs four times (what libstdc++'s heap does with exact ties)."""
+    ref = Ref()
+    rng = np.random.default_rng(20260927)
+    out = {}
+    for dt in (F32, F16, I8):
+        out[f"x_{NAMES[dt]}"] = gen(rng, dt, 700, 48)
+        out[f"q_{NAMES[dt]}"] = gen(rng, dt, 6, 48)
+    ks = [1, 10, 100]
+    out["ks"] = np.array(ks)
+    for qa, qb in [(F32, F32), (F32, F16), (F16, F16), (I8, I8), (F32, I8)]:
+        for m in (L2, IP, COS):
+            for k in ks:
+                ids, dd = ref.flat_search(m, out[f"x_{NAMES[qb]}"], out[f"q_{NAMES[qa]}"], k)
+                out[f"ids_{NAMES[qa]}_{NAMES[qb]}_{m}_{k}"] = ids
+                out[f"dists_{NAMES[qa]}_{NAMES[qb]}_{m}_{k}"] = dd
+    base = rng.standard_normal((50, 24)).astype(np.float32)
+    out["x_tied"] = np.concatenate([base, base, base, base])[rng.permutation(200)]
+    out["q_tied"] = rng.standard_normal((5, 24)).astype(np.float32)
+    for k in (3, 10):
+        ids, dd = ref.flat_search(L2, out["x_tied"], out["q_tied"], k)
+        out[f"ids_tied_{k}"] = ids
+        out[f"dists_tied_{k}"] = dd
+    np.savez_compressed(os.path.join(HERE, "flat.npz"), **out)
+    print("flat.npz", os.path.getsize(os.path.join(HERE, "flat.npz")))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "iterator":
         return make_iterator_golden()
+    if len(sys.argv) > 1 and sys.argv[1] == "flat":
+        return make_flat_golden()
     ref, orc = Ref(), Oracle()
     rng = np.random.default_rng(20260926)
 
@@ -154,6 +185,7 @@ def main():
     for f in ("distances.npz", "search.npz", "buffer_trace.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
     make_iterator_golden()
+    make_flat_golden()
 
 
 if __name__ == "__main__":

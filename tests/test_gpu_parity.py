@@ -631,3 +631,30 @@ def test_search_buffers_beyond_one_waves_lds(svs, oracle, small_world, w, c, k, 
         assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all(), (w, c, k, mode)
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
         assert "general=1" in idx.last_kernel_info(), idx.last_kernel_info()
+
+
+def test_contraction_sensitive_inputs(svs, oracle):
+    """the inputs of tests/test_contraction_choices.py (scalar-quantization decompress, inner-product epilogue and cosine query norm where a
+    contracted multiply-add would give other float32 bits): the GPU path follows the oracle's -- the reference build's -- un-contracted reading"""
+    from test_contraction_choices import contraction_sensitive_sq
+
+    scale, bias, codes = contraction_sensitive_sq()
+    rng = np.random.default_rng(1)
+    d = 64
+    x = rng.choice(codes, size=(600, d)).astype(np.int8)
+    q = rng.standard_normal((16, d)).astype(np.float32)
+    sq = (float(scale), float(bias))
+    for metric, fn in ((COS, svs.DistanceCosineSimilarity()), (IP, svs.DistanceIP())):
+        g, e = oracle.build_vamana(metric, x.astype(np.float32) * scale + bias, R=16, L=32, alpha=0.95)
+        idx = svs.VamanaIndex(g, x, fn, e, sq=sq)
+        for mode in (0, 2):
+            if mode:
+                idx.build_bound_codes(mode)
+            res = idx.search(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(40), True))
+            ids, dists = oracle.search(metric, x, g, e, q, 10, 40, sq=sq)
+            assert (res.indices == ids.astype(np.uint64)).all() and (res.distances.view(np.uint32) == dists.view(np.uint32)).all(), (metric, mode)
+    rngq = np.random.default_rng(7)  # cosine query norms on plain float rows
+    xf = rngq.standard_normal((400, 96)).astype(np.float32)
+    qf = rngq.standard_normal((64, 96)).astype(np.float32)
+    got = svs.compute(svs.DistanceCosineSimilarity(), qf, xf)
+    assert (got.view(np.uint32) == oracle.distance_batch(COS, qf, xf).view(np.uint32)).all()

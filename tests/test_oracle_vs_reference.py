@@ -146,3 +146,94 @@ def test_live_buffer_nan_distances_vs_reference_headers(oracle, ref):
             assert len(sa) == len(sb)
             for u, v in zip(sa, sb):
                 assert u[0] == v[0] and u[2] == v[2] and same(u[1], v[1]), (trial, step, u, v)
+
+
+def test_live_flat_search_vs_reference_inserters(oracle, ref):
+    """FlatIndex::search keeps every query's k best in a HeapInserter (index/flat/inserters.h:76-116 through BulkInserter, flat.h:173) fed in
+    data order and returns what std::sort_heap leaves.  Without ties that is THE top-k: oracle == reference, ids and distance bits.  With exact
+    ties the reference's ids are whatever libstdc++'s heap leaves (an equal candidate replaces the heap's top, inserters.h:96-106); the oracle
+    and the GPU path order ties by lower id -- distances are still identical row by row, ids can only differ inside a group of equal
+    distance.  Both facts are pinned here against the reference's own inserter."""
+    rng = np.random.default_rng(11)
+    for m in (L2, IP, COS):
+        for qa, qb in [(F32, F32), (F32, F16), (F16, F16), (I8, I8), (F32, U8)]:
+            x = (rng.standard_normal((500, 40)) * (20 if qb in (I8, U8) else 1)).astype({F32: np.float32, F16: np.float16, I8: np.int8, U8: np.uint8}[qb])
+            if qb == U8:
+                x = np.abs(x.astype(np.int16)).astype(np.uint8)
+            q = (rng.standard_normal((7, 40)) * (20 if qa == I8 else 1)).astype({F32: np.float32, F16: np.float16, I8: np.int8}[qa])
+            oi, od = oracle.flat_search(m, x, q, 10)
+            ri, rd = ref.flat_search(m, x, q, 10)
+            assert _bits_equal(od, rd), (m, qa, qb)
+            tie_free = np.array([len(np.unique(ref.distance_batch(m, q[i : i + 1], x)[0])) == 500 for i in range(len(q))])
+            assert (oi[tie_free] == ri[tie_free].astype(np.uint32)).all(), (m, qa, qb)
+    # exact ties: every vector four times, k cuts through a tie group
+    base = rng.standard_normal((60, 24)).astype(np.float32)
+    x = np.concatenate([base, base, base, base])[rng.permutation(240)]
+    q = rng.standard_normal((9, 24)).astype(np.float32)
+    differ = 0
+    for k in (1, 3, 6, 10):
+        oi, od = oracle.flat_search(L2, x, q, k)
+        ri, rd = ref.flat_search(L2, x, q, k)
+        assert _bits_equal(od, rd)                       # the same distances in the same order ...
+        full = ref.distance_batch(L2, q, x)
+        for i in range(len(q)):
+            for ids in (oi[i].astype(np.int64), ri[i].astype(np.int64)):
+                assert len(set(ids.tolist())) == k and (full[i][ids].view(np.uint32) == rd[i].view(np.uint32)).all()  # ... of real, distinct rows
+            differ += int((oi[i].astype(np.int64) != ri[i].astype(np.int64)).any())
+    assert differ > 0  # the heap really does not pick the lowest ids: a documented difference under exact ties (DESIGN section 2)
+
+
+def test_live_vecs_readers_vs_reference(ref, tmp_path):
+    """[fbi]vecs (core/io/vecs.h): this repo's readers / writer against the reference's get_dims (with its element-size deduction),
+    VecsReader and VecsWriter, on float / int / byte files incl. the reference-held known_f32.fvecs, a one-vector file, and malformed files."""
+    from scalablevectorsearch_amd import io
+
+    rng = np.random.default_rng(5)
+    f = rng.standard_normal((13, 7)).astype(np.float32)
+    io.write_fvecs(str(tmp_path / "a.fvecs"), f)
+    assert ref.vecs_dims(str(tmp_path / "a.fvecs")) == (13, 7) and ref.vecs_dims(str(tmp_path / "a.fvecs"), 4) == (13, 7)
+    assert (ref.vecs_read(str(tmp_path / "a.fvecs"), np.float32).view(np.uint32) == f.view(np.uint32)).all()
+    assert (io.read_fvecs(str(tmp_path / "a.fvecs")).view(np.uint32) == f.view(np.uint32)).all()
+    iv = rng.integers(0, 2**31, (5, 100)).astype(np.uint32)   # the layout of the reference's groundtruth_*.ivecs (1000 x 100)
+    ref.vecs_write_u32(str(tmp_path / "b.ivecs"), iv)          # the reference WRITES, we read
+    assert (io.read_ivecs(str(tmp_path / "b.ivecs")).view(np.uint32) == iv).all() and ref.vecs_dims(str(tmp_path / "b.ivecs")) == (5, 100)
+    bv = rng.integers(0, 256, (9, 16)).astype(np.uint8)
+    raw = np.empty((9, 4 + 16), np.uint8)
+    raw[:, :4] = np.array([16], np.uint32).view(np.uint8)
+    raw[:, 4:] = bv
+    raw.tofile(str(tmp_path / "c.bvecs"))
+    assert ref.vecs_dims(str(tmp_path / "c.bvecs")) == (9, 16)   # element size 1 deduced
+    assert (ref.vecs_read(str(tmp_path / "c.bvecs"), np.uint8) == bv).all() and (io.read_bvecs(str(tmp_path / "c.bvecs")) == bv).all()
+    known = os.path.join(GOLD, "known_f32.fvecs")
+    assert ref.vecs_dims(known) is not None
+    assert (ref.vecs_read(known, np.float32).view(np.uint32) == io.read_fvecs(known).view(np.uint32)).all()
+    io.write_fvecs(str(tmp_path / "one.fvecs"), f[:1])
+    assert ref.vecs_dims(str(tmp_path / "one.fvecs")) == (1, 7) and io.read_fvecs(str(tmp_path / "one.fvecs")).shape == (1, 7)
+    open(tmp_path / "bad.fvecs", "wb").write(open(tmp_path / "a.fvecs", "rb").read()[:-3])  # truncated: both sides refuse
+    assert ref.vecs_dims(str(tmp_path / "bad.fvecs")) is None
+    with pytest.raises(Exception):
+        io.read_fvecs(str(tmp_path / "bad.fvecs"))
+
+
+def test_golden_flat_search(oracle):
+    """tests/golden/flat.npz (generated from the reference's own inserters): where a query's distances are tie-free the oracle returns the same
+    ids and distance bits, k = 1 / 10 / 100; with exact ties the distances agree and every returned id is a real row at that distance."""
+    g = np.load(os.path.join(GOLD, "flat.npz"))
+    for qa, qb in [(F32, F32), (F32, F16), (F16, F16), (I8, I8), (F32, I8)]:
+        x, q = g[f"x_{NAMES[qb]}"], g[f"q_{NAMES[qa]}"]
+        for m in (L2, IP, COS):
+            full = oracle.distance_batch(m, q, x)
+            for k in (int(v) for v in g["ks"]):
+                oi, od = oracle.flat_search(m, x, q, k)
+                gi, gd = g[f"ids_{NAMES[qa]}_{NAMES[qb]}_{m}_{k}"], g[f"dists_{NAMES[qa]}_{NAMES[qb]}_{m}_{k}"]
+                assert _bits_equal(od, gd), (qa, qb, m, k)
+                for i in range(len(q)):
+                    if len(np.unique(full[i])) == len(full[i]):
+                        assert (oi[i] == gi[i].astype(np.uint32)).all(), (qa, qb, m, k, i)
+    for k in (3, 10):
+        oi, od = oracle.flat_search(L2, g["x_tied"], g["q_tied"], k)
+        assert _bits_equal(od, g[f"dists_tied_{k}"])
+        full = oracle.distance_batch(L2, g["q_tied"], g["x_tied"])
+        for i in range(len(od)):
+            for ids in (oi[i].astype(np.int64), g[f"ids_tied_{k}"][i].astype(np.int64)):
+                assert len(set(ids.tolist())) == k and (full[i][ids].view(np.uint32) == od[i].view(np.uint32)).all()
