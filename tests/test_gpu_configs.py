@@ -236,6 +236,44 @@ def test_native_sharded_search_in_the_library(svs, oracle, single_rank_comm):
     ns.close()
 
 
+@pytest.mark.parametrize("n_local,comm", [(1, True), (3, True), (3, False)])
+def test_native_sharded_pipeline_large_batches(svs, oracle, n_local, comm):
+    """svsx_sharded_search_device's pipeline on one GPU: batches of >= 8 192 queries are exchanged in two chunks (the all-gather + merge of the
+    first on an internal stream under the second's search), several local shards run on two internal streams; a one-rank RCCL communicator
+    stands in for the world.  Against oracle searches merged by the rule; then a small batch on another stream right behind it."""
+    import torch
+
+    from oracle.oracle import merge_topk_ref
+    from scalablevectorsearch_amd.sharded import NativeShardedSearcher
+
+    n, d, nq, k = 1200, 96, 8300, 5
+    base = (1 << 32) + 99
+    q = deep_like(nq, d, 24, seed=61)
+    indexes, want_d, want_i = [], [], []
+    for s in range(n_local):
+        x = deep_like(n, d, 24, seed=700 + s)
+        g, e = oracle.build_vamana(L2, x, R=24, L=40)
+        idx = svs.VamanaIndex(g, x, svs.DistanceL2(), e, id_offset=s * base)
+        if s == 0:
+            idx.build_bound_codes(2)
+        indexes.append(idx)
+        oi, od = oracle.search(L2, x, g, e, q, k, 24)
+        want_i.append(oi.astype(np.int64) + s * base)
+        want_d.append(od)
+    wd, wi = merge_topk_ref(L2, np.stack(want_d), np.stack(want_i), k)
+    ns = NativeShardedSearcher(indexes, single_rank_comm=comm)
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(24))
+    dq = torch.from_numpy(q).cuda()
+    side = torch.cuda.Stream()
+    for _ in range(2):
+        md, mi = ns.search(dq, k, sp)
+        md2, mi2 = ns.search(dq[:7], k, sp, stream=side.cuda_stream)  # chained behind the big call although it is on another stream
+        torch.cuda.synchronize()
+        assert (mi.cpu().numpy() == wi).all() and (_bits(md.cpu().numpy()) == _bits(wd)).all()
+        assert (mi2.cpu().numpy() == wi[:7]).all() and (_bits(md2.cpu().numpy()) == _bits(wd[:7])).all()
+    ns.close()
+
+
 def test_config5_shards_with_64bit_offsets(svs, oracle):
     import torch
 

@@ -226,8 +226,8 @@ def test_range_and_filtered_search_on_gpu(svs, oracle, small_world):
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (_bits(a[2]) == _bits(b[2])).all()
         assert a[0][-1] > 0
     for k, stop in ((10, 0.0), (25, 0.0), (10, 0.5)):
-        a = svs.filtered_search(idx, q, k, member, filter_stop=stop)
-        b = svs.filtered_search(fake, q, k, member, filter_stop=stop, make_iterator=_OracleBatchIterator)
+        a = svs.filtered_search(idx, q, k, member, filter_stop=stop, filter_estimate_batch=False)
+        b = svs.filtered_search(fake, q, k, member, filter_stop=stop, make_iterator=_OracleBatchIterator, filter_estimate_batch=False)
         assert (a.indices == b.indices).all() and (_bits(a.distances) == _bits(b.distances)).all()
         # the same loop inside the library (svsx_search_filtered: the IDFilter argument of the runtime's batch operator)
         c = idx.search_filtered(q, k, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), filter_stop=stop, filter_estimate_batch=False)
@@ -245,7 +245,7 @@ def test_range_and_filtered_search_on_gpu(svs, oracle, small_world):
     assert (none.indices == np.uint64(2**64 - 1)).all() and np.isposinf(none.distances).all()
     few = np.zeros(sw["x"].shape[0], bool)
     few[[3, 500, 900, 1400]] = True
-    a = svs.filtered_search(idx, q, 3, few)
+    a = svs.filtered_search(idx, q, 3, few, filter_estimate_batch=False)
     c = idx.search_filtered(q, 3, few, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)), filter_estimate_batch=False)
     assert (a.indices == c.indices).all() and (c.indices != np.uint64(2**64 - 1)).all()
 
@@ -273,8 +273,8 @@ def test_filtered_search_with_buffers_beyond_lds(svs, oracle):
     member = np.zeros(n, bool)
     far = np.argsort(((x - q[0]) ** 2).sum(1))[-4:]  # the members are the points FARTHEST from the first query
     member[far] = True
-    want = svs.filtered_search(fake, q, 3, member, make_iterator=_OracleBatchIterator)
-    got = svs.filtered_search(idx, q, 3, member)
+    want = svs.filtered_search(fake, q, 3, member, make_iterator=_OracleBatchIterator, filter_estimate_batch=False)
+    got = svs.filtered_search(idx, q, 3, member, filter_estimate_batch=False)
     assert (got.indices == want.indices).all() and (_bits(got.distances) == _bits(want.distances)).all()
     lib = idx.search_filtered(q, 3, member, svs.VamanaSearchParameters(svs.SearchBufferConfig(4000)), filter_estimate_batch=False)
     assert (lib.indices == want.indices).all() and (_bits(lib.distances) == _bits(want.distances)).all()
