@@ -60,16 +60,17 @@ def counter_normal(n_rows, n_cols, seed, stream, device, row0=0):
     return (torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)).to(torch.float32)
 
 
-def deep_like_device(n, d, latent, seed, device, sigma=0.1, normalize=True):
-    """SURVEY 8d generator G(latent, sigma): x = normalize(z A + sigma eps), A from seed 7, own counter-based RNG."""
+def deep_like_device(n, d, latent, seed, device, sigma=0.1, normalize=True, row0=0):
+    """SURVEY 8d generator G(latent, sigma): x = normalize(z A + sigma eps), A from seed 7, own counter-based RNG.  Rows row0 .. row0 + n of
+    the stream (a pure function of the row index: chunked generation equals one-shot generation)."""
     import torch
 
     a = counter_normal(latent, d, 7, 0, device)
     out = torch.empty((n, d), device=device)
     for lo in range(0, n, 1 << 18):
         m = min(1 << 18, n - lo)
-        z = counter_normal(m, latent, seed, 1, device, row0=lo)
-        e = counter_normal(m, d, seed, 2, device, row0=lo)
+        z = counter_normal(m, latent, seed, 1, device, row0=row0 + lo)
+        e = counter_normal(m, d, seed, 2, device, row0=row0 + lo)
         x = z @ a + sigma * e
         out[lo : lo + m] = x / x.norm(dim=1, keepdim=True) if normalize else x
     return out
@@ -247,7 +248,43 @@ def cpu_baseline(x, q, graph, entry, R, k, window, gpu_ids):
     }
 
 
-def build_or_load_graph(svs, x, n, d, R, local_rank, cache, distance=None, alpha=1.2, data_dtype=np.float32, sq=None):
+def cpu_scaling(x, q, graph, entry, R, k, windows):
+    """QPS of the CPU leg at 1 / 2 / 4 / ... threads (the reference's own code, oracle/_ref; static partition of the queries over threads like
+    index/vamana/index.h:571-574), 1 warm-up + 3 timed runs each (best reported; benchmark/include/svs-benchmark/search.h:209-219), samples sized
+    for ~1.5 s per run: how far from linear the host leg scales, next to the speed-up that assumes it."""
+    from scalablevectorsearch_amd.build import device_graph_to_svs
+
+    from oracle.oracle import L2, Ref
+
+    if not Ref.available():
+        return None
+    r = Ref()
+    xh, qh, gh, eh = x.cpu().numpy(), q.cpu().numpy(), device_graph_to_svs(graph, R), np.array([entry], np.uint32)
+    ncores = host_cores()
+    counts = [t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t <= ncores]
+    if counts[-1] != ncores:
+        counts.append(ncores)
+    out = {}
+    for w in windows:
+        t0 = time.perf_counter()
+        r.search(L2, xh, gh, eh, qh[:32], k, w, nthreads=1)
+        per_thread_rate = 32 / (time.perf_counter() - t0)
+        row = {}
+        for t in counts:
+            ns = int(min(len(qh), max(32 * t, per_thread_rate * t * 1.5)))
+            best = 0.0
+            for rep in range(4):
+                t0 = time.perf_counter()
+                r.search(L2, xh, gh, eh, qh[:ns], k, w, nthreads=t)
+                dt = time.perf_counter() - t0
+                if rep:
+                    best = max(best, ns / dt)
+            row[str(t)] = best
+        out[str(w)] = {"qps_by_threads": row, "efficiency_at_max_threads": row[str(counts[-1])] / (row["1"] * counts[-1])}
+    return out
+
+
+def build_or_load_graph(svs, x, n, d, R, local_rank, cache, distance=None, alpha=1.2, data_dtype=np.float32, sq=None, build_window=0):
     import torch
 
     from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device
@@ -257,7 +294,7 @@ def build_or_load_graph(svs, x, n, d, R, local_rank, cache, distance=None, alpha
         blob = torch.load(cache, map_location=x.device)
         graph, entry = blob["graph"], blob["entry"]
     else:
-        bp = VamanaBuildParameters(alpha=alpha, graph_max_degree=R, window_size=2 * R, max_candidate_pool_size=750, prune_to=R - 4)
+        bp = VamanaBuildParameters(alpha=alpha, graph_max_degree=R, window_size=build_window or 2 * R, max_candidate_pool_size=750, prune_to=R - 4)
         graph, entry = build_vamana_device(x, n, d, distance if distance is not None else svs.DistanceL2(), bp, data_dtype=data_dtype, device=local_rank, sq=sq)
         if cache:
             torch.save({"graph": graph, "entry": entry}, cache)
@@ -278,7 +315,11 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
     if total % world:
         return {"skipped": f"8 shards do not divide over {world} GPUs"}
     per = total // world
-    n5, nq = args.c5_n, q.shape[0]
+    nq = q.shape[0]
+    # --c5-n 0 (default): BASELINE config 5's own shard, 12 500 000 vectors, whenever the 8 / N shards of a GPU fit its HBM with their inline
+    # records (N >= 2: 37 GB per shard), else -- one GPU holding all eight -- 1 000 000 vectors per shard so that the default N = 1 line stays
+    # within minutes (the 100 M index on one GPU is `--config c5`: profiles/r03_bench_c5_100M_8shards_1gpu.json)
+    n5 = args.c5_n or (12_500_000 if world >= 2 else 1_000_000)
     t0 = time.time()
     keep, indexes = [], []
     for s_ in range(per):
@@ -342,12 +383,119 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
            "rccl_communicator": info["communicator"], "rccl_ranks": info["world"], "build_seconds_this_rank": t_build,
            "path": "svsx_sharded_search_device (libsvsx: per-shard search -> local merge -> ONE ncclAllGather -> world-way merge, one stream)",
            "scaling": "strong (the set of 8 shards is fixed as N grows)",
-           "shard_size_note": f"{n5} vectors per shard so that the build fits the bench's time budget; the 12.5 M-vector shard of BASELINE config 5 is --config c5"}
+           "shard_size_note": ("BASELINE config 5's shard size" if n5 == 12_500_000 else
+                               f"{n5} vectors per shard: all eight shards of a one-GPU run with 12.5 M vectors take 8 x 29 s to build (that run is --config c5)")}
     ns.close()
     return res
 
 
+def config4_point(args, svs, device, local_rank, k, t_run0):
+    """BASELINE config 4 inside the default line: synthetic N x 768 scalar-quantized int8 rows (SQDataset-style global scale / bias, scalar.h:454-462),
+    float32 queries, cosine, batch 4 096, the reference's regression graph parameters (R = 128, L = 200, prune_to 124, alpha 0.95).  N = --c4-n
+    (10 M) when the GPU has the memory and the run the time (build ~340 s), else 2 M -- the size is in the point.  Smallest window with
+    recall@10 >= 0.9 by binary search, timed like the headline; ids of a query sample checked against the CPU oracle."""
+    import torch
+
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
+
+    d4, nq4, R4 = 768, 4096, 128
+    total_hbm = torch.cuda.get_device_properties(device).total_memory
+    free_hbm = torch.cuda.mem_get_info(device)[0]
+    n4 = args.c4_n
+    left = args.budget_s - (time.time() - t_run0)
+    need = lambda n_: n_ * (d4 + 129 * 4 + 128 * 132 + 2 * d4 + 8) * 1.08  # codes, graph, 128-byte inline records, float16 shadow, row norms
+    why = None
+    if n4 > 2_000_000 and (need(n4) > free_hbm or left < 60 + 40e-6 * n4 * 1.3):
+        why = f"{n4} vectors need {need(n4) / 1e9:.0f} GB and ~{40e-6 * n4:.0f} s; {free_hbm / 1e9:.0f} GB free and {left:.0f} s left"
+        n4 = 2_000_000
+    t0 = time.time()
+    fn = svs.DistanceCosineSimilarity()
+    mn, mx = None, None
+    x4 = torch.empty((n4, d4), dtype=torch.int8, device=device)
+    # two passes over the generator keep the float32 rows out of memory: global min / max first (scalar.h:454-462), then the codes
+    for lo in range(0, n4, 1 << 20):
+        xf = deep_like_device(min(1 << 20, n4 - lo), d4, 64, seed=1, device=device, normalize=False, row0=lo)
+        mn = float(xf.min()) if mn is None else min(mn, float(xf.min()))
+        mx = float(xf.max()) if mx is None else max(mx, float(xf.max()))
+    scale = (mx - mn) / 255.0
+    bias = mn + 128.0 * scale
+    for lo in range(0, n4, 1 << 20):
+        xf = deep_like_device(min(1 << 20, n4 - lo), d4, 64, seed=1, device=device, normalize=False, row0=lo)
+        x4[lo : lo + xf.shape[0]] = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8)
+    del xf
+    q4 = deep_like_device(nq4, d4, 64, seed=2, device=device, normalize=False)
+    sq = (scale, bias)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    g4, e4 = build_vamana_device(x4, n4, d4, fn, VamanaBuildParameters(alpha=0.95, graph_max_degree=R4, window_size=200, prune_to=R4 - 4), data_dtype=np.int8, device=local_rank, sq=sq)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    i4 = svs.VamanaIndex.from_device(g4, x4, fn, torch.tensor([e4], dtype=torch.int32, device=device), n4, d4, np.int8, device=local_rank, sq=sq)
+    gt4, _ = i4.flat_search_device(q4, k)  # exhaustive ground truth (MFMA shortlist + exact re-rank) before the inline records take their memory
+    torch.cuda.synchronize()
+    i4.build_bound_codes(2)
+    ids4 = torch.empty((nq4, k), dtype=torch.int64, device=device)
+    dd4 = torch.empty((nq4, k), dtype=torch.float32, device=device)
+    st4 = torch.zeros((nq4, 6), dtype=torch.int32, device=device)
+    lo_w, hi_w = 64, 1024
+    while lo_w < hi_w:  # calibrate.h:286-300
+        mid = (lo_w + hi_w) // 2
+        i4.search_device(q4, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(mid), 1), d_ids64=ids4, d_dists=dd4)
+        torch.cuda.synchronize()
+        if recall_at(gt4, ids4, k) >= 0.9:
+            hi_w = mid
+        else:
+            lo_w = mid + 1
+    sp4 = svs.VamanaSearchParameters(svs.SearchBufferConfig(lo_w), 1)
+    i4.search_device(q4, k, sp4, d_ids64=ids4, d_dists=dd4, d_stats=st4)
+    for _ in range(args.warmup):
+        i4.search_device(q4, k, sp4, d_ids64=ids4, d_dists=dd4)
+    torch.cuda.synchronize()
+    ev4 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, args.steps // 2))]
+    for a_, b_ in ev4:
+        a_.record()
+        i4.search_device(q4, k, sp4, d_ids64=ids4, d_dists=dd4)
+        b_.record()
+    torch.cuda.synchronize()
+    ms4 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev4]))
+    k4 = i4.last_kernel_info()
+    rb4 = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(k4[-8:], 128)
+    l4 = designed_lines(st4.to(torch.int64), 128, d4, 2, d4, k, rb4)
+    point = {"workload": f"synthetic {n4} x 768 scalar-quantized int8 (global scale / bias), float32 queries, cosine, batch={nq4}, k=10, graph R=128 L=200 prune_to 124 alpha 0.95, 1xMI355X",
+             "vectors": n4, "size_note": why or "BASELINE config 4's size", "window_for_recall_0.9": lo_w, "recall_at_10": recall_at(gt4, ids4, k), "qps": nq4 / (ms4 * 1e-3), "kernel_ms": ms4,
+             "kernel": "svsx::" + k4, "expansions_per_query": int(st4[:, 0].sum()) / nq4, "distance_evals_per_query": int(st4[:, 2].sum()) / nq4,
+             "bound_code_rejects_per_query": int(st4[:, 5].sum()) / nq4, "designed_lines_per_query": l4["total"] / nq4,
+             "frac_designed": l4["total"] * LINE / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, "generate_seconds": t_gen, "build_seconds": t_build,
+             "bound": "vector ALU (decompress + dot product per element, scalar.h:155-195); row norms precomputed at index creation since round 4"}
+    try:  # the same searches on the host by the CPU oracle for a query sample: ids identical?
+        from oracle.oracle import COS, Oracle
+
+        ns = 8
+        host_need = 4 * (n4 * d4 + n4 * (R4 + 1) * 4)  # host copies of codes and graph, plus the temporaries of the layout conversion
+        try:
+            lim = open("/sys/fs/cgroup/memory.max").read().strip()
+            host_have = int(lim) if lim != "max" else 1 << 62
+        except OSError:
+            host_have = 1 << 62
+        import psutil
+
+        host_have = min(host_have, psutil.virtual_memory().available)
+        if host_need > 0.5 * host_have:
+            raise MemoryError(f"host copies need {host_need / 1e9:.0f} GB, {host_have / 1e9:.0f} GB available: sample check skipped")
+        o = Oracle()
+        xh = x4.cpu().numpy()
+        gh = device_graph_to_svs(g4, R4)
+        oi, _ = o.search(COS, xh, gh, np.array([e4], np.uint32), q4[:ns].cpu().numpy(), k, lo_w, sq=sq)
+        point["oracle_sample"] = {"queries": ns, "ids_identical": bool((oi.astype(np.int64) == ids4[:ns].cpu().numpy()).all())}
+        del xh, gh
+    except Exception as e:  # noqa: BLE001
+        point["oracle_sample"] = {"error": f"{type(e).__name__}: {e}"}
+    del x4, g4, i4, gt4, ids4, dd4, st4
+    return point
+
+
 def main():
+    t_run0 = time.time()
     _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,7 +512,9 @@ def main():
     ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
     ap.add_argument("--bound-codes", type=int, default=2, help="result-neutral lower-bound rejection: 2 graph-inline records (default), 1 128-B code rows, 0 off")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph(s) here (lets a profiler run skip the build)")
-    ap.add_argument("--c5-n", type=int, default=1_000_000, help="vectors per shard of the config.sharded_c5 point of the default line (0 = skip it)")
+    ap.add_argument("--c5-n", type=int, default=0, help="vectors per shard of the sharded_c5 point (0 = 12 500 000 at N >= 2, 1 000 000 at N = 1; -1 = skip the point)")
+    ap.add_argument("--c4-n", type=int, default=10_000_000, help="vectors of the config-4 point (10 M = BASELINE config 4; falls back to 2 M when time or memory is short; 0 = skip)")
+    ap.add_argument("--budget-s", type=float, default=1500.0, help="wall-clock budget of the whole run: the long extras (config 4 at 10 M) are sized against what is left")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational points (sharded_c5, other configs, 4x batch)")
     args = ap.parse_args()
 
@@ -561,7 +711,7 @@ def main():
 
     # ---- the sharded search of SURVEY 8(e), measured in the same run (every rank takes part) -----------------------------------------
     sharded = None
-    if not c5 and not args.no_extras and args.c5_n > 0:
+    if not c5 and not args.no_extras and args.c5_n >= 0:
         import threading
 
         def give_up():  # a collective that never returns must not cost the headline line
@@ -803,6 +953,45 @@ def main():
                 del x3, q3, g3, i3, ids3, dd3, st3, gt3
             except Exception as e:  # informational: never fail the line over it
                 log(f"[bench] config-3 point skipped: {e}")
+        if not args.no_extras:
+            try:  # config 2 on the reference's regression graph (tools/benchmark_inputs/vamana/static-regression.toml: R = 128, L = 200, prune_to 124)
+                t0 = time.time()
+                g128, e128, _ = build_or_load_graph(svs, shards[0]["x"], n, d, 128, local_rank, "", build_window=200)
+                i128 = svs.VamanaIndex.from_device(g128, shards[0]["x"], svs.DistanceL2(), torch.tensor([e128], dtype=torch.int32, device=device), n, d, np.float32, device=local_rank)
+                i128.build_bound_codes(2)
+                torch.cuda.synchronize()
+                t_b128 = time.time() - t0
+                ids128 = torch.empty((nq, k), dtype=torch.int64, device=device)
+                dd128 = torch.empty((nq, k), dtype=torch.float32, device=device)
+                st128 = torch.zeros((nq, 6), dtype=torch.int32, device=device)
+                i128.search_device(q, k, sp, d_ids64=ids128, d_dists=dd128, d_stats=st128)
+                for _ in range(args.warmup):
+                    i128.search_device(q, k, sp, d_ids64=ids128, d_dists=dd128)
+                torch.cuda.synchronize()
+                ev128 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                for a_, b_ in ev128:
+                    a_.record()
+                    i128.search_device(q, k, sp, d_ids64=ids128, d_dists=dd128)
+                    b_.record()
+                torch.cuda.synchronize()
+                ms128 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev128]))
+                k128 = i128.last_kernel_info()
+                l128 = designed_lines(st128.to(torch.int64), 128, d * 4, 2, d, k, {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(k128[-8:], 32))
+                result["config"].setdefault("other_configs", {})["c2_regression_graph_r128"] = {
+                    "workload": f"deep-1M-like d=96 float32 L2, batch={nq}, search_window={args.window}, k=10, graph R=128 L=200 prune_to 124 alpha 1.2 (static-regression.toml), 1xMI355X",
+                    "qps": nq / (ms128 * 1e-3), "kernel_ms": ms128, "recall_at_10": recall_at(gt, ids128, k), "kernel": "svsx::" + k128,
+                    "mean_degree": float((g128[:, :128] >= 0).sum(1).float().mean()), "expansions_per_query": int(st128[:, 0].sum()) / nq,
+                    "designed_lines_per_query": l128["total"] / nq, "frac_designed": l128["total"] * LINE / (ms128 * 1e-3) / 1e9 / HBM_PEAK_GBS, "build_seconds": t_b128}
+                del g128, i128, ids128, dd128, st128
+            except Exception as e:  # informational: never fail the line over it
+                log(f"[bench] config-2 R=128 point skipped: {e}")
+            try:
+                if args.c4_n > 0:
+                    result["config"].setdefault("other_configs", {})["c4"] = config4_point(args, svs, device, local_rank, k, t_run0)
+            except Exception as e:  # informational: never fail the line over it
+                result["config"].setdefault("other_configs", {})["c4"] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"[bench] config-4 point failed: {e}")
+            torch.cuda.empty_cache()
         index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)  # restore window-128 results for the parity sample
         torch.cuda.synchronize()
         if not args.no_cpu_baseline:
@@ -820,9 +1009,26 @@ def main():
             matched["gpu_over_cpu_note"] = (f"CPU leg uses {cm['cores']} threads (cgroup quota) of {cm['cores_present']} logical CPUs present; "
                                             "a fully used host would be proportionally faster")
             matched["ids_identical_on_sample"] = "identical on sample: True" in cm["sample"]
+            matched["gpu_over_full_host_if_linear"] = matched["gpu_over_cpu"] * cm["cores"] / max(cm["cores_present"], 1)
+            try:  # how the host leg really scales with its threads: both operating points
+                cb["thread_scaling"] = cpu_scaling(sh["x"], q, sh["graph"], sh["entry"], R, k, [args.window, matched["window"]])
+                if cb["thread_scaling"]:
+                    eff = cb["thread_scaling"][str(args.window)]["efficiency_at_max_threads"]
+                    cb["thread_scaling"]["note"] = (f"parallel efficiency of the host leg at its {cm['cores']} usable threads: {eff:.2f} at window {args.window}; "
+                                                    "gpu_over_full_host_if_linear assumes 1.0 for the CPUs the cgroup withholds, so it is a LOWER bound of the real ratio")
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] cpu scaling curve skipped: {e}")
+    if sharded is not None:  # the multi-GPU data path (per-shard search -> ONE RCCL all-gather -> merge) as a top-level metric of its own
+        ok = isinstance(sharded, dict) and "merged_answers_per_s" in sharded
+        result["sharded_search"] = {"metric": "merged answers per second over a FIXED set of 8 database shards (SURVEY 8e; strong scaling in N)",
+                                    "value": sharded.get("merged_answers_per_s") if ok else None, "unit": "queries/s", "n_gpus": world,
+                                    "vectors_per_shard": sharded.get("vectors_per_shard") if ok else None, "failed": not ok,
+                                    "error": None if ok else (sharded.get("error") or sharded.get("skipped") or "unknown")}
     _emit(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+    if world > 1 and sharded is not None and result["sharded_search"]["failed"] and "skipped" not in (sharded or {}):
+        sys.exit(3)  # at N > 1 the sharded search IS the multi-GPU path: its failure fails the run, loudly, after the line has been printed
 
 
 if __name__ == "__main__":

@@ -70,6 +70,13 @@ for f in glob.glob(f"{base}/trace/*kernel_trace.csv"):
     s["kernel_trace"] = {"launches": len(dur), "avg_ms": statistics.mean(dur) / 1e6, "min_ms": min(dur) / 1e6, "max_ms": max(dur) / 1e6,
                          "vgpr": sel[0].get("VGPR_Count"), "sgpr": sel[0].get("SGPR_Count"), "lds": sel[0].get("LDS_Block_Size"),
                          "note": "rocprofv3 --kernel-trace --stats of the same command, the target launches only"}
+    try:  # the HIP-event time of the SAME traced process (target_traced.json) next to the trace's own durations, and the un-profiled process's
+        traced = json.loads(open(f"{base}/target_traced.json").read().strip().splitlines()[-1])
+        s["kernel_ms"] = {"hip_events_unprofiled_process": target["kernel_ms_unprofiled_or_profiled"], "hip_events_in_the_traced_process": traced["kernel_ms_unprofiled_or_profiled"],
+                          "kernel_trace_avg_same_traced_process": s["kernel_trace"]["avg_ms"],
+                          "note": "all three after 12 warm-up launches; the traced figures carry the tracer's per-dispatch overhead, the bench line uses HIP events of its own timed region"}
+    except Exception as e:  # noqa: BLE001
+        s["kernel_ms"] = {"error": str(e)}
     ms = s["kernel_trace"]["avg_ms"]
     s["traffic_rate_GBs"] = s["traffic_bytes_per_launch"] / ms / 1e6
     s["frac_traffic_of_8TBs"] = s["traffic_rate_GBs"] / 8000
