@@ -207,8 +207,8 @@ int svsx_sharded_search_device(
 );
 
 /* Exhaustive search: svs::index::flat::FlatIndex::search (index/flat/flat.h:322-460) -- every query
- * against every vector, k <= 96 best by (distance, then id).  A float16 MFMA pass shortlists min(128, max(4k, k+32))
- * candidates per query (always >= k + 32), which are re-ranked with the exact reference-order distance kernels.  Works on any index, including one
+ * against every vector, k <= 224 best by (distance, then id).  A float16 MFMA pass shortlists min(128, max(4k, k+32)) candidates per query
+ * (k + 32 beyond k = 96; always >= k + 32), which are re-ranked with the exact reference-order distance kernels.  Works on any index, including one
  * created with graph == NULL (a flat index).  Device pointers, enqueued on hip_stream. */
 int svsx_flat_search_device(
     const svsx_index* index, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream

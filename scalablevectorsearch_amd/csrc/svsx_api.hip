@@ -1185,7 +1185,7 @@ int svsx_flat_search_device(
 ) {
     if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k, false)) return rc;
     if (nq == 0) return SVSX_SUCCESS;
-    if (k > 96) return fail(SVSX_INVALID_ARGUMENT, "flat search supports k <= 96 (the float16 shortlist keeps min(128, max(4k, k + 32)) candidates: at least 32 spare ranks for float16 rounding)");
+    if (k > 224) return fail(SVSX_INVALID_ARGUMENT, "flat search supports k <= 224 (the float16 shortlist keeps k + 32 <= 256 candidates per query in LDS: 32 spare ranks for float16 rounding)");
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
     HIP_TRY(hipSetDevice(ix->device));
@@ -1205,10 +1205,16 @@ int svsx_flat_search_device(
             ix->d_norm2 = nrm;
         }
     }
+    // shortlist length: max(4k, k + 32) up to 128 entries; beyond k = 96 (the reference's own ground-truth files hold 100 neighbours per
+    // query, data/test_dataset/groundtruth_*.ivecs) k + 32, the general insert path of the shortlist kernel, up to 256 entries
     size_t kk = 4 * k > k + 32 ? 4 * k : k + 32;
-    if (kk > 128) kk = 128;
-    if (kk < k) kk = k;
+    if (kk > 128) kk = k + 32 > 128 ? k + 32 : 128;
     if (kk > ix->n) kk = ix->n < k ? k : ix->n;
+    {   // the shortlist kernel keeps 64 shortlists (and, beyond d = 128, the 64 queries) of a wave in LDS
+        const size_t need = (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0) + 64 * kk * 8 + 256;
+        if (need > 160 * 1024)
+            return fail(SVSX_INVALID_ARGUMENT, "flat search: k = %zu at d = %zu needs %zu bytes of LDS per wave (160 KB available): lower k", k, ix->d, need);
+    }
     const size_t nqb = (nq + 63) / 64;
     // one round of resident waves: LDS (64 shortlists of kk entries) bounds the waves per CU; a second round would
     // double the time, more slices than needed only add shortlist inserts (measured: 14.1 ms at 80 % of the slots)

@@ -658,3 +658,53 @@ def test_contraction_sensitive_inputs(svs, oracle):
     qf = rngq.standard_normal((64, 96)).astype(np.float32)
     got = svs.compute(svs.DistanceCosineSimilarity(), qf, xf)
     assert (got.view(np.uint32) == oracle.distance_batch(COS, qf, xf).view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("k", [100, 128, 224])
+def test_flat_search_k_beyond_96(svs, oracle, k):
+    """the reference's ground-truth files hold 100 neighbours per query (data/test_dataset/groundtruth_*.ivecs); the shortlist kernel's general
+    insert path keeps k + 32 <= 256 candidates.  Small set (shortlist kernel alone) and a set large enough for the threshold pipeline."""
+    import torch
+
+    for n, d, nq in ((3000, 96, 40), (70_000, 64, 33)):
+        x = deep_like(n, d, 24, seed=41)
+        q = deep_like(nq, d, 24, seed=42)
+        idx = svs.FlatIndex(x, svs.DistanceL2())
+        r = idx.search(q, k)
+        oi, od = oracle.flat_search(L2, x, q, k)
+        same = (r.indices == oi.astype(np.uint64))
+        assert same.mean() > 0.999, (n, k, same.mean())
+        assert (r.distances.view(np.uint32) == od.view(np.uint32)).mean() > 0.999
+        assert (np.diff(r.distances, axis=1) >= 0).all()
+    with pytest.raises(svs.SvsxError):
+        svs.FlatIndex(x, svs.DistanceL2()).search(q, 225)
+
+
+def test_golden_flat_search_on_gpu(svs):
+    """tests/golden/flat.npz, generated from the reference's own BulkInserter / HeapInserter (oracle/_ref): tie-free queries give the same ids and
+    distance bits at k = 1 / 10 / 100; with exact ties the distances are the reference's and every id is a real row at its distance."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flat.npz"))
+    names = {F32: "f32", F16: "f16", I8: "i8"}
+    fns = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}
+    for qa, qb in [(F32, F32), (F32, F16), (F16, F16), (I8, I8), (F32, I8)]:
+        x, q = g[f"x_{names[qb]}"], g[f"q_{names[qa]}"]
+        for m in (L2, IP, COS):
+            full = svs.compute(fns[m], q, x)
+            idx = svs.FlatIndex(x, fns[m])
+            for k in (int(v) for v in g["ks"]):
+                r = idx.search(q, k)
+                gi, gd = g[f"ids_{names[qa]}_{names[qb]}_{m}_{k}"], g[f"dists_{names[qa]}_{names[qb]}_{m}_{k}"]
+                assert ((r.distances.view(np.uint32) == gd.view(np.uint32)) | (np.isnan(r.distances) & np.isnan(gd))).all(), (qa, qb, m, k)
+                for i in range(len(q)):
+                    if len(np.unique(full[i])) == len(full[i]):
+                        assert (r.indices[i] == gi[i]).all(), (qa, qb, m, k, i)
+    idx = svs.FlatIndex(g["x_tied"], svs.DistanceL2())
+    full = svs.compute(svs.DistanceL2(), g["q_tied"], g["x_tied"])
+    for k in (3, 10):
+        r = idx.search(g["q_tied"], k)
+        assert (r.distances.view(np.uint32) == g[f"dists_tied_{k}"].view(np.uint32)).all()
+        for i in range(len(r.indices)):
+            ids = r.indices[i].astype(np.int64)
+            assert len(set(ids.tolist())) == k and (full[i][ids].view(np.uint32) == r.distances[i].view(np.uint32)).all()
