@@ -119,12 +119,14 @@ def _emit(line: str):
 
 
 def kernel_src_sha() -> str:
-    """Hash of the device-code sources: a PMC summary is only reused for the kernels it was measured on."""
+    """Hash of the sources the search kernel and its inline records are built from: a PMC summary is only reused for the kernel it was measured on
+    (flat search, builder, sharded host logic and the C ABI file do not enter: they cannot change the search kernel's traffic)."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "scalablevectorsearch_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):  # real sources only (no *.orig, *.o)
-        if os.path.basename(f) != "svsx_api.hip":  # host-side C ABI: no device code
-            h.update(open(f, "rb").read())
+    names = ["svsx_device.h", "svsx_kernels.h", "svsx_search_kernel.h", "svsx_search.hip", "svsx_search_f32.hip", "svsx_search_f16.hip", "svsx_search_i8.hip",
+             "svsx_search_u8.hip", "svsx_codes.hip", "Makefile"]
+    for f in names:
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
