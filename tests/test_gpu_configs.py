@@ -511,6 +511,41 @@ def test_flat_search_k_limit(svs):
     assert e.value.code == 2 and "k <= 96" in e.value.message
 
 
+def test_gpu_builder_at_scale_against_the_oracle_builder(svs, oracle):
+    """the in-library builder (svsx_vamana_build_device) against the ORACLE's sequential builder (vamana_build.h / prune.h semantics) -- not against
+    this repo's other builder -- on 30 000 vectors: degree statistics, recall-vs-window curves searched by the oracle on both graphs, and the
+    navigability property the reference's construction guarantees (every vertex reachable from the entry point)."""
+    n, d = 30_000, 96
+    x = deep_like(n, d, 24, seed=1)
+    q = deep_like(300, d, 24, seed=2)
+    g_o, e_o = oracle.build_vamana(L2, x, R=32, L=64, prune_to=28, alpha=1.2)
+    g_g, e_g = _gpu_graph(svs, x, L2, R=32, L=64, alpha=1.2)
+    assert abs(g_o[:, 0].mean() - g_g[:, 0].mean()) < 0.1 * g_o[:, 0].mean()
+    assert g_g[:, 0].max() <= 32 and g_g[:, 0].min() >= 1
+    for g in (g_o, g_g):  # no self loops, no duplicate neighbours (core/graph/graph.h:169-172)
+        deg = g[:, 0].astype(np.int64)
+        rows = np.arange(n)[:, None]
+        valid = np.arange(32)[None, :] < deg[:, None]
+        assert not ((g[:, 1:] == rows) & valid).any()
+        srt = np.sort(np.where(valid, g[:, 1:].astype(np.int64), -np.arange(1, 33)[None, :]), axis=1)
+        assert (np.diff(srt, axis=1) != 0).all()
+    gt, _ = oracle.flat_search(L2, x, q, 10)
+    for w in (10, 16, 24, 40, 64, 100):
+        r_o = oracle.recall(gt, oracle.search(L2, x, g_o, e_o, q, 10, w)[0], 10, 10)
+        r_g = oracle.recall(gt, oracle.search(L2, x, g_g, e_g, q, 10, w)[0], 10, 10)
+        assert abs(r_o - r_g) < 0.012, (w, r_o, r_g)
+    for g, e in ((g_o, e_o), (g_g, e_g)):  # breadth-first from the entry point reaches everything
+        seen = np.zeros(n, bool)
+        front = np.array([int(np.atleast_1d(e)[0])])
+        seen[front] = True
+        while front.size:
+            nb = g[front, 1:][np.arange(32)[None, :] < g[front, 0][:, None]]
+            nb = np.unique(nb[~seen[nb]])
+            seen[nb] = True
+            front = nb
+        assert seen.mean() > 0.999, seen.mean()
+
+
 # ---- SURVEY 7 step 4 gate: graphs of the GPU builder are as good as the oracle builder's --------------------------------------------------
 @pytest.mark.parametrize("metric,n,d,latent,normalize,alpha", [(L2, 4000, 96, 24, True, 1.2), (IP, 3000, 128, 32, False, 0.95), (COS, 3000, 128, 32, False, 0.95)])
 def test_gpu_built_graph_matches_oracle_graph_quality(svs, oracle, metric, n, d, latent, normalize, alpha):
