@@ -7,6 +7,7 @@
 #include "../../include/svsx.h"
 #include "svsx_device.h"
 #include "svsx_kernels.h"
+#include "svsx_flat_proof.h"
 
 #include <algorithm>
 #include <atomic>
@@ -45,6 +46,7 @@ struct svsx_index {
     mutable std::mutex shadow_mutex;
     mutable void* d_half = nullptr;
     mutable float* d_norm2 = nullptr;
+    mutable float shadow_max2 = 0.0f, shadow_min2 = 0.0f; // range of d_norm2 (flat search: exactness proof)
     // bound codes (svsx_index_build_bound_codes): 128 B per vector
     void* d_codes = nullptr;
     float code_scale = 1.0f, code_bias = 0.0f, code_eq_abs = 0.0f;
@@ -1183,8 +1185,16 @@ int svsx_distance_batch(
 int svsx_flat_search_device(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream
 ) {
+    return svsx_flat_search_device_counted(ix, d_queries, q_dtype, nq, k, d_ids64, d_dists, nullptr, hip_stream);
+}
+
+int svsx_flat_search_device_counted(
+    const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, uint32_t* d_recomputed,
+    void* hip_stream
+) {
     if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k, false)) return rc;
     if (nq == 0) return SVSX_SUCCESS;
+    if (!d_ids64) return fail(SVSX_INVALID_ARGUMENT, "null argument");
     if (k > 224) return fail(SVSX_INVALID_ARGUMENT, "flat search supports k <= 224 (the float16 shortlist keeps k + 32 <= 256 candidates per query in LDS: 32 spare ranks for float16 rounding)");
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
@@ -1200,7 +1210,17 @@ int svsx_flat_search_device(
             if (hipMalloc(reinterpret_cast<void**>(&nrm), ix->n * 4) != hipSuccess) { (void)hipFree(h); return fail(SVSX_RUNTIME_ERROR, "hipMalloc failed"); }
             hipError_t e = launch_to_half(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), dpad,
                                           ix->sq_enabled, ix->sq_scale, ix->sq_bias, h, nrm, stream);
-            if (e != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(h); (void)hipFree(nrm); return fail(SVSX_RUNTIME_ERROR, "float16 shadow conversion failed"); }
+            uint32_t* mm = nullptr; // {max, min} bits of the squared norms
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&mm), 8);
+            uint32_t range[2] = {0u, 0xFFFFFFFFu};
+            if (e == hipSuccess) e = hipMemcpyAsync(mm, range, 8, hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = launch_norm_range(nrm, static_cast<uint32_t>(ix->n), mm, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(range, mm, 8, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (mm) (void)hipFree(mm);
+            if (e != hipSuccess) { (void)hipFree(h); (void)hipFree(nrm); return fail(SVSX_RUNTIME_ERROR, "float16 shadow conversion failed: %s", hipGetErrorString(e)); }
+            memcpy(&ix->shadow_max2, &range[0], 4);
+            memcpy(&ix->shadow_min2, &range[1], 4);
             ix->d_half = h;
             ix->d_norm2 = nrm;
         }
@@ -1229,7 +1249,12 @@ int svsx_flat_search_device(
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     const size_t q_stride = ix->d * dtype_size(q_dtype);
-    StreamBuffer bqh, bsk, bsi, bmk, bmi;
+    StreamBuffer bqh, bsk, bsi, bmk, bmi, bredo, bdist;
+    HIP_TRY(bredo.alloc(nq * 4, stream));
+    if (!d_dists) { // the proof needs the k-th exact distance
+        HIP_TRY(bdist.alloc(nq * k * 4, stream));
+        d_dists = static_cast<float*>(bdist.p);
+    }
     HIP_TRY(bqh.alloc(nq * dpad * 2 + 64, stream));
     HIP_TRY(bsk.alloc(slices * nq * kk * 4, stream));
     HIP_TRY(bsi.alloc(slices * nq * kk * 8, stream));
@@ -1264,6 +1289,15 @@ int svsx_flat_search_device(
     // threshold -- which at least kk rows of the next level satisfy, because the samples are nested.  The last level is
     // the full set; its lists (>= kk rows, ~16 kk expected) are re-ranked exactly.  Queries whose lists overflow
     // (unrepresentative samples) are recomputed by the full shortlist kernel, gated per 64-query block.
+    FlatProofArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.metric = ix->metric; pa.nq = ra.nq; pa.k = ra.k; pa.kk = ra.kk; pa.d = ra.d; pa.dpad = dpad;
+    pa.queries = d_queries; pa.q_row_bytes = q_stride; pa.q_dtype = q_dtype;
+    pa.sq_l2 = qmode == QM_SQ_L2 ? 1 : 0; pa.data_dtype = ix->data_dtype; pa.sq_scale = ix->sq_scale; pa.sq_bias = ix->sq_bias;
+    pa.out_ids = d_ids64; pa.out_dists = d_dists;
+    pa.short_keys = static_cast<const float*>(mk); pa.short_ids = static_cast<const uint64_t*>(mi);
+    pa.xmax2 = ix->shadow_max2; pa.xmin2 = ix->shadow_min2;
+    pa.redo = static_cast<uint32_t*>(bredo.p); pa.redo_count = d_recomputed;
     bool thresh_path = dpad <= 128 && ix->n >= 65536 && nq <= 65536;
 #ifdef SVSX_DIAG
     if (getenv("SVSX_FLAT_SHORTLIST_ONLY")) thresh_path = false; // A/B builds only
@@ -1321,12 +1355,19 @@ int svsx_flat_search_device(
         if (e == hipSuccess) e = launch_merge(M_L2, ma, stream);
         ra.cand32 = ta.cand; ra.cnt = ta.cnt; ra.cap = ta.cap; ra.n_lists = ta.n_slices;
         if (e == hipSuccess) e = launch_rerank2(ix->data_dtype, ix->metric, qmode, ra, stream);
+        pa.tau = tau_cur; pa.cnt = ta.cnt; pa.cap = ta.cap; pa.n_lists = ta.n_slices;
+        if (e == hipSuccess) e = launch_flat_certify(pa, stream);
     } else {
         if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream); // +inf, order-encoded
         if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
         if (e == hipSuccess) e = launch_merge(M_L2, ma, stream); // keys: smaller is better for every metric
         if (e == hipSuccess) e = launch_rerank(ix->data_dtype, ix->metric, qmode, ra, stream);
+        if (e == hipSuccess) e = launch_flat_certify(pa, stream);
     }
+    // the queries whose shortlist is not PROVEN to hold the exact answer are recomputed exhaustively in float32 (svsx_flat.hip stages 4, 5)
+    FlatExactArgs xa;
+    xa.r = ra; xa.redo = pa.redo; xa.n = static_cast<uint32_t>(ix->n);
+    if (e == hipSuccess) e = launch_flat_exact(ix->data_dtype, ix->metric, qmode, xa, stream);
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "flat search launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
 }

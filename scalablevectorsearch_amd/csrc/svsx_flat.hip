@@ -17,6 +17,7 @@
 // the kk-th candidate.  Values must fit float16 (|x| < 65504).
 #include "svsx_device.h"
 #include "svsx_kernels.h"
+#include "svsx_flat_proof.h"
 
 namespace svsx {
 
@@ -887,6 +888,254 @@ hipError_t launch_rerank2(int data_dtype, int metric, int qmode, const RerankArg
         case QM_SQ_L2:
             if (data_dtype == DT_I8) return launch_rerank2_metric<DT_I8, QM_SQ_L2>(metric, a, stream);
             if (data_dtype == DT_U8) return launch_rerank2_metric<DT_U8, QM_SQ_L2>(metric, a, stream);
+            break;
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- stage 4: proof that the re-ranked answer is the exhaustive answer ------------------------------------------------------
+// The shortlist is chosen by float16 keys, the answer by the reference-order float32 distances.  A row that was not re-ranked has
+// key >= tau (tau = the threshold of the last threshold pass, or the kk-th key of the merged shortlist); from tau, the norms of the
+// query and of the longest / shortest row and the rounding model below, a bound on the best reference distance such a row can have
+// follows.  If that bound is strictly worse than the k-th re-ranked distance the answer is exact (ties included: an outside row
+// with an EQUAL distance and a smaller id would belong in the answer, hence strictly).  Otherwise the query is recomputed by the
+// exhaustive float32 kernel below.  Rounding model (u = 2^-11 = float16 unit roundoff, a = sqrt(dpad) 2^-25 = subnormal spacing):
+//   ||v - fl16(v)|| <= u ||v|| + a;   float32 accumulation of dpad products (MFMA or FMA chain), |error| <= gam ||.|| ||.||, gam = dpad 2^-22;
+//   the reference's float32 value is within a relative e = (d + 8) 2^-22 of the real-number distance (L2: of the distance itself, all terms
+//   being non-negative; inner product / cosine: of ||q|| ||x||) -- each several times what the error analysis of a d-term sum gives.
+// Non-finite norms or distances, a zero row under cosine, fewer than k answers: not proven.  Everything in double.
+__global__ __launch_bounds__(64) void flat_certify_kernel(const FlatProofArgs a) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(q) * a.q_row_bytes;
+    double s2 = 0.0, ds2 = 0.0;
+    for (uint32_t i = lane; i < a.d; i += 64) {
+        float v;
+        switch (a.q_dtype) {
+            case DT_F32: v = reinterpret_cast<const float*>(qptr)[i]; break;
+            case DT_F16: v = static_cast<float>(reinterpret_cast<const _Float16*>(qptr)[i]); break;
+            case DT_I8: v = static_cast<float>(static_cast<int>(reinterpret_cast<const int8_t*>(qptr)[i])); break;
+            default: v = static_cast<float>(static_cast<unsigned>(qptr[i])); break;
+        }
+        s2 += static_cast<double>(v) * static_cast<double>(v);
+        if (a.sq_l2) { // the reference's query is the decompressed code of the query
+            const int c = a.data_dtype == DT_I8 ? sq_compress<DT_I8>(v, a.sq_scale, a.sq_bias) : sq_compress<DT_U8>(v, a.sq_scale, a.sq_bias);
+            const double back = static_cast<double>(a.sq_scale) * static_cast<double>(c) + static_cast<double>(a.sq_bias);
+            ds2 += (back - static_cast<double>(v)) * (back - static_cast<double>(v));
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        s2 += __shfl_xor(s2, off);
+        ds2 += __shfl_xor(ds2, off);
+    }
+    if (lane != 0) return;
+    const double nq = sqrt(s2), dqs = sqrt(ds2);
+    const double u = 0x1p-11, ab = sqrt(static_cast<double>(a.dpad)) * 0x1p-25;
+    const double xmax = sqrt(static_cast<double>(a.xmax2)), xmin = sqrt(static_cast<double>(a.xmin2));
+    const double e16 = u * nq + ab;            // >= ||q - q_h||
+    const double eq = dqs + e16;               // >= ||q* - q_h||, q* = the query the reference measures from
+    const double ex = 1.001 * (u * xmax + ab); // >= ||x - x_h|| (xmax is the norm of the SHADOW row; 1.001 also covers the f32 decompression)
+    const double qh_hi = nq + e16, qh_lo = nq - e16 > 0.0 ? nq - e16 : 0.0;
+    const double gam = static_cast<double>(a.dpad) * 0x1p-22, e = static_cast<double>(a.d + 8u) * 0x1p-22;
+    uint32_t total = 0;
+    const bool from_shortlist = a.tau == nullptr || flat_overflow(a.cnt, q, a.n_lists, a.cap, total);
+    bool every_row = false;
+    double tau = 0.0;
+    if (from_shortlist) {
+        const size_t last = static_cast<size_t>(q) * a.kk + a.kk - 1u;
+        if (a.short_ids[last] == ~0ull) every_row = true; // the shortlist never filled: every row was re-ranked
+        else tau = static_cast<double>(a.short_keys[last]);
+    } else tau = static_cast<double>(a.tau[q]);
+    const size_t kth = static_cast<size_t>(q) * a.k + a.k - 1u;
+    const bool have_k = a.out_ids[kth] != ~0ull;
+    const double dk = static_cast<double>(a.out_dists[kth]);
+    bool ok = false;
+    if (!(nq <= 1.0e30) || !(xmax <= 1.0e30)) ok = false; // NaN / inf anywhere in the query or the data
+    else if (every_row) ok = true;
+    else if (!have_k) ok = false;
+    else if (a.metric == M_L2) {
+        const double r2 = tau + qh_lo * qh_lo - gam * (xmax + qh_hi) * (xmax + qh_hi);
+        if (r2 > 0.0) {
+            const double r = sqrt(r2) - eq - ex;
+            ok = r > 0.0 && r * r * (1.0 - e) > dk;
+        }
+    } else if (a.metric == M_IP) {
+        const double best = -tau + gam * qh_hi * xmax + eq * xmax + nq * ex + 1.001 * e * nq * xmax;
+        ok = best < dk; // dk is the reference's own float32 number: compared as is
+    } else {
+        if (xmin > 0.0 && nq > 0.0) {
+            const double best = (-tau + fabs(tau) * gam + gam * qh_hi + eq + qh_hi * 2.002 * (u + ab / xmin)) / nq + 2.0 * e;
+            ok = best < dk;
+        }
+    }
+    a.redo[q] = ok ? 0u : 1u;
+    if (!ok && a.redo_count != nullptr) atomicAdd(a.redo_count, 1u);
+}
+
+hipError_t launch_flat_certify(const FlatProofArgs& a, hipStream_t stream) {
+    if (a.nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(flat_certify_kernel, dim3(a.nq), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+// max / min of the shadow rows' squared norms as raw bits (non-negative floats order like their bits; a NaN sorts above +inf)
+__global__ __launch_bounds__(256) void norm_range_kernel(const float* __restrict__ norm2, uint32_t n, uint32_t* __restrict__ mm) {
+    uint32_t hi = 0u, lo = 0xFFFFFFFFu;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t b = __float_as_uint(norm2[i]) & 0x7FFFFFFFu;
+        hi = b > hi ? b : hi;
+        lo = b < lo ? b : lo;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t oh = static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi), off));
+        const uint32_t ol = static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo), off));
+        hi = oh > hi ? oh : hi;
+        lo = ol < lo ? ol : lo;
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicMax(mm, hi);
+        atomicMin(mm + 1, lo);
+    }
+}
+
+hipError_t launch_norm_range(const float* norm2, uint32_t n, uint32_t* mm, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (n + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(norm_range_kernel, dim3(blocks), dim3(256), 0, stream, norm2, n, mm);
+    return hipGetLastError();
+}
+
+// ---- stage 5: exhaustive float32 pass for the queries stage 4 could not prove --------------------------------------------------
+// One wave per flagged query over ALL rows with the reference-order distance routines; the k best by (distance, then id) live
+// sorted in LDS.  A pass of 64 / G rows inserts (wave-uniform, one candidate at a time) only the rows that beat the current k-th.
+template <int DT, int METRIC, int QMODE>
+__global__ __launch_bounds__(64) void flat_exact_kernel(const FlatExactArgs xa) {
+    const RerankArgs& a = xa.r;
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool GREATER = METRIC != M_L2;
+    constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    constexpr bool BC = !INTPATH && use_block_cyclic<DT>();
+    constexpr int G = (INTPATH || BC) ? 4 : 16 / Elem<DT>::E;
+    constexpr int RPP = 64 / G;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    if (xa.redo[qi] == 0u) return;
+    const int d = static_cast<int>(a.d);
+    const int dpad = (d + 15) & ~15;
+    float* qf = reinterpret_cast<float*>(smem);
+    uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t q_bytes = INTPATH ? static_cast<uint32_t>(dpad) : static_cast<uint32_t>(dpad) * 4u;
+    float* cd = reinterpret_cast<float*>(smem + q_bytes);  // k distances, best first
+    uint32_t* ci = reinterpret_cast<uint32_t*>(cd + a.k);  // k ids
+    const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
+    const QueryFix fx = prepare_query<DT, METRIC, QMODE>(qptr, a.q_dtype, d, dpad, qf, qw, a.sq_scale, a.sq_bias, lane);
+    const int sub = static_cast<int>(lane) & (G - 1);
+    const uint32_t grp = lane / G;
+    const unsigned char* data = static_cast<const unsigned char*>(a.data);
+    uint32_t cnt = 0;
+    // (dc, ic) ranks before (dd, id)?  NaN compares false both ways and falls through to the id, like the re-rank kernels
+    auto before = [](float dc, uint32_t ic, float dd, uint32_t id) { return cmpf<GREATER>(dc, dd) || (!cmpf<GREATER>(dd, dc) && ic < id); };
+    for (uint32_t j0 = 0; j0 < xa.n; j0 += RPP) {
+        const uint32_t id = j0 + grp;
+        const bool act = id < xa.n;
+        const unsigned char* row = data + static_cast<size_t>(act ? id : 0u) * a.row_bytes;
+        float fmain = 0.0f, fnrm = 0.0f;
+        int ab = 0, bb = 0;
+        if constexpr (INTPATH) int_row_sums<DT>(row, act, qw, d, sub, ab, bb);
+        else if constexpr (BC) float_row_distance_bc<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+        else float_row_distance<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+        const float dist = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
+        bool cand = act && sub == 0;
+        if (cand && cnt == a.k) cand = before(dist, id, cd[cnt - 1u], ci[cnt - 1u]);
+        unsigned long long m = __ballot(cand);
+        while (m != 0ull) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), l));
+            const uint32_t did = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id), l));
+            if (cnt == a.k && !before(dd, did, cd[cnt - 1u], ci[cnt - 1u])) continue; // an earlier insert of this pass moved the k-th
+            uint32_t pos = 0;
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                pos += static_cast<uint32_t>(__builtin_popcountll(__ballot(i < cnt && before(cd[i], ci[i], dd, did))));
+            }
+            const uint32_t top = cnt < a.k ? cnt : a.k - 1u; // entries [pos, top) move one place down (the k-th falls off a full list)
+            for (int c = static_cast<int>((a.k + 63u) / 64u) - 1; c >= 0; --c) {
+                const uint32_t i = static_cast<uint32_t>(c) * 64u + lane;
+                const bool mv = i >= pos && i < top;
+                float v = 0.0f;
+                uint32_t w = 0;
+                if (mv) { v = cd[i]; w = ci[i]; }
+                lds_order();
+                if (mv) { cd[i + 1u] = v; ci[i + 1u] = w; }
+                lds_order();
+            }
+            if (lane == 0) { cd[pos] = dd; ci[pos] = did; }
+            lds_order();
+            if (cnt < a.k) ++cnt;
+        }
+    }
+    for (uint32_t j = lane; j < a.k; j += 64) {
+        const size_t o = static_cast<size_t>(qi) * a.k + j;
+        const bool have = j < cnt;
+        if (a.ids64 != nullptr) a.ids64[o] = have ? static_cast<uint64_t>(ci[j]) + a.id_offset : ~0ull;
+        if (a.dists != nullptr) a.dists[o] = have ? cd[j] : __builtin_inff();
+    }
+}
+
+template <int DT, int METRIC, int QMODE> static hipError_t launch_flat_exact_one(const FlatExactArgs& xa, hipStream_t stream) {
+    const RerankArgs& a = xa.r;
+    const int dpad = (static_cast<int>(a.d) + 15) & ~15;
+    const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
+    const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + static_cast<size_t>(a.k) * 8;
+    auto kern = flat_exact_kernel<DT, METRIC, QMODE>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), lds, stream, xa);
+    return hipGetLastError();
+}
+
+template <int DT, int QMODE> static hipError_t launch_flat_exact_metric(int metric, const FlatExactArgs& a, hipStream_t stream) {
+    switch (metric) {
+        case M_L2:
+            if constexpr (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_flat_exact_one<DT, M_L2, QMODE>(a, stream);
+        case M_IP:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_COS) return hipErrorInvalidValue;
+            else return launch_flat_exact_one<DT, M_IP, QMODE>(a, stream);
+        case M_COS:
+            if constexpr (QMODE == QM_SQ_L2 || QMODE == QM_SQ_IP) return hipErrorInvalidValue;
+            else return launch_flat_exact_one<DT, M_COS, QMODE>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_flat_exact(int data_dtype, int metric, int qmode, const FlatExactArgs& a, hipStream_t stream) {
+    if (a.r.nq == 0 || a.redo == nullptr) return hipErrorInvalidValue;
+    const bool i8 = data_dtype == DT_I8, u8 = data_dtype == DT_U8;
+    switch (qmode) {
+        case QM_FLOAT:
+            switch (data_dtype) {
+                case DT_F32: return launch_flat_exact_metric<DT_F32, QM_FLOAT>(metric, a, stream);
+                case DT_F16: return launch_flat_exact_metric<DT_F16, QM_FLOAT>(metric, a, stream);
+                case DT_I8: return launch_flat_exact_metric<DT_I8, QM_FLOAT>(metric, a, stream);
+                case DT_U8: return launch_flat_exact_metric<DT_U8, QM_FLOAT>(metric, a, stream);
+            }
+            break;
+        case QM_INT:
+            if (i8) return launch_flat_exact_metric<DT_I8, QM_INT>(metric, a, stream);
+            if (u8) return launch_flat_exact_metric<DT_U8, QM_INT>(metric, a, stream);
+            break;
+        case QM_SQ_IP:
+            if (i8) return launch_flat_exact_metric<DT_I8, QM_SQ_IP>(metric, a, stream);
+            if (u8) return launch_flat_exact_metric<DT_U8, QM_SQ_IP>(metric, a, stream);
+            break;
+        case QM_SQ_COS:
+            if (i8) return launch_flat_exact_metric<DT_I8, QM_SQ_COS>(metric, a, stream);
+            if (u8) return launch_flat_exact_metric<DT_U8, QM_SQ_COS>(metric, a, stream);
+            break;
+        case QM_SQ_L2:
+            if (i8) return launch_flat_exact_metric<DT_I8, QM_SQ_L2>(metric, a, stream);
+            if (u8) return launch_flat_exact_metric<DT_U8, QM_SQ_L2>(metric, a, stream);
             break;
     }
     return hipErrorInvalidValue;

@@ -236,9 +236,11 @@ class VamanaIndex:
 
         return BatchIterator(self, queries, extra_search_buffer_capacity)
 
-    def flat_search_device(self, d_queries, num_neighbors: int, d_ids64=None, d_dists=None, q_dtype=None, stream=None):
+    def flat_search_device(self, d_queries, num_neighbors: int, d_ids64=None, d_dists=None, q_dtype=None, stream=None, recomputed=None):
         """Exhaustive search (FlatIndex::search, index/flat/flat.h:322-460) on torch CUDA tensors: MFMA f16 shortlist +
-        exact re-rank.  Returns (ids int64 [nq,k], dists f32 [nq,k])."""
+        exact re-rank + per-query proof of exactness (unproven queries are recomputed exhaustively in float32).
+        Returns (ids int64 [nq,k], dists f32 [nq,k]).  `recomputed`: optional int32 CUDA tensor of one element, incremented
+        by the number of queries that needed the exhaustive float32 pass."""
         import torch
 
         nq = d_queries.shape[0]
@@ -248,7 +250,9 @@ class VamanaIndex:
         if d_dists is None:
             d_dists = torch.empty((nq, num_neighbors), dtype=torch.float32, device=d_queries.device)
         s = stream if stream is not None else torch.cuda.current_stream(d_queries.device).cuda_stream
-        _lib.check(_lib.lib().svsx_flat_search_device(self._h, d_queries.data_ptr(), code, nq, num_neighbors, d_ids64.data_ptr(), d_dists.data_ptr(), C.c_void_p(s)))
+        _lib.check(_lib.lib().svsx_flat_search_device_counted(
+            self._h, d_queries.data_ptr(), code, nq, num_neighbors, d_ids64.data_ptr(), d_dists.data_ptr(),
+            recomputed.data_ptr() if recomputed is not None else None, C.c_void_p(s)))
         return d_ids64, d_dists
 
     def vamana_build(self, alpha: float, graph_max_degree: int, window_size: int, max_candidate_pool_size: int = 750, prune_to: int = 0, stream=None) -> None:

@@ -505,10 +505,10 @@ def test_cancel_flag_device_and_host(svs, oracle, small_world):
 def test_flat_search_k_limit(svs):
     x = deep_like(500, 32, 8, seed=3)
     f = svs.FlatIndex(x, svs.DistanceL2())
-    assert f.search(x[:4], 96).indices.shape == (4, 96)
+    assert f.search(x[:4], 224).indices.shape == (4, 224)
     with pytest.raises(svs.SvsxError) as e:
-        f.search(x[:4], 97)
-    assert e.value.code == 2 and "k <= 96" in e.value.message
+        f.search(x[:4], 225)
+    assert e.value.code == 2 and "k <= 224" in e.value.message
 
 
 def test_gpu_builder_at_scale_against_the_oracle_builder(svs, oracle):
