@@ -708,8 +708,9 @@ def main():
         host_pointer["ids_equal_device_path"] = bool((h_ids.astype(np.int64) == loc_i.cpu().numpy()).all())
         dev_med = float(np.median([a.elapsed_time(b) for a, b in ev]))
         host_pointer["over_device_resident"] = dev_med / host_pointer["median_ms"]
-        host_pointer["how"] = ("page-locked mirrors, device staging and two streams kept with the index; two launches: the first 4 096 queries start as soon as their "
-                               "bytes have crossed PCIe, the rest is copied while they run (DESIGN.md section 1, profiles/r03_notes.md section 5)")
+        host_pointer["how"] = ("device staging and two streams kept with the index, copies straight from / to the caller's pageable arrays; two launches: the first "
+                               "4 096 queries start as soon as their bytes have crossed PCIe, the rest is copied while they run (DESIGN.md section 1, "
+                               "profiles/r03_notes.md section 5, profiles/r04_notes.md section 6)")
 
     # ---- the sharded search of SURVEY 8(e), measured in the same run (every rank takes part) -----------------------------------------
     sharded = None

@@ -154,8 +154,8 @@ struct CallStream {
 
 } // namespace
 
-// Everything a host-pointer svsx_search needs between calls: streams, page-locked bounce buffers and device staging, all grown on demand
-// and kept with the index -- the per-call hipStreamCreate / hipMallocAsync / pageable copies of round 2 cost 0.65 ms per 10 000-query batch.
+// Everything a host-pointer svsx_search needs between calls: streams and device staging, grown on demand and kept with the index -- the
+// per-call hipStreamCreate / hipMallocAsync of round 2 cost 0.65 ms per 10 000-query batch.
 // The batch is cut into chunks, each on its own stream: H2D of chunk i+1 and D2H of chunk i-1 overlap the kernel of chunk i (queries are
 // independent, index/vamana/index.h:571-574, so the results are those of one launch).
 struct HostCallContext {
@@ -163,8 +163,6 @@ struct HostCallContext {
     hipStream_t streams[kMaxChunks] = {};
     void* d_in = nullptr;   size_t d_in_cap = 0;    // queries
     void* d_out = nullptr;  size_t d_out_cap = 0;   // ids64 | ids32 | dists | stats | history ids | history dists | history len
-    void* h_in = nullptr;   size_t h_in_cap = 0;    // page-locked mirrors of the two
-    void* h_out = nullptr;  size_t h_out_cap = 0;
     bool dirty = false;                             // an error return left work in flight on the streams: drained before the context is reused
     static constexpr size_t kKeepBytes = size_t(64) << 20; // staging beyond this is given back when a call that needed it has returned
     ~HostCallContext() {
@@ -174,33 +172,29 @@ struct HostCallContext {
     void release() {
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
-        if (h_in) (void)hipHostFree(h_in);
-        if (h_out) (void)hipHostFree(h_out);
-        d_in = d_out = h_in = h_out = nullptr;
-        d_in_cap = d_out_cap = h_in_cap = h_out_cap = 0;
+        d_in = d_out = nullptr;
+        d_in_cap = d_out_cap = 0;
     }
     void drain() { // every stream idle: nothing reads or writes the staging any more
         for (auto st : streams) if (st) (void)hipStreamSynchronize(st);
         dirty = false;
     }
-    void trim() {  // one huge batch must not pin gigabytes of page-locked memory for the life of the index
+    void trim() {  // one huge batch must not keep gigabytes of staging for the life of the index
         if (d_in_cap + d_out_cap > 2 * kKeepBytes) { drain(); release(); }
     }
     hipError_t reserve(size_t in_bytes, size_t out_bytes, int n_streams) {
         for (int i = 0; i < n_streams; ++i)
             if (!streams[i]) { hipError_t e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking); if (e != hipSuccess) return e; }
-        auto grow = [](void*& p, size_t& cap, size_t want, bool host) -> hipError_t {
+        auto grow = [](void*& p, size_t& cap, size_t want) -> hipError_t {
             if (want <= cap) return hipSuccess;
-            if (p) { (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; cap = 0; }
+            if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
             const size_t bytes = want + want / 4 + 4096;
-            hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+            hipError_t e = hipMalloc(&p, bytes);
             if (e == hipSuccess) cap = bytes;
             return e;
         };
-        hipError_t e = grow(d_in, d_in_cap, in_bytes, false);
-        if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes, false);
-        if (e == hipSuccess) e = grow(h_in, h_in_cap, in_bytes, true);
-        if (e == hipSuccess) e = grow(h_out, h_out_cap, out_bytes, true);
+        hipError_t e = grow(d_in, d_in_cap, in_bytes);
+        if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes);
         return e;
     }
     hipError_t stream0() { return streams[0] ? hipSuccess : hipStreamCreateWithFlags(&streams[0], hipStreamNonBlocking); }
@@ -986,8 +980,8 @@ int svsx_search_device(
 
 
 // Host pointers in, host results out (SURVEY 8d's QPS definition; benchmark/include/svs-benchmark/search.h:209-219 times exactly this call).
-// The form that also serves the side outputs (statistics, search history): page-locked mirror -> H2D -> kernel -> D2H on one stream with
-// persistent staging, in two chunks on two streams (below).
+// The form that also serves the side outputs (statistics, search history): H2D -> kernel -> D2H with persistent device staging, in two
+// chunks on two streams (below).
 static int search_host_pipelined(
     const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, const svsx_search_params* params,
     uint64_t* ids64, uint32_t* ids32, float* dists, const svsx_search_aux* aux, size_t q_stride
@@ -1001,7 +995,9 @@ static int search_host_pipelined(
     bounds[0] = 0;
     // Two launches on two streams: the first 4 096 queries start as soon as their 1.5 MB have crossed PCIe, the rest is copied while they
     // run.  More chunks lose: a later launch only gets compute units when an earlier one has drained, so every extra launch adds a drain
-    // (five chunks: 1.43-1.50 ms against 1.15 ms for the kernel alone; profiles/r03_notes.md).
+    // (five chunks: 1.43-1.50 ms against 1.15 ms for the kernel alone; profiles/r03_notes.md).  The copies go straight between the caller's
+    // (pageable) arrays and the device staging: the runtime's own pipelined bounce (1.5 MB in 41 us, 3.8 MB in 92 us on the bench host)
+    // beats memcpy into a page-locked mirror followed by the DMA (33 + 37 us, 79 + 76 us; profiles/r04_notes.md section 6).
     size_t first = nq > 4096 ? 4096 : nq;
     if (first < nq) {
         nc = 2;
@@ -1010,7 +1006,7 @@ static int search_host_pipelined(
     } else {
         bounds[1] = nq;
     }
-    // layout of the output staging (device and page-locked mirror alike): one region per output array
+    // layout of the output staging: one region per output array
     const size_t hcap = aux ? aux->history_cap : 0;
     struct Region { void* host; size_t row_bytes; size_t offset; };
     Region regions[7];
@@ -1034,10 +1030,9 @@ static int search_host_pipelined(
         const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
         if (cnt == 0) continue;
         hipStream_t st = c->streams[i];
-        unsigned char* hq = static_cast<unsigned char*>(c->h_in) + q_stride * lo;
-        memcpy(hq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * (cnt - 1) + q_row); // never past the caller's last row
         void* dq = static_cast<unsigned char*>(c->d_in) + q_stride * lo;
-        HIP_TRY(hipMemcpyAsync(dq, hq, q_stride * cnt, hipMemcpyHostToDevice, st));
+        // never past the caller's last row
+        HIP_TRY(hipMemcpyAsync(dq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * (cnt - 1) + q_row, hipMemcpyHostToDevice, st));
         svsx_search_aux daux;
         memset(&daux, 0, sizeof(daux));
         daux.query_row_stride_bytes = q_stride;
@@ -1051,18 +1046,17 @@ static int search_host_pipelined(
             for (int j = 0; j <= i; ++j) (void)hipStreamSynchronize(c->streams[j]);
             return rc;
         }
-        for (int r = 0; r < nr; ++r) {
-            const size_t off = regions[r].offset + regions[r].row_bytes * lo;
-            HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(c->h_out) + off, static_cast<unsigned char*>(c->d_out) + off, regions[r].row_bytes * cnt, hipMemcpyDeviceToHost, st));
-        }
     }
+    // results: a copy into pageable memory returns when it has happened, so they are requested only after every launch is enqueued
     for (int i = 0; i < nc; ++i) {
         const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
         if (cnt == 0) continue;
+        for (int r = 0; r < nr; ++r) {
+            const size_t off = regions[r].offset + regions[r].row_bytes * lo;
+            HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(regions[r].host) + regions[r].row_bytes * lo, static_cast<unsigned char*>(c->d_out) + off,
+                                   regions[r].row_bytes * cnt, hipMemcpyDeviceToHost, c->streams[i]));
+        }
         HIP_TRY(hipStreamSynchronize(c->streams[i]));
-        for (int r = 0; r < nr; ++r)
-            memcpy(static_cast<unsigned char*>(regions[r].host) + regions[r].row_bytes * lo,
-                   static_cast<const unsigned char*>(c->h_out) + regions[r].offset + regions[r].row_bytes * lo, regions[r].row_bytes * cnt);
     }
     c->dirty = false; // every stream has been synchronised
     return SVSX_SUCCESS;
@@ -1345,7 +1339,7 @@ int svsx_flat_search_device_counted(
         ta.tau = tau_cur;
         ta.cand_keys = nullptr;
         if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
-        if (e == hipSuccess) e = launch_flat_gate(ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t*>(bgate.p), stream);
+        if (e == hipSuccess) e = launch_flat_gate_kk(ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t>(kk), static_cast<uint32_t*>(bgate.p), stream);
         // gated fallback: full shortlist pass and merge only for the query blocks that overflowed
         fa.tile_step = 1;
         fa.block_gate = static_cast<const uint32_t*>(bgate.p);

@@ -343,11 +343,17 @@ hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
 // The thresholds come from two cheap refinement steps (svsx_api.hip): the shortlist kernel on a ~4096-row sample, then
 // this kernel on every 16th tile with that threshold, then flat_select_kernel -> the kk-th best key of the 1/16 sample,
 // which at least kk rows satisfy by construction.
-constexpr uint32_t kFlatRerankCap = 2048; // candidates per query the exact re-rank accepts (LDS)
-constexpr uint32_t kFlatSelectCap = 4096; // keys per query the threshold selection accepts (LDS)
+// A threshold taken as the kk-th key of a 1/16 sample admits ~16 kk rows of the 16x larger set (std ~16 sqrt(kk)): lists of up to
+// max(2048, 32 kk) candidates are re-ranked / selected from (LDS), longer ones count as overflow.
+constexpr uint32_t kFlatSelectMax = 8192; // static LDS of the select kernel (kk <= 256)
+__host__ __device__ __forceinline__ uint32_t flat_rerank_cap(uint32_t kk) { return 32u * kk > 2048u ? 32u * kk : 2048u; }
+__host__ __device__ __forceinline__ uint32_t flat_select_cap(uint32_t kk) {
+    const uint32_t c = 32u * kk > 4096u ? 32u * kk : 4096u;
+    return c < kFlatSelectMax ? c : kFlatSelectMax;
+}
 
 __device__ __forceinline__ bool flat_overflow(const uint32_t* cnt, uint32_t q, uint32_t n_slices, uint32_t cap, uint32_t& total,
-                                              uint32_t total_cap = kFlatRerankCap) {
+                                              uint32_t total_cap) {
     bool over = false;
     total = 0;
     for (uint32_t s2 = 0; s2 < n_slices; ++s2) {
@@ -572,10 +578,10 @@ hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t s
 __global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict__ keys, const uint32_t* __restrict__ cnt, uint32_t nq,
                                                          uint32_t n_slices, uint32_t cap, uint32_t kk, const float* __restrict__ fb,
                                                          uint32_t fb_stride, float* __restrict__ out) {
-    __shared__ uint32_t buf[kFlatSelectCap];
+    __shared__ uint32_t buf[kFlatSelectMax];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     uint32_t total = 0;
-    const bool over = flat_overflow(cnt, q, n_slices, cap, total, kFlatSelectCap);
+    const bool over = flat_overflow(cnt, q, n_slices, cap, total, flat_select_cap(kk));
     if (over || total < kk) {
         if (lane == 0) out[q] = fb[static_cast<size_t>(q) * fb_stride];
         return;
@@ -615,17 +621,21 @@ hipError_t launch_flat_select(const float* cand_keys, const uint32_t* cnt, uint3
 }
 
 // one word per 64-query block: non-zero if any of its queries overflowed (that block re-runs the shortlist kernel)
-__global__ void flat_gate_kernel(const uint32_t* __restrict__ cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t* __restrict__ gate) {
+__global__ void flat_gate_kernel(const uint32_t* __restrict__ cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t total_cap,
+                                 uint32_t* __restrict__ gate) {
     const uint32_t q = blockIdx.x * 64u + threadIdx.x;
     uint32_t total = 0;
-    const bool over = q < nq && flat_overflow(cnt, q, n_slices, cap, total);
+    const bool over = q < nq && flat_overflow(cnt, q, n_slices, cap, total, total_cap);
     const unsigned long long m = __ballot(over);
     if (threadIdx.x == 0) gate[blockIdx.x] = m != 0ull ? 1u : 0u;
 }
 
-hipError_t launch_flat_gate(const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t* block_gate, hipStream_t stream) {
-    hipLaunchKernelGGL(flat_gate_kernel, dim3((nq + 63) / 64), dim3(64), 0, stream, cnt, nq, n_slices, cap, block_gate);
+hipError_t launch_flat_gate_kk(const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t kk, uint32_t* block_gate, hipStream_t stream) {
+    hipLaunchKernelGGL(flat_gate_kernel, dim3((nq + 63) / 64), dim3(64), 0, stream, cnt, nq, n_slices, cap, flat_rerank_cap(kk), block_gate);
     return hipGetLastError();
+}
+hipError_t launch_flat_gate(const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t* block_gate, hipStream_t stream) {
+    return launch_flat_gate_kk(cnt, nq, n_slices, cap, 40u, block_gate, stream);
 }
 
 // ---- stage 3: exact re-rank of the shortlist --------------------------------------------------------------------------------
@@ -713,7 +723,7 @@ __global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
     float* qf = reinterpret_cast<float*>(smem);
     uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
     const uint32_t q_bytes = INTPATH ? static_cast<uint32_t>(dpad) : static_cast<uint32_t>(dpad) * 4u;
-    const uint32_t cm = kFlatRerankCap > a.kk ? kFlatRerankCap : a.kk;
+    const uint32_t cm = flat_rerank_cap(a.kk);
     float* cd = reinterpret_cast<float*>(smem + q_bytes);
     uint32_t* ci = reinterpret_cast<uint32_t*>(cd + cm);
     const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
     const unsigned char* data = static_cast<const unsigned char*>(a.data);
     const float worst = GREATER ? -__builtin_inff() : __builtin_inff();
     uint32_t total = 0;
-    const bool overflow = flat_overflow(a.cnt, qi, a.n_lists, a.cap, total);
+    const bool overflow = flat_overflow(a.cnt, qi, a.n_lists, a.cap, total, cm);
     const uint32_t c_n = overflow ? a.kk : total;
     // gather the candidate ids into LDS
     if (overflow) {
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
 template <int DT, int METRIC, int QMODE> static hipError_t launch_rerank2_one(const RerankArgs& a, hipStream_t stream) {
     const int dpad = (static_cast<int>(a.d) + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
-    const size_t cm = kFlatRerankCap > a.kk ? kFlatRerankCap : a.kk;
+    const size_t cm = flat_rerank_cap(a.kk);
     const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + cm * 8 + (static_cast<size_t>(a.n_lists) + 1) * 4;
     auto kern = rerank2_kernel<DT, METRIC, QMODE>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -937,7 +947,7 @@ __global__ __launch_bounds__(64) void flat_certify_kernel(const FlatProofArgs a)
     const double qh_hi = nq + e16, qh_lo = nq - e16 > 0.0 ? nq - e16 : 0.0;
     const double gam = static_cast<double>(a.dpad) * 0x1p-22, e = static_cast<double>(a.d + 8u) * 0x1p-22;
     uint32_t total = 0;
-    const bool from_shortlist = a.tau == nullptr || flat_overflow(a.cnt, q, a.n_lists, a.cap, total);
+    const bool from_shortlist = a.tau == nullptr || flat_overflow(a.cnt, q, a.n_lists, a.cap, total, flat_rerank_cap(a.kk));
     bool every_row = false;
     double tau = 0.0;
     if (from_shortlist) {

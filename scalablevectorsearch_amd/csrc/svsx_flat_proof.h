@@ -35,6 +35,8 @@ struct FlatProofArgs {
     uint32_t* redo_count;        // optional: += number of queries flagged
 };
 hipError_t launch_flat_certify(const FlatProofArgs& a, hipStream_t stream);
+// the overflow gate with the re-rank capacity of a kk-entry shortlist (max(2048, 32 kk) candidates per query)
+hipError_t launch_flat_gate_kk(const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t kk, uint32_t* block_gate, hipStream_t stream);
 hipError_t launch_norm_range(const float* norm2, uint32_t n, uint32_t* d_max_min_bits, hipStream_t stream); // [0] = max bits (init 0), [1] = min bits (init ~0)
 
 } // namespace svsx

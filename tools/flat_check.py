@@ -1,5 +1,5 @@
 """Flat search at scale: time per batch and how many queries the exactness proof sends to the exhaustive float32 pass.
-usage: python tools/flat_check.py [n] [d] [nq] [k]"""
+usage: python tools/flat_check.py [n] [d] [nq] [k] [metrics, e.g. l2,ip,cos]"""
 import json
 import os
 import sys
@@ -16,12 +16,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+wanted = (sys.argv[5] if len(sys.argv) > 5 else "l2,ip,cos").split(",")
 dev = torch.device("cuda", 0)
 x = deep_like_device(n, d, 64, 1, dev)
 q = deep_like_device(nq, d, 64, 2, dev)
 graph = torch.full((n, 16), -1, dtype=torch.int32, device=dev)  # flat search never reads it
 entry = torch.zeros(1, dtype=torch.int32, device=dev)
 for metric, fn in (("l2", svs.DistanceL2()), ("ip", svs.DistanceIP()), ("cos", svs.DistanceCosineSimilarity())):
+    if metric not in wanted:
+        continue
     idx = svs.VamanaIndex.from_device(graph, x, fn, entry, n, d, np.float32, device=0)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     idx.flat_search_device(q, k, recomputed=cnt)
