@@ -1200,7 +1200,7 @@ int svsx_flat_search_device_counted(
         if (!ix->d_half) {
             void* h = nullptr;
             float* nrm = nullptr;
-            HIP_TRY(hipMalloc(&h, ix->n * dpad * 2 + 64));
+            HIP_TRY(hipMalloc(&h, (ix->n + 32) * dpad * 2 + 64)); // one tile of padding: the threshold kernel loads whole 32-row tiles
             if (hipMalloc(reinterpret_cast<void**>(&nrm), ix->n * 4) != hipSuccess) { (void)hipFree(h); return fail(SVSX_RUNTIME_ERROR, "hipMalloc failed"); }
             hipError_t e = launch_to_half(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), dpad,
                                           ix->sq_enabled, ix->sq_scale, ix->sq_bias, h, nrm, stream);

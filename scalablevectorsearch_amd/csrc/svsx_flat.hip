@@ -345,10 +345,10 @@ hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
 // which at least kk rows satisfy by construction.
 // A threshold taken as the kk-th key of a 1/16 sample admits ~16 kk rows of the 16x larger set (std ~16 sqrt(kk)): lists of up to
 // max(2048, 32 kk) candidates are re-ranked / selected from (LDS), longer ones count as overflow.
-constexpr uint32_t kFlatSelectMax = 8192; // static LDS of the select kernel (kk <= 256)
+constexpr uint32_t kFlatSelectMax = 8192; // keys per query the select kernel accepts (kk <= 256)
 __host__ __device__ __forceinline__ uint32_t flat_rerank_cap(uint32_t kk) { return 32u * kk > 2048u ? 32u * kk : 2048u; }
 __host__ __device__ __forceinline__ uint32_t flat_select_cap(uint32_t kk) {
-    const uint32_t c = 32u * kk > 4096u ? 32u * kk : 4096u;
+    const uint32_t c = 32u * kk > 4096u ? 32u * kk : 4096u; // the coarsest level appends all of its up to 64 tiles = 2 048 rows
     return c < kFlatSelectMax ? c : kFlatSelectMax;
 }
 
@@ -367,7 +367,7 @@ __device__ __forceinline__ bool flat_overflow(const uint32_t* cnt, uint32_t q, u
 // Offsets of one query's (query, slice) lists in the flattened candidate order: loff[s] = sum of the counts of slices < s
 // (loff[n_slices] = total).  n_slices <= 1024.  All lanes then walk the flattened index space in parallel (independent
 // loads) and find an element's slice by binary search in LDS.
-constexpr uint32_t kFlatMaxSlices = 1024;
+// (n_slices <= 1024, svsx_api.hip)
 __device__ __forceinline__ void flat_list_offsets(const uint32_t* cnt, uint32_t q, uint32_t n_slices, uint32_t* loff, uint32_t lane) {
     uint32_t carry = 0;
     for (uint32_t s0 = 0; s0 < n_slices; s0 += 64) {
@@ -430,9 +430,25 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
                 afr1[s2] = r1 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r1) * dpad + 16 * s2 + 8u * half) : z;
             }
         }
-        // thresholds of the 64 queries in LDS (-inf for padding queries); a lane's 32 cells read them as 8 float4
-        ltau[lane] = q0 + lane < a.nq ? a.tau[static_cast<size_t>(q0 + lane) * a.tau_stride] : -__builtin_inff();
+        // Thresholds in the accumulator's domain, so that the accept test is ONE compare per cell: the accumulators start from the row's
+        // constant (L2: -|x|^2 / 2, through the MFMA's C operand) and a cell is accepted iff acc >= thr,
+        //   L2: key = |x|^2 - 2 q.x = -2 acc <= tau  <=>  acc >= -tau / 2;   IP: key = -acc <= tau  <=>  acc >= -tau;
+        //   cosine: key = -(acc * rinv) <= tau  <=>  acc * rinv >= -tau.
+        // The scalings are exact, so the accepted set is exactly {key <= tau} for the key that is stored and selected from.
+        // -inf for padding queries' tau (thr = +inf: never accepted).  A lane's 32 thresholds live in registers.
+        {
+            const float t = q0 + lane < a.nq ? a.tau[static_cast<size_t>(q0 + lane) * a.tau_stride] : -__builtin_inff();
+            ltau[lane] = METRIC == M_L2 ? -0.5f * t : -t;
+#ifdef SVSX_FLAT_DIAG_NO_HITS   // timing builds only: nothing is ever accepted at the full-set level
+            if (a.tile_step == 1) ltau[lane] = __builtin_inff();
+#endif
+        }
         lds_order();
+        float thr[2][16];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) thr[qt][r] = ltau[qt * 32 + 8 * (r >> 2) + 4 * static_cast<int>(half) + (r & 3)];
         constexpr uint32_t ROWB = KS * 32u;       // bytes of one f16 row (dpad * 2)
         constexpr uint32_t PITCH = ROWB + 16u;
         uint32_t lds_off[KS];                      // where this lane's 16-B piece of 1-KB chunk i lands
@@ -442,17 +458,18 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
             lds_off[i] = (g / ROWB) * PITCH + (g % ROWB);
         }
         const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(xh);
+        // a tile is 32 whole rows = KS contiguous KB: wave-uniform base + lane * 16 + i * 1024 (the shadow is padded by one tile, so the
+        // last, partial tile reads initialised bytes; its surplus rows are masked when a cell is appended)
         auto load_tile = [&](uint32_t xt, half8_t (&dst)[KS], float& xnv) { // native 16-B vectors stay in registers
+#ifdef SVSX_FLAT_DIAG_NO_LOADS  // timing builds only: every tile is the slice's first (cache-resident)
+            if (a.tile_step == 1) xt = x_first;
+#endif
+            const unsigned char* base = xbytes + static_cast<size_t>(xt) * ROWB + lane * 16u;
 #pragma unroll
-            for (int i = 0; i < KS; ++i) {
-                const uint32_t g = static_cast<uint32_t>(i) * 1024u + lane * 16u;
-                const uint32_t r = xt + g / ROWB;                      // row this piece belongs to
-                const size_t src = r < a.n ? static_cast<size_t>(xt) * ROWB + g : static_cast<size_t>(g % ROWB); // past the end: row 0
-                dst[i] = *reinterpret_cast<const half8_t*>(xbytes + src);
-            }
+            for (int i = 0; i < KS; ++i) dst[i] = *reinterpret_cast<const half8_t*>(base + static_cast<size_t>(i) * 1024u);
             if constexpr (METRIC != M_IP) {
                 const uint32_t r = xt + col;
-                xnv = a.xnorm2[r < a.n ? r : 0u];
+                xnv = a.xnorm2[r < a.n ? r : a.n - 1u];
             }
         };
         auto stage = [&](uint32_t buf, const half8_t (&src)[KS]) {
@@ -467,19 +484,28 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
         const size_t lane_base = (static_cast<size_t>(q0 + 4u * half) * a.n_slices + slice) * a.cap; // this lane's query group
         auto consume = [&](uint32_t x0, const half8_t (&b)[KS], float xn) {
             float16v_t acc0, acc1;
+            {
+                const float c0 = METRIC == M_L2 ? -0.5f * xn : 0.0f;
+                float16v_t cin;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+                for (int i = 0; i < 16; ++i) cin[i] = c0;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[0], b[0], cin, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr1[0], b[0], cin, 0, 0, 0);
+            }
 #pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2) {
+            for (int s2 = 1; s2 < KS; ++s2) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[s2], b[s2], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr1[s2], b[s2], acc1, 0, 0, 0);
             }
             float rinv = 1.0f;
             if constexpr (METRIC == M_COS) rinv = 1.0f / sqrtf(xn > 0.0f ? xn : 1.0f);
-            auto keyof = [&](float sc) -> float {
-                if constexpr (METRIC == M_L2) return xn - 2.0f * sc;
-                else if constexpr (METRIC == M_IP) return -sc;
-                else return -sc * rinv;
+            auto score = [&](float v) -> float { // what is compared with thr
+                if constexpr (METRIC == M_COS) return v * rinv;
+                else return v;
+            };
+            auto keyof = [&](float v) -> float { // the key that is stored (smaller = better), an exact scaling of the score
+                if constexpr (METRIC == M_L2) return -2.0f * v;
+                else return -score(v);
             };
             // accept test: one compare per cell, folded into 8 wave-level masks (4 cells each); the append path only
             // revisits the groups in which some lane hit
@@ -489,18 +515,18 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
             for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(&ltau[qt * 32 + 8 * g4 + 4 * static_cast<int>(half)]);
-                    const float t[4] = {t4.x, t4.y, t4.z, t4.w};
-                    bool anyg = false;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) anyg = anyg || (keyof(qt == 0 ? acc0[4 * g4 + j] : acc1[4 * g4 + j]) <= t[j]);
-                    gm[qt][g4] = __ballot(anyg);
+                    // four independent compares OR-ed as masks (no short circuit: `||` compiles to exec-mask branches here)
+                    const bool h0 = score(qt == 0 ? acc0[4 * g4 + 0] : acc1[4 * g4 + 0]) >= thr[qt][4 * g4 + 0];
+                    const bool h1 = score(qt == 0 ? acc0[4 * g4 + 1] : acc1[4 * g4 + 1]) >= thr[qt][4 * g4 + 1];
+                    const bool h2 = score(qt == 0 ? acc0[4 * g4 + 2] : acc1[4 * g4 + 2]) >= thr[qt][4 * g4 + 2];
+                    const bool h3 = score(qt == 0 ? acc0[4 * g4 + 3] : acc1[4 * g4 + 3]) >= thr[qt][4 * g4 + 3];
+                    gm[qt][g4] = __ballot(h0) | __ballot(h1) | __ballot(h2) | __ballot(h3);
                     anym |= gm[qt][g4];
                 }
             }
             if (anym == 0ull) return;
             const uint32_t row = x0 + col;
-            const bool valid = row < x_hi; // lanes of a partial last tile hold a duplicate of another row
+            const bool valid = row < x_hi; // lanes of a partial last tile hold rows of the next slice / the padding
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
@@ -509,15 +535,15 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * g4 + j;
-                        const float kv = keyof(qt == 0 ? acc0[r] : acc1[r]);
+                        const float v = qt == 0 ? acc0[r] : acc1[r];
                         const uint32_t cell = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>(j + 8 * g4);
-                        const bool hit = valid && kv <= ltau[cell + 4u * half];
+                        const bool hit = valid && score(v) >= thr[qt][r];
                         if (hit) {
                             const uint32_t pos = atomicAdd(&lcnt[cell + 4u * half], 1u);
                             if (pos < a.cap) {
                                 const size_t o = lane_base + static_cast<size_t>(cell) * stride_q + pos; // cell * stride_q is wave-uniform
                                 a.cand[o] = row;
-                                if (a.cand_keys != nullptr) a.cand_keys[o] = kv;
+                                if (a.cand_keys != nullptr) a.cand_keys[o] = keyof(v);
                             }
                         }
                     }
@@ -530,6 +556,8 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
         load_tile(x_first, gnext, xn_next);
         stage(0u, gnext);
         uint32_t buf = 0;
+        // Issuing tile t + 1's MFMAs before tile t's epilogue inside the wave (two accumulator sets, 249 VGPRs) was measured and is slower
+        // (6.7 ms against 6.0 per 10 000 x 1 M x 96 search): profiles/r04_notes.md section 7.
         for (uint32_t x0 = x_first; x0 < x_hi; x0 += xs, buf ^= 1u) {
             xn_cur = xn_next;
             // next tile in flight during this tile's MFMAs and epilogue (past the end: a harmless re-read of the first)
@@ -578,7 +606,10 @@ hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t s
 __global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict__ keys, const uint32_t* __restrict__ cnt, uint32_t nq,
                                                          uint32_t n_slices, uint32_t cap, uint32_t kk, const float* __restrict__ fb,
                                                          uint32_t fb_stride, float* __restrict__ out) {
-    __shared__ uint32_t buf[kFlatSelectMax];
+    // dynamic LDS: flat_select_cap(kk) keys + n_slices + 1 list offsets (a static 8 192-key buffer would hold the kernel to 4 waves per CU)
+    extern __shared__ __align__(16) unsigned char select_smem[];
+    uint32_t* buf = reinterpret_cast<uint32_t*>(select_smem);
+    uint32_t* loff = buf + flat_select_cap(kk);
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     uint32_t total = 0;
     const bool over = flat_overflow(cnt, q, n_slices, cap, total, flat_select_cap(kk));
@@ -586,7 +617,6 @@ __global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict
         if (lane == 0) out[q] = fb[static_cast<size_t>(q) * fb_stride];
         return;
     }
-    __shared__ uint32_t loff[kFlatMaxSlices + 1];
     flat_list_offsets(cnt, q, n_slices, loff, lane);
     for (uint32_t e = lane; e < total; e += 64) {
         const uint32_t s2 = flat_find_slice(loff, n_slices, e);
@@ -616,7 +646,8 @@ __global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict
 
 hipError_t launch_flat_select(const float* cand_keys, const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t kk,
                               const float* tau_fallback, uint32_t fallback_stride, float* tau_out, hipStream_t stream) {
-    hipLaunchKernelGGL(flat_select_kernel, dim3(nq), dim3(64), 0, stream, cand_keys, cnt, nq, n_slices, cap, kk, tau_fallback, fallback_stride, tau_out);
+    const size_t lds = (static_cast<size_t>(flat_select_cap(kk)) + n_slices + 1) * 4;
+    hipLaunchKernelGGL(flat_select_kernel, dim3(nq), dim3(64), lds, stream, cand_keys, cnt, nq, n_slices, cap, kk, tau_fallback, fallback_stride, tau_out);
     return hipGetLastError();
 }
 
@@ -704,10 +735,47 @@ __global__ __launch_bounds__(64) void rerank_kernel(const RerankArgs a) {
     }
 }
 
+// Sorted k-best list of one query in LDS (cd = distances, ci = ids, best first, cnt entries), owned by one wave.  One pass offers up to 64
+// candidates (lanes with cand set: distance `dist`, id `id`); they are inserted wave-uniformly, one at a time, by (distance, then id).
+// NaN compares false both ways and falls through to the id, like rerank_kernel's ranking.
+template <bool GREATER>
+__device__ __forceinline__ void topk_offer(float* cd, uint32_t* ci, uint32_t& cnt, uint32_t k, float dist, uint32_t id, bool cand, uint32_t lane) {
+    auto before = [](float dc, uint32_t ic, float dd, uint32_t idd) { return cmpf<GREATER>(dc, dd) || (!cmpf<GREATER>(dd, dc) && ic < idd); };
+    if (cand && cnt == k) cand = before(dist, id, cd[cnt - 1u], ci[cnt - 1u]);
+    unsigned long long m = __ballot(cand);
+    while (m != 0ull) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), l));
+        const uint32_t did = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id), l));
+        if (cnt == k && !before(dd, did, cd[cnt - 1u], ci[cnt - 1u])) continue; // an earlier insert of this pass moved the k-th
+        uint32_t pos = 0;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            pos += static_cast<uint32_t>(__builtin_popcountll(__ballot(i < cnt && before(cd[i], ci[i], dd, did))));
+        }
+        const uint32_t top = cnt < k ? cnt : k - 1u; // entries [pos, top) move one place down (the k-th falls off a full list)
+        for (int c = static_cast<int>((k + 63u) / 64u) - 1; c >= 0; --c) {
+            const uint32_t i = static_cast<uint32_t>(c) * 64u + lane;
+            const bool mv = i >= pos && i < top;
+            float v = 0.0f;
+            uint32_t w = 0;
+            if (mv) { v = cd[i]; w = ci[i]; }
+            lds_order();
+            if (mv) { cd[i + 1u] = v; ci[i + 1u] = w; }
+            lds_order();
+        }
+        if (lane == 0) { cd[pos] = dd; ci[pos] = did; }
+        lds_order();
+        if (cnt < k) ++cnt;
+    }
+}
+
 // ---- stage 3b: exact re-rank of a variable-length candidate list (threshold pass) ----------------------------------------------
-// Same exact-order distance routines as rerank_kernel; the k best by (distance, then id) are then extracted by k
-// rounds of a wave-wide arg-min over the list held in LDS.  A query whose list overflowed uses the gated shortlist path's
-// merged list instead.
+// Same exact-order distance routines as rerank_kernel.  The candidates stream through: a pass computes the distances of 64 / G of them and
+// offers them to the k-best list in LDS (topk_offer), so a wave's LDS is the query, the list offsets and k entries -- not the whole
+// candidate list -- and eight waves per SIMD hide the two dependent gathers (candidate id, then its row); the ids of the next pass are
+// requested before the current pass's rows are used.  A query whose list overflowed uses the gated shortlist path's merged list instead.
 template <int DT, int METRIC, int QMODE>
 __global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -723,37 +791,32 @@ __global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
     float* qf = reinterpret_cast<float*>(smem);
     uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
     const uint32_t q_bytes = INTPATH ? static_cast<uint32_t>(dpad) : static_cast<uint32_t>(dpad) * 4u;
-    const uint32_t cm = flat_rerank_cap(a.kk);
-    float* cd = reinterpret_cast<float*>(smem + q_bytes);
-    uint32_t* ci = reinterpret_cast<uint32_t*>(cd + cm);
+    float* cd = reinterpret_cast<float*>(smem + q_bytes);   // k distances, best first
+    uint32_t* ci = reinterpret_cast<uint32_t*>(cd + a.k);   // k ids
+    uint32_t* loff = ci + a.k;                              // n_lists + 1 offsets of the (query, slice) lists in the flattened order
     const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(qi) * a.q_row_bytes;
     const QueryFix fx = prepare_query<DT, METRIC, QMODE>(qptr, a.q_dtype, d, dpad, qf, qw, a.sq_scale, a.sq_bias, lane);
     const int sub = static_cast<int>(lane) & (G - 1);
     const uint32_t grp = lane / G;
     const unsigned char* data = static_cast<const unsigned char*>(a.data);
-    const float worst = GREATER ? -__builtin_inff() : __builtin_inff();
     uint32_t total = 0;
-    const bool overflow = flat_overflow(a.cnt, qi, a.n_lists, a.cap, total, cm);
+    const bool overflow = flat_overflow(a.cnt, qi, a.n_lists, a.cap, total, flat_rerank_cap(a.kk));
     const uint32_t c_n = overflow ? a.kk : total;
-    // gather the candidate ids into LDS
-    if (overflow) {
-        for (uint32_t c = lane; c < c_n; c += 64) {
+    if (!overflow) flat_list_offsets(a.cnt, qi, a.n_lists, loff, lane);
+    auto candidate = [&](uint32_t c) -> uint32_t { // id of flattened candidate c (kInvalidId past the end / empty slot)
+        if (c >= c_n) return kInvalidId;
+        if (overflow) {
             const uint64_t id64 = a.cand_ids[static_cast<size_t>(qi) * a.kk + c];
-            ci[c] = id64 == ~0ull ? kInvalidId : static_cast<uint32_t>(id64);
+            return id64 == ~0ull ? kInvalidId : static_cast<uint32_t>(id64);
         }
-    } else {
-        uint32_t* loff = ci + cm; // n_lists + 1 words behind the id array
-        flat_list_offsets(a.cnt, qi, a.n_lists, loff, lane);
-        for (uint32_t e = lane; e < total; e += 64) {
-            const uint32_t l = flat_find_slice(loff, a.n_lists, e);
-            ci[e] = a.cand32[(static_cast<size_t>(qi) * a.n_lists + l) * a.cap + (e - loff[l])];
-        }
-    }
-    lds_order();
+        const uint32_t l = flat_find_slice(loff, a.n_lists, c);
+        return a.cand32[(static_cast<size_t>(qi) * a.n_lists + l) * a.cap + (c - loff[l])];
+    };
+    uint32_t cnt = 0;
+    uint32_t id_next = candidate(grp);
     for (uint32_t c0 = 0; c0 < c_n; c0 += RPP) {
-        const uint32_t c = c0 + grp;
-        uint32_t id = kInvalidId;
-        if (c < c_n) id = ci[c];
+        const uint32_t id = id_next;
+        id_next = candidate(c0 + RPP + grp);
         const bool act = id != kInvalidId;
         const unsigned char* row = data + static_cast<size_t>(act ? id : 0u) * a.row_bytes;
         float fmain = 0.0f, fnrm = 0.0f;
@@ -762,43 +825,20 @@ __global__ __launch_bounds__(64) void rerank2_kernel(const RerankArgs a) {
         else if constexpr (BC) float_row_distance_bc<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         else float_row_distance<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         const float dist = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
-        if (c < c_n && sub == 0) cd[c] = act ? dist : worst;
+        topk_offer<GREATER>(cd, ci, cnt, a.k, dist, id, act && sub == 0, lane);
     }
-    lds_order();
-    for (uint32_t j = 0; j < a.k; ++j) {
-        float bd = worst;
-        uint32_t bi = kInvalidId, bp = 0;
-        for (uint32_t i = lane; i < c_n; i += 64) {
-            const uint32_t id = ci[i];
-            if (id == kInvalidId) continue;
-            const float dd = cd[i];
-            const bool better = bi == kInvalidId || cmpf<GREATER>(dd, bd) || (!cmpf<GREATER>(bd, dd) && id < bi);
-            if (better) { bd = dd; bi = id; bp = i; }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float od = __shfl_xor(bd, off);
-            const uint32_t oi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(bi), off));
-            const uint32_t op = static_cast<uint32_t>(__shfl_xor(static_cast<int>(bp), off));
-            const bool take = oi != kInvalidId && (bi == kInvalidId || cmpf<GREATER>(od, bd) || (!cmpf<GREATER>(bd, od) && oi < bi));
-            if (take) { bd = od; bi = oi; bp = op; }
-        }
-        const bool have = bi != kInvalidId;
-        if (lane == 0) {
-            const size_t o = static_cast<size_t>(qi) * a.k + j;
-            if (a.ids64 != nullptr) a.ids64[o] = have ? static_cast<uint64_t>(bi) + a.id_offset : ~0ull;
-            if (a.dists != nullptr) a.dists[o] = have ? bd : __builtin_inff();
-            if (have) ci[bp] = kInvalidId;
-        }
-        lds_order();
+    for (uint32_t j = lane; j < a.k; j += 64) {
+        const size_t o = static_cast<size_t>(qi) * a.k + j;
+        const bool have = j < cnt;
+        if (a.ids64 != nullptr) a.ids64[o] = have ? static_cast<uint64_t>(ci[j]) + a.id_offset : ~0ull;
+        if (a.dists != nullptr) a.dists[o] = have ? cd[j] : __builtin_inff();
     }
 }
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_rerank2_one(const RerankArgs& a, hipStream_t stream) {
     const int dpad = (static_cast<int>(a.d) + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
-    const size_t cm = flat_rerank_cap(a.kk);
-    const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + cm * 8 + (static_cast<size_t>(a.n_lists) + 1) * 4;
+    const size_t lds = (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) + static_cast<size_t>(a.k) * 8 + (static_cast<size_t>(a.n_lists) + 1) * 4;
     auto kern = rerank2_kernel<DT, METRIC, QMODE>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), lds, stream, a);
@@ -977,6 +1017,9 @@ __global__ __launch_bounds__(64) void flat_certify_kernel(const FlatProofArgs a)
             ok = best < dk;
         }
     }
+#ifdef SVSX_FLAT_DIAG_NO_HITS
+    ok = true; // timing builds only
+#endif
     a.redo[q] = ok ? 0u : 1u;
     if (!ok && a.redo_count != nullptr) atomicAdd(a.redo_count, 1u);
 }
@@ -1043,8 +1086,6 @@ __global__ __launch_bounds__(64) void flat_exact_kernel(const FlatExactArgs xa) 
     const uint32_t grp = lane / G;
     const unsigned char* data = static_cast<const unsigned char*>(a.data);
     uint32_t cnt = 0;
-    // (dc, ic) ranks before (dd, id)?  NaN compares false both ways and falls through to the id, like the re-rank kernels
-    auto before = [](float dc, uint32_t ic, float dd, uint32_t id) { return cmpf<GREATER>(dc, dd) || (!cmpf<GREATER>(dd, dc) && ic < id); };
     for (uint32_t j0 = 0; j0 < xa.n; j0 += RPP) {
         const uint32_t id = j0 + grp;
         const bool act = id < xa.n;
@@ -1055,35 +1096,7 @@ __global__ __launch_bounds__(64) void flat_exact_kernel(const FlatExactArgs xa) 
         else if constexpr (BC) float_row_distance_bc<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         else float_row_distance<DT, METRIC, 0, QMODE == QM_SQ_COS>(row, act, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         const float dist = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
-        bool cand = act && sub == 0;
-        if (cand && cnt == a.k) cand = before(dist, id, cd[cnt - 1u], ci[cnt - 1u]);
-        unsigned long long m = __ballot(cand);
-        while (m != 0ull) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1ull;
-            const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), l));
-            const uint32_t did = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id), l));
-            if (cnt == a.k && !before(dd, did, cd[cnt - 1u], ci[cnt - 1u])) continue; // an earlier insert of this pass moved the k-th
-            uint32_t pos = 0;
-            for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                pos += static_cast<uint32_t>(__builtin_popcountll(__ballot(i < cnt && before(cd[i], ci[i], dd, did))));
-            }
-            const uint32_t top = cnt < a.k ? cnt : a.k - 1u; // entries [pos, top) move one place down (the k-th falls off a full list)
-            for (int c = static_cast<int>((a.k + 63u) / 64u) - 1; c >= 0; --c) {
-                const uint32_t i = static_cast<uint32_t>(c) * 64u + lane;
-                const bool mv = i >= pos && i < top;
-                float v = 0.0f;
-                uint32_t w = 0;
-                if (mv) { v = cd[i]; w = ci[i]; }
-                lds_order();
-                if (mv) { cd[i + 1u] = v; ci[i + 1u] = w; }
-                lds_order();
-            }
-            if (lane == 0) { cd[pos] = dd; ci[pos] = did; }
-            lds_order();
-            if (cnt < a.k) ++cnt;
-        }
+        topk_offer<GREATER>(cd, ci, cnt, a.k, dist, id, act && sub == 0, lane);
     }
     for (uint32_t j = lane; j < a.k; j += 64) {
         const size_t o = static_cast<size_t>(qi) * a.k + j;
