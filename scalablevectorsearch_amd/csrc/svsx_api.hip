@@ -1176,6 +1176,9 @@ int svsx_distance_batch(
     return SVSX_SUCCESS;
 }
 
+#ifndef SVSX_FLAT_WAVES
+#define SVSX_FLAT_WAVES 2
+#endif
 int svsx_flat_search_device(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream
 ) {
@@ -1301,7 +1304,7 @@ int svsx_flat_search_device_counted(
         const size_t tiles = (ix->n + 31) / 32;
         uint32_t step = 1;
         while (tiles / (static_cast<size_t>(step) * 16) >= 4) step *= 16; // coarsest level keeps >= 4 tiles = 128 rows >= kk
-        size_t s2 = (2 * 1024) / nqb; // two waves per SIMD, one generation
+        size_t s2 = (SVSX_FLAT_WAVES * 1024) / nqb; // resident waves per SIMD x 1 024 SIMDs, one generation
         if (s2 > ix->n / 4096) s2 = ix->n / 4096;
         if (s2 < 1) s2 = 1;
         if (s2 > 1024) s2 = 1024;

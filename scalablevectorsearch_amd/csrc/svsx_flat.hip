@@ -497,6 +497,12 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[s2], b[s2], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr1[s2], b[s2], acc1, 0, 0, 0);
             }
+#ifdef SVSX_FLAT_DIAG_NO_EPILOGUE  // timing builds only: the MFMAs stay alive through one compare
+            if (a.tile_step == 1) {
+                if (acc0[0] + acc1[15] == 123.456f) lcnt[0] = 1u;
+                return;
+            }
+#endif
             float rinv = 1.0f;
             if constexpr (METRIC == M_COS) rinv = 1.0f / sqrtf(xn > 0.0f ? xn : 1.0f);
             auto score = [&](float v) -> float { // what is compared with thr
@@ -562,6 +568,14 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
             xn_cur = xn_next;
             // next tile in flight during this tile's MFMAs and epilogue (past the end: a harmless re-read of the first)
             load_tile(x0 + xs < x_hi ? x0 + xs : x_first, gnext, xn_next);
+#ifdef SVSX_FLAT_DIAG_NO_LDS       // timing builds only: the loaded pieces are used as fragments where they are
+            if (a.tile_step == 1) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i) bcur[i] = gnext[i];
+                consume(x0, bcur, xn_cur);
+                continue;
+            }
+#endif
             lds_order();
             fragments(buf, bcur);
             consume(x0, bcur, xn_cur);
@@ -581,16 +595,17 @@ hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t s
         hipLaunchKernelGGL(kern, grid, dim3(64), 0, stream, a);
         return hipGetLastError();
     };
+#define SVSX_THRESH_KERNEL flat_thresh_kernel
 #define SVSX_THRESH_CASE(M)                                   \
     switch (ks) {                                             \
-        case 1: return go(flat_thresh_kernel<M, 1>);          \
-        case 2: return go(flat_thresh_kernel<M, 2>);          \
-        case 3: return go(flat_thresh_kernel<M, 3>);          \
-        case 4: return go(flat_thresh_kernel<M, 4>);          \
-        case 5: return go(flat_thresh_kernel<M, 5>);          \
-        case 6: return go(flat_thresh_kernel<M, 6>);          \
-        case 7: return go(flat_thresh_kernel<M, 7>);          \
-        default: return go(flat_thresh_kernel<M, 8>);         \
+        case 1: return go(SVSX_THRESH_KERNEL<M, 1>);          \
+        case 2: return go(SVSX_THRESH_KERNEL<M, 2>);          \
+        case 3: return go(SVSX_THRESH_KERNEL<M, 3>);          \
+        case 4: return go(SVSX_THRESH_KERNEL<M, 4>);          \
+        case 5: return go(SVSX_THRESH_KERNEL<M, 5>);          \
+        case 6: return go(SVSX_THRESH_KERNEL<M, 6>);          \
+        case 7: return go(SVSX_THRESH_KERNEL<M, 7>);          \
+        default: return go(SVSX_THRESH_KERNEL<M, 8>);         \
     }
     switch (metric) {
         case M_L2: SVSX_THRESH_CASE(M_L2)
