@@ -567,6 +567,9 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
         for (uint32_t x0 = x_first; x0 < x_hi; x0 += xs, buf ^= 1u) {
             xn_cur = xn_next;
             // next tile in flight during this tile's MFMAs and epilogue (past the end: a harmless re-read of the first)
+#ifdef SVSX_FLAT_DIAG_NO_VMEM      // timing builds only: no vector-memory instruction in the full pass's loop (the first tile is reused)
+            if (a.tile_step != 1)
+#endif
             load_tile(x0 + xs < x_hi ? x0 + xs : x_first, gnext, xn_next);
 #ifdef SVSX_FLAT_DIAG_NO_LDS       // timing builds only: the loaded pieces are used as fragments where they are
             if (a.tile_step == 1) {
