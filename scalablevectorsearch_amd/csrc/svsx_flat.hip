@@ -976,6 +976,7 @@ __global__ __launch_bounds__(64) void flat_certify_kernel(const FlatProofArgs a)
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const unsigned char* qptr = static_cast<const unsigned char*>(a.queries) + static_cast<size_t>(q) * a.q_row_bytes;
     double s2 = 0.0, ds2 = 0.0;
+    float qmax = 0.0f; // a query component beyond the float16 range makes its shadow +-inf and every key NaN / inf
     for (uint32_t i = lane; i < a.d; i += 64) {
         float v;
         switch (a.q_dtype) {
@@ -985,6 +986,7 @@ __global__ __launch_bounds__(64) void flat_certify_kernel(const FlatProofArgs a)
             default: v = static_cast<float>(static_cast<unsigned>(qptr[i])); break;
         }
         s2 += static_cast<double>(v) * static_cast<double>(v);
+        qmax = fabsf(v) > qmax || v != v ? (v != v ? __builtin_inff() : fabsf(v)) : qmax;
         if (a.sq_l2) { // the reference's query is the decompressed code of the query
             const int c = a.data_dtype == DT_I8 ? sq_compress<DT_I8>(v, a.sq_scale, a.sq_bias) : sq_compress<DT_U8>(v, a.sq_scale, a.sq_bias);
             const double back = static_cast<double>(a.sq_scale) * static_cast<double>(c) + static_cast<double>(a.sq_bias);
@@ -994,6 +996,8 @@ __global__ __launch_bounds__(64) void flat_certify_kernel(const FlatProofArgs a)
     for (int off = 32; off >= 1; off >>= 1) {
         s2 += __shfl_xor(s2, off);
         ds2 += __shfl_xor(ds2, off);
+        const float oq = __shfl_xor(qmax, off);
+        qmax = oq > qmax ? oq : qmax;
     }
     if (lane != 0) return;
     const double nq = sqrt(s2), dqs = sqrt(ds2);
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(64) void flat_certify_kernel(const FlatProofArgs a)
     const bool have_k = a.out_ids[kth] != ~0ull;
     const double dk = static_cast<double>(a.out_dists[kth]);
     bool ok = false;
-    if (!(nq <= 1.0e30) || !(xmax <= 1.0e30)) ok = false; // NaN / inf anywhere in the query or the data
+    if (!(nq <= 1.0e30) || !(xmax <= 1.0e30) || !(qmax <= 65504.0f)) ok = false; // NaN / inf anywhere in the query, the data or their shadows
     else if (every_row) ok = true;
     else if (!have_k) ok = false;
     else if (a.metric == M_L2) {

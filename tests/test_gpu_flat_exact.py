@@ -83,6 +83,23 @@ def test_rows_float16_cannot_hold(svs, oracle, metric):
     assert redone == 20
 
 
+@pytest.mark.parametrize("n", [3000, 70_000])
+def test_queries_float16_cannot_hold(svs, oracle, n):
+    """a query component beyond the float16 range turns the query's shadow into +-inf and every float16 key into NaN / inf: nothing can be
+    proven for that query (an EMPTY shortlist must not read as 'every row was re-ranked'), the exhaustive pass answers it."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((n, 32)).astype(np.float32)
+    q = rng.standard_normal((6, 32)).astype(np.float32)
+    q[1, 3] = np.float32(1.0e6)
+    q[4] *= np.float32(3.0e5)
+    for metric in (L2, IP, COS):
+        idx = svs.FlatIndex(x, _fn(svs, metric))
+        ids, dists, redone = _search_counted(idx, q, 10)
+        want_i, want_d = oracle.flat_search(metric, x, q, 10)
+        _assert_equal(ids, dists, want_i, want_d, (metric, n))
+        assert 2 <= redone <= 3, redone
+
+
 def test_exhaustive_pass_orders_ties_and_short_sets(svs, oracle):
     """duplicates of one row (equal float32 distances: lowest ids win) spread over the whole set, more of them than the shortlist holds; and a
     set smaller than k."""
