@@ -1,7 +1,9 @@
 // Step-by-step model of the flat threshold kernel's tile loop (64 queries x 32 rows x 96 dims per tile and wave): which ingredient costs what.
 //   hipcc --offload-arch=gfx950 -O3 -o flat_loop_model tools/ubench/flat_loop_model.hip && ./flat_loop_model
 // F bits: 1 = accumulators start from a per-tile constant and are read at the end of the tile (drain), 2 = B fragments re-read from LDS,
-//         4 = tile staged into LDS from registers (ds_write), 8 = tile streamed from global memory (6 KB per tile), 16 = 32 compares + mask ORs.
+//         4 = tile staged into LDS from registers (ds_write), 8 = tile streamed from global memory (6 KB per tile), 16 = 32 compares + mask ORs,
+//         32 = the row norm of every tile loaded from global memory (the accumulators' constant), 64 = the product's eight group masks with the
+//         (never taken) append path behind them instead of one OR-ed mask.
 // Occupancy is set like the product kernel's (2 waves per SIMD) through the dynamic LDS size.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -46,11 +48,13 @@ __global__ __launch_bounds__(64) void tile_loop(const unsigned char* __restrict_
     uint32_t buf = 0;
     float xn = thr_in[lane];
     for (int t = 0; t < tiles; ++t, buf ^= 1u) {
+        float xn_next = xn;
         if (F & 8) {
             const unsigned char* p = base + static_cast<size_t>(t + 1) * 6144u;
 #pragma unroll
             for (int i = 0; i < KS; ++i) gnext[i] = *reinterpret_cast<const half8_t*>(p + i * 1024);
         }
+        if (F & 32) xn_next = -0.5f * reinterpret_cast<const float*>(x)[((wave_base >> 2) + static_cast<size_t>(t + 1) * 32u + col) & ((x_bytes >> 2) - 1)];
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (F & 2) {
 #pragma unroll
@@ -71,7 +75,36 @@ __global__ __launch_bounds__(64) void tile_loop(const unsigned char* __restrict_
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[s], bcur[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr1[s], bcur[s], acc1, 0, 0, 0);
         }
-        if (F & 16) {
+        if (F & 64) {
+            unsigned long long gm[2][4], anym = 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float16v_t& ac = q == 0 ? acc0 : acc1;
+                    gm[q][g4] = __ballot(ac[4 * g4] >= thr[q][4 * g4]) | __ballot(ac[4 * g4 + 1] >= thr[q][4 * g4 + 1]) | __ballot(ac[4 * g4 + 2] >= thr[q][4 * g4 + 2]) |
+                                __ballot(ac[4 * g4 + 3] >= thr[q][4 * g4 + 3]);
+                    anym |= gm[q][g4];
+                }
+            if (anym != 0ull) {
+                uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + 2 * 32 * PITCH);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        if (gm[q][g4] == 0ull) continue;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = q == 0 ? acc0[4 * g4 + j] : acc1[4 * g4 + j];
+                            if (v >= thr[q][4 * g4 + j]) {
+                                const uint32_t pos = atomicAdd(&lcnt[q * 32 + 8 * g4 + j + 4 * half], 1u);
+                                if (pos < 512u) out[64 + ((blockIdx.x * 64u + q * 32 + 8 * g4 + j + 4 * half) * 512u + pos) % 4096u] = v;
+                            }
+                        }
+                    }
+                hits += 1;
+            }
+        } else if (F & 16) {
             unsigned long long m = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) m |= __ballot(acc0[r] >= thr[0][r]) | __ballot(acc1[r] >= thr[1][r]);
@@ -84,7 +117,8 @@ __global__ __launch_bounds__(64) void tile_loop(const unsigned char* __restrict_
             for (int i = 0; i < KS; ++i) *reinterpret_cast<half8_t*>(&btile[(buf ^ 1u) * 32 * PITCH + lds_off[i]]) = gnext[i];
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        if (F & 1) xn = xn * 1.0001f;
+        if (F & 32) xn = xn_next;
+        else if (F & 1) xn = xn * 1.0001f;
     }
     float s = static_cast<float>(hits);
     for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
@@ -110,7 +144,7 @@ template <int F> static void run(const unsigned char* x, size_t x_bytes, const f
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kern));
     const double flop = static_cast<double>(blocks) * tiles * 12.0 * 32768.0;
-    printf("{\"share\": %d, \"features\": %d, \"drain\": %d, \"lds_read\": %d, \"lds_write\": %d, \"global\": %d, \"compares\": %d, \"vgprs\": %d, \"ms\": %.3f, \"tflops\": %.1f, \"ns_per_tile_per_wave\": %.1f}\n", share, F,
+    printf("{\"share\": %d, \"features\": %d, \"norm_load\": %d, \"group_masks\": %d, \"drain\": %d, \"lds_read\": %d, \"lds_write\": %d, \"global\": %d, \"compares\": %d, \"vgprs\": %d, \"ms\": %.3f, \"tflops\": %.1f, \"ns_per_tile_per_wave\": %.1f}\n", share, F, (F >> 5) & 1, (F >> 6) & 1,
            F & 1, (F >> 1) & 1, (F >> 2) & 1, (F >> 3) & 1, (F >> 4) & 1, at.numRegs, ms, flop / (ms * 1e-3) / 1e12, ms * 1e6 / tiles);
 }
 
@@ -224,7 +258,7 @@ int main() {
     float *thr, *out;
     (void)hipMalloc(&x, x_bytes);
     (void)hipMalloc(&thr, 256);
-    (void)hipMalloc(&out, 64);
+    (void)hipMalloc(&out, 64 * 4 + 4096 * 4);
     (void)hipMemset(x, 0x11, x_bytes);
     std::vector<float> h(64, 1.0e30f);
     (void)hipMemcpy(thr, h.data(), 256, hipMemcpyHostToDevice);
@@ -242,6 +276,9 @@ int main() {
     run<1 | 2 | 4 | 8>(x, x_bytes, thr, out, 1);
     run<1 | 2 | 4 | 8>(x, x_bytes, thr, out, 64);
     run<1 | 2 | 4 | 8>(x, x_bytes, thr, out, 256);
+    run<1 | 2 | 4 | 8 | 16 | 32>(x, x_bytes, thr, out, 13);
+    run<1 | 2 | 4 | 8 | 64>(x, x_bytes, thr, out, 13);
+    run<1 | 2 | 4 | 8 | 32 | 64>(x, x_bytes, thr, out, 13);
     run_pipelined<0>(x, x_bytes, thr, out, 13);
     run_pipelined<0>(x, x_bytes, thr, out, 0);
     return 0;
