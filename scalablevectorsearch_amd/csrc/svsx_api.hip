@@ -1179,6 +1179,9 @@ int svsx_distance_batch(
 #ifndef SVSX_FLAT_WAVES
 #define SVSX_FLAT_WAVES 2
 #endif
+#ifndef SVSX_FLAT_KT
+#define SVSX_FLAT_KT(k, kk) ((k) + 8 > 16 ? ((k) + 8 < (kk) ? (k) + 8 : (kk)) : (16 < (kk) ? size_t(16) : (kk)))
+#endif
 int svsx_flat_search_device(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream
 ) {
@@ -1310,7 +1313,12 @@ int svsx_flat_search_device_counted(
         if (s2 > 1024) s2 = 1024;
         // rows per (query, slice) list: ~16 kk / s2 expected at every level, at most 16 x 32 at the coarsest; 4x head room
         size_t cap = 512;
-        while (cap < 4 * (16 * kk / s2 + 1)) cap *= 2;
+        // The thresholds are taken at rank kt < kk: with the proof of stage 4 behind it, the threshold pipeline needs no float16 safety margin
+        // in its candidate lists -- ~16 kt rows per query (288 for k = 10) are appended and re-ranked instead of ~16 kk (640), and whether
+        // that was enough is decided per query by the proof, not by the margin.  (The shortlist kernel keeps kk: its proof needs the gap
+        // between the k-th and the kk-th key.)
+        const size_t kt = SVSX_FLAT_KT(k, kk);
+        while (cap < 4 * (16 * kt / s2 + 1)) cap *= 2;
         const size_t coarse_rows = (tiles / step + 1) * 32; // all of them are appended at the first level
         while (cap < 2 * coarse_rows / s2 && cap < 8192) cap *= 2;
         HIP_TRY(bcand.alloc(nq * s2 * cap * 4, stream));
@@ -1335,7 +1343,7 @@ int svsx_flat_search_device_counted(
             ta.tau = tau_cur;
             ta.cand_keys = static_cast<float*>(bkeys.p);
             if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
-            if (e == hipSuccess) e = launch_flat_select(ta.cand_keys, ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t>(kk), tau_cur, 1, tau_nxt, stream);
+            if (e == hipSuccess) e = launch_flat_select(ta.cand_keys, ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t>(kt), tau_cur, 1, tau_nxt, stream);
             float* t = tau_cur; tau_cur = tau_nxt; tau_nxt = t;
         }
         ta.tile_step = 1;
