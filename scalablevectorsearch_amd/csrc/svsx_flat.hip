@@ -348,7 +348,9 @@ hipError_t launch_flat_mfma(int metric, const FlatArgs& a, hipStream_t stream) {
 constexpr uint32_t kFlatSelectMax = 8192; // keys per query the select kernel accepts (kk <= 256)
 __host__ __device__ __forceinline__ uint32_t flat_rerank_cap(uint32_t kk) { return 32u * kk > 2048u ? 32u * kk : 2048u; }
 __host__ __device__ __forceinline__ uint32_t flat_select_cap(uint32_t kk) {
-    const uint32_t c = 32u * kk > 4096u ? 32u * kk : 4096u; // the coarsest level appends all of its up to 64 tiles = 2 048 rows
+    // the coarsest level appends all of its up to 64 tiles = 2 048 rows (+ one partial tile); the key buffer in LDS decides how many of the
+    // kernel's one-wave workgroups a compute unit holds, and the kernel is a chain of dependent latencies: 9 KB instead of 16 KB halves its time
+    const uint32_t c = 32u * kk > 2304u ? 32u * kk : 2304u;
     return c < kFlatSelectMax ? c : kFlatSelectMax;
 }
 

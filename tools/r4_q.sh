@@ -1,10 +1,8 @@
 #!/bin/bash
-# round 4, call w: threshold rank kt = k + 4 / k + 8 (production) / k + 16
-R=$PWD; O=$R/gpurun_out/r04w; mkdir -p $O; rm -rf $O/*
-for V in fkt4 base fkt16; do
-  if [ $V = base ]; then unset SVSX_LIB; else export SVSX_LIB=$R/variants/$V/libsvsx.so; fi
-  echo "== $V" >> $O/out.txt
-  timeout 200 python tools/flat_check.py 1000000 96 10000 10 l2 >> $O/out.txt 2>/dev/null
-  timeout 200 python tools/flat_check.py 1000000 96 10000 32 l2 >> $O/out.txt 2>/dev/null
-done
-cat $O/out.txt
+R=$PWD; O=$R/gpurun_out/r04y; mkdir -p $O; rm -rf $O/*
+timeout 600 python -m pytest tests/test_gpu_flat_exact.py tests/test_gpu_parity.py -q -k "flat" > $O/flat_tests.log 2>&1; echo "flat tests rc=$?" >> $O/out.txt
+timeout 200 python tools/flat_check.py 1000000 96 10000 10 >> $O/out.txt 2>/dev/null
+timeout 200 python tools/flat_check.py 1000000 96 10000 100 l2 >> $O/out.txt 2>/dev/null
+timeout 200 python tools/flat_check.py 1000000 128 10000 10 l2 >> $O/out.txt 2>/dev/null
+timeout 200 python tools/flat_check.py 100000 96 1000 10 l2 >> $O/out.txt 2>/dev/null
+tail -3 $O/flat_tests.log; cat $O/out.txt
