@@ -1,8 +1,16 @@
 #!/bin/bash
-R=$PWD; O=$R/gpurun_out/r04y; mkdir -p $O; rm -rf $O/*
-timeout 600 python -m pytest tests/test_gpu_flat_exact.py tests/test_gpu_parity.py -q -k "flat" > $O/flat_tests.log 2>&1; echo "flat tests rc=$?" >> $O/out.txt
-timeout 200 python tools/flat_check.py 1000000 96 10000 10 >> $O/out.txt 2>/dev/null
-timeout 200 python tools/flat_check.py 1000000 96 10000 100 l2 >> $O/out.txt 2>/dev/null
-timeout 200 python tools/flat_check.py 1000000 128 10000 10 l2 >> $O/out.txt 2>/dev/null
-timeout 200 python tools/flat_check.py 100000 96 1000 10 l2 >> $O/out.txt 2>/dev/null
-tail -3 $O/flat_tests.log; cat $O/out.txt
+set -u
+OUT=gpurun_out/r04bench
+mkdir -p $OUT; rm -f $OUT/*
+( time python bench.py > $OUT/bench_1gpu.json 2> $OUT/bench.err ) 2>&1 | tail -n 4
+echo "bench rc=$?"
+tail -n 3 $OUT/bench.err
+python - <<'PY'
+import json
+j=json.load(open('gpurun_out/r04bench/bench_1gpu.json'))
+print(j['value'], j['ms_per_step'], j['roofline']['kernel_ms'], j['roofline']['frac'])
+print('flat', j['config']['other_configs']['c3'].get('flat_search'))
+print('host', j['config']['host_pointer']['median_ms'], j['config']['host_pointer']['over_device_resident'])
+print('c4', {k:v for k,v in j['config']['other_configs']['c4'].items() if k in ('qps','recall_at_10','window_for_recall_0.9','oracle_sample')})
+print('sharded', j.get('sharded_search',{}).get('value'), 'gt', j['config']['ground_truth'].get('queries_recomputed_exhaustively'), j['config']['ground_truth'].get('id_sets_equal_to_float64_brute_force'))
+PY
