@@ -998,6 +998,7 @@ static int search_host_pipelined(
     // (five chunks: 1.43-1.50 ms against 1.15 ms for the kernel alone; profiles/r03_notes.md).  The copies go straight between the caller's
     // (pageable) arrays and the device staging: the runtime's own pipelined bounce (1.5 MB in 41 us, 3.8 MB in 92 us on the bench host)
     // beats memcpy into a page-locked mirror followed by the DMA (33 + 37 us, 79 + 76 us; profiles/r04_notes.md section 6).
+    // (three chunks 2 048 + 4 096 + rest with direct copies: 1.30-1.31 ms against 1.25-1.27, profiles/r04_notes.md section 6)
     size_t first = nq > 4096 ? 4096 : nq;
     if (first < nq) {
         nc = 2;
