@@ -220,6 +220,9 @@ int svsx_flat_search_device_counted(
     const svsx_index* index, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, uint32_t* d_recomputed,
     void* hip_stream
 );
+/* The same search with host pointers in and out (svs::Flat::search, include/svs/orchestrators/exhaustive.h): queries [nq][d] of q_dtype, ids64 [nq][k],
+ * dists [nq][k] or NULL.  Blocks until the answer is in the caller's arrays. */
+int svsx_flat_search(const svsx_index* index, const void* queries, int q_dtype, size_t nq, size_t k, uint64_t* ids64, float* dists);
 
 /* VamanaBuildParameters (index/vamana/build_params.h:28-75). */
 typedef struct {

@@ -96,6 +96,32 @@ template <typename Idx = size_t> class QueryResult {
 };
 
 // Read-only Vamana index resident in one GPU's HBM.  Graph = SVS rows [deg, ids...] (core/graph/graph.h:32-48).
+// svs::Flat (include/svs/orchestrators/exhaustive.h; index/flat/flat.h:322-460): exhaustive search over a data set resident in HBM.  Exact by
+// proof (svsx.h): float16 MFMA shortlist, float32 re-rank in the reference's operation order, per-query certificate, exhaustive pass for the rest.
+template <typename T, typename Dist> class FlatIndex {
+    svsx_index* h_ = nullptr;
+  public:
+    FlatIndex(const T* data, size_t n, size_t d, Dist = {}, int device = 0) {
+        svsx_index_desc desc{};
+        desc.metric = Dist::metric; desc.data_dtype = dtype_of<T>(); desc.n = n; desc.d = d; desc.data = data; desc.device = device;
+        check(svsx_index_create(&desc, &h_)); // graph == NULL: a flat index
+    }
+    FlatIndex(const FlatIndex&) = delete;
+    FlatIndex& operator=(const FlatIndex&) = delete;
+    FlatIndex(FlatIndex&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    ~FlatIndex() { svsx_index_destroy(h_); }
+    template <typename Q> void search(QueryResultView<size_t> result, const Q* queries) const {
+        static_assert(sizeof(size_t) == sizeof(uint64_t));
+        check(svsx_flat_search(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), reinterpret_cast<uint64_t*>(result.indices), result.distances));
+    }
+    template <typename Q> QueryResult<size_t> search(const Q* queries, size_t nq, size_t k) const {
+        QueryResult<size_t> r(nq, k);
+        search(r.view(), queries);
+        return r;
+    }
+    const svsx_index* handle() const { return h_; }
+};
+
 template <typename T, typename Dist> class VamanaIndex {
     svsx_index* h_ = nullptr;
     VamanaSearchParameters defaults_{};

@@ -82,7 +82,7 @@ EXPORTS = [
     "svsx_iterator_next_device", "svsx_iterator_state", "svsx_index_build_bound_codes", "svsx_merge_topk_strided_device",
     "svsx_last_kernel_info", "svsx_search_filtered", "svsx_search_filtered_ex", "svsx_vamana_build_device", "svsx_find_medoid_device",
     "svsx_sharded_unique_id", "svsx_sharded_create", "svsx_sharded_create_with_comm", "svsx_sharded_destroy", "svsx_sharded_info",
-    "svsx_sharded_search_device", "svsx_abi_version", "svsx_flat_search_device_counted",
+    "svsx_sharded_search_device", "svsx_abi_version", "svsx_flat_search_device_counted", "svsx_flat_search",
 ]
 
 _lib = None
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
         L.svsx_prune_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         L.svsx_flat_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_flat_search_device_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svsx_flat_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.svsx_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.svsx_iterator_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
         L.svsx_iterator_destroy.argtypes = [C.c_void_p]

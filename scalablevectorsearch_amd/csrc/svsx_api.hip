@@ -1189,6 +1189,30 @@ int svsx_flat_search_device(
     return svsx_flat_search_device_counted(ix, d_queries, q_dtype, nq, k, d_ids64, d_dists, nullptr, hip_stream);
 }
 
+// host pointers in, host results out (svs::Flat::search through the C ABI): staging in stream order, one synchronisation at the end
+int svsx_flat_search(const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, uint64_t* ids64, float* dists) {
+    if (int rc = check_search_args(ix, queries, q_dtype, nq, k, false)) return rc;
+    if (nq == 0) return SVSX_SUCCESS;
+    if (!ids64) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    CallStream cs;
+    HIP_TRY(cs.create());
+    StreamBuffer dq, di, dd;
+    const size_t q_bytes = nq * ix->d * dtype_size(q_dtype);
+    HIP_TRY(dq.alloc(q_bytes, cs.s));
+    HIP_TRY(di.alloc(nq * k * 8, cs.s));
+    HIP_TRY(dd.alloc(nq * k * 4, cs.s));
+    HIP_TRY(hipMemcpyAsync(dq.p, queries, q_bytes, hipMemcpyHostToDevice, cs.s));
+    if (int rc = svsx_flat_search_device_counted(ix, dq.p, q_dtype, nq, k, static_cast<uint64_t*>(di.p), static_cast<float*>(dd.p), nullptr, cs.s)) {
+        (void)hipStreamSynchronize(cs.s);
+        return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(ids64, di.p, nq * k * 8, hipMemcpyDeviceToHost, cs.s));
+    if (dists) HIP_TRY(hipMemcpyAsync(dists, dd.p, nq * k * 4, hipMemcpyDeviceToHost, cs.s));
+    HIP_TRY(hipStreamSynchronize(cs.s));
+    return SVSX_SUCCESS;
+}
+
 int svsx_flat_search_device_counted(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, uint32_t* d_recomputed,
     void* hip_stream

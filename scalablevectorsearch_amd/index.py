@@ -331,7 +331,8 @@ class FlatIndex:
         queries = np.ascontiguousarray(np.atleast_2d(queries))
         if queries.shape[1] != self.d:
             raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Query dimension {queries.shape[1]} does not match index dimension {self.d}")
-        dq = torch.from_numpy(queries.view(np.int8) if queries.dtype == np.int8 else queries).to(torch.device("cuda", self.device))
-        ids, dists = self.flat_search_device(dq, num_neighbors, q_dtype=dtype_code(queries))
-        torch.cuda.synchronize(self.device)
-        return QueryResult(ids.cpu().numpy().view(np.uint64), dists.cpu().numpy())
+        nq = queries.shape[0]
+        ids = np.empty((nq, num_neighbors), np.uint64)
+        dists = np.empty((nq, num_neighbors), np.float32)
+        _lib.check(_lib.lib().svsx_flat_search(self._h, queries.ctypes.data, dtype_code(queries), nq, num_neighbors, ids.ctypes.data, dists.ctypes.data))
+        return QueryResult(ids, dists)

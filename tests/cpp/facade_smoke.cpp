@@ -26,6 +26,11 @@ int main(int argc, char**) {
         index.search(result.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}));
         std::printf("%zu %zu %zu\n", result.index(0, 0), result.index(0, 1), result.index(0, 2));
         if (!(result.index(0, 0) == 5 && result.index(0, 1) == 6 && result.index(0, 2) == 4)) return 1;
+        {   // svs::Flat-shaped facade over the same 8 points: exhaustive search, host pointers in and out
+            svsx::FlatIndex<float, svsx::DistanceL2> flat(data.data(), n, d);
+            const auto fr = flat.search(q.data(), 1, 3);
+            if (!(fr.index(0, 0) == 5 && fr.index(0, 1) == 6 && fr.index(0, 2) == 4)) return 15;
+        }
         // the cancel predicate of VamanaIndex::search (index.h:564-570): false -> same answer; true -> nothing is written
         svsx::QueryResult<size_t> r2(1, 3);
         index.search(r2.view(), q.data(), svsx::VamanaSearchParameters{}.buffer_config({8}), [] { return false; });
