@@ -1177,9 +1177,6 @@ int svsx_distance_batch(
     return SVSX_SUCCESS;
 }
 
-#ifndef SVSX_FLAT_WAVES
-#define SVSX_FLAT_WAVES 2
-#endif
 #ifndef SVSX_FLAT_KT
 #define SVSX_FLAT_KT(k, kk) ((k) + 8 > 16 ? ((k) + 8 < (kk) ? (k) + 8 : (kk)) : (16 < (kk) ? size_t(16) : (kk)))
 #endif
@@ -1225,7 +1222,9 @@ int svsx_flat_search_device_counted(
     if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const uint32_t dpad = static_cast<uint32_t>((ix->d + 15) & ~size_t(15));
+    // rows of the float16 shadow: padded to 16 elements, between 129 and 768 dimensions to 128 (the threshold kernel for those takes the
+    // dimension in chunks of 128)
+    const uint32_t dpad = static_cast<uint32_t>(ix->d > 128 && ix->d <= 768 ? (ix->d + 127) & ~size_t(127) : (ix->d + 15) & ~size_t(15));
     {   // float16 shadow of the database + squared norms, built once
         std::lock_guard<std::mutex> lock(ix->shadow_mutex);
         if (!ix->d_half) {
@@ -1255,8 +1254,12 @@ int svsx_flat_search_device_counted(
     size_t kk = 4 * k > k + 32 ? 4 * k : k + 32;
     if (kk > 128) kk = k + 32 > 128 ? k + 32 : 128;
     if (kk > ix->n) kk = ix->n < k ? k : ix->n;
-    {   // the shortlist kernel keeps 64 shortlists (and, beyond d = 128, the 64 queries) of a wave in LDS
-        const size_t need = (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0) + 64 * kk * 8 + 256;
+    {   // the shortlist kernel keeps 64 shortlists (and, beyond d = 128, the 64 queries) of a wave in LDS; where that does not fit the
+        // shortlist shrinks towards k + 8 -- the answer stays exact, a shorter shortlist only makes the proof of stage 4 fail more often
+        const size_t fixed = (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0) + 256;
+        while (fixed + 64 * kk * 8 > 160 * 1024 && kk > k + 8) kk -= 4;
+        if (kk < k) kk = k;
+        const size_t need = fixed + 64 * kk * 8;
         if (need > 160 * 1024)
             return fail(SVSX_INVALID_ARGUMENT, "flat search: k = %zu at d = %zu needs %zu bytes of LDS per wave (160 KB available): lower k", k, ix->d, need);
     }
@@ -1323,7 +1326,7 @@ int svsx_flat_search_device_counted(
     pa.short_keys = static_cast<const float*>(mk); pa.short_ids = static_cast<const uint64_t*>(mi);
     pa.xmax2 = ix->shadow_max2; pa.xmin2 = ix->shadow_min2;
     pa.redo = static_cast<uint32_t*>(bredo.p); pa.redo_count = d_recomputed;
-    bool thresh_path = dpad <= 128 && ix->n >= 65536 && nq <= 65536;
+    bool thresh_path = flat_thresh_supports(dpad) && ix->n >= 65536 && nq <= 65536;
 #ifdef SVSX_DIAG
     if (getenv("SVSX_FLAT_SHORTLIST_ONLY")) thresh_path = false; // A/B builds only
 #endif
@@ -1332,7 +1335,7 @@ int svsx_flat_search_device_counted(
         const size_t tiles = (ix->n + 31) / 32;
         uint32_t step = 1;
         while (tiles / (static_cast<size_t>(step) * 16) >= 4) step *= 16; // coarsest level keeps >= 4 tiles = 128 rows >= kk
-        size_t s2 = (SVSX_FLAT_WAVES * 1024) / nqb; // resident waves per SIMD x 1 024 SIMDs, one generation
+        size_t s2 = (flat_thresh_waves_per_simd(dpad) * 1024) / nqb; // resident waves per SIMD x 1 024 SIMDs, one generation
         if (s2 > ix->n / 4096) s2 = ix->n / 4096;
         if (s2 < 1) s2 = 1;
         if (s2 > 1024) s2 = 1024;

@@ -592,14 +592,187 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
     if (q0 + lane < a.nq) a.cnt[static_cast<size_t>(q0 + lane) * a.n_slices + slice] = lcnt[lane];
 }
 
+// ---- stage 1b for 128 < d <= 768 ---------------------------------------------------------------------------------------------
+// The same threshold pass with the dimension cut into KCH chunks of 128 (the shadow's rows are padded to a multiple of 128 there).  All A
+// fragments of a wave's 64 queries stay in registers (2 x 8 KCH x 4 = 384 at d = 768: one wave per SIMD owns the whole 512-register file);
+// a B tile arrives chunk by chunk -- 32 rows x 256 B through registers into LDS, fragments re-read from there, like the d <= 128 kernel
+// with KS = 8 -- and the accumulators run across the chunks, so one epilogue follows 16 KCH MFMAs instead of 12-16.
+template <int METRIC, int KCH>
+__global__ __launch_bounds__(64, 1) void flat_thresh_big_kernel(const FlatThreshArgs a) {
+    __shared__ uint32_t lcnt[64];
+    __shared__ __align__(16) float ltau[64];
+    constexpr uint32_t CHB = 256u;        // bytes of one row's chunk (128 float16)
+    constexpr uint32_t PITCH = CHB + 16u; // conflict-free ds_read_b128 in the MFMA fragment layout
+    constexpr uint32_t ROWB = KCH * CHB;  // bytes of one float16 row
+    __shared__ __align__(16) unsigned char btile[2][32 * PITCH];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q0 = blockIdx.x * 64u;
+    const uint32_t slice = blockIdx.y;
+    const uint32_t dpad = a.dpad;
+    const uint32_t rows_per_slice = ((a.n + a.n_slices - 1) / a.n_slices + 31u) & ~31u;
+    const uint32_t x_lo = slice * rows_per_slice;
+    const uint32_t x_hi = (x_lo + rows_per_slice) < a.n ? (x_lo + rows_per_slice) : a.n;
+    const uint32_t xs = 32u * (a.tile_step ? a.tile_step : 1u);
+    const uint32_t x_first = ((x_lo + xs - 1u) / xs) * xs;
+    lcnt[lane] = 0u;
+    lds_order();
+    const uint32_t half = lane >> 5, col = lane & 31u;
+    const _Float16* qh = static_cast<const _Float16*>(a.qh);
+    if (x_lo < x_hi && x_first < x_hi) {
+        half8_t afr0[KCH * 8], afr1[KCH * 8];
+        {
+            const uint32_t r0 = q0 + col, r1 = q0 + 32u + col;
+#pragma unroll
+            for (int s2 = 0; s2 < KCH * 8; ++s2) {
+                half8_t z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = static_cast<_Float16>(0.0f);
+                afr0[s2] = r0 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r0) * dpad + 16 * s2 + 8u * half) : z;
+                afr1[s2] = r1 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r1) * dpad + 16 * s2 + 8u * half) : z;
+            }
+        }
+        {   // thresholds in the accumulator's domain (see flat_thresh_kernel); read from LDS in the epilogue: the registers hold A
+            const float t = q0 + lane < a.nq ? a.tau[static_cast<size_t>(q0 + lane) * a.tau_stride] : -__builtin_inff();
+            ltau[lane] = METRIC == M_L2 ? -0.5f * t : -t;
+        }
+        lds_order();
+        // a chunk of a tile: 32 rows x 256 B = 512 pieces of 16 B, 8 per lane; piece i * 64 + lane is piece (lane % 16) of row 4 i + lane / 16
+        const uint32_t prow = lane >> 4, pcol = lane & 15u;
+        const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(a.xh);
+        auto load_chunk = [&](uint32_t xt, uint32_t c, half8_t (&dst)[8]) {
+            const unsigned char* base = xbytes + static_cast<size_t>(xt) * ROWB + static_cast<size_t>(prow) * ROWB + c * CHB + pcol * 16u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const half8_t*>(base + static_cast<size_t>(i) * 4u * ROWB);
+        };
+        auto stage = [&](uint32_t buf, const half8_t (&src)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<half8_t*>(&btile[buf][(static_cast<uint32_t>(i) * 4u + prow) * PITCH + pcol * 16u]) = src[i];
+        };
+        auto fragment = [&](uint32_t buf, int s2) -> half8_t {
+            return *reinterpret_cast<const half8_t*>(&btile[buf][col * PITCH + 32u * static_cast<uint32_t>(s2) + 16u * half]);
+        };
+        const size_t stride_q = static_cast<size_t>(a.n_slices) * a.cap;
+        const size_t lane_base = (static_cast<size_t>(q0 + 4u * half) * a.n_slices + slice) * a.cap;
+        auto epilogue = [&](uint32_t x0, float xn, const float16v_t& acc0, const float16v_t& acc1) {
+            float rinv = 1.0f;
+            if constexpr (METRIC == M_COS) rinv = 1.0f / sqrtf(xn > 0.0f ? xn : 1.0f);
+            auto score = [&](float v) -> float {
+                if constexpr (METRIC == M_COS) return v * rinv;
+                else return v;
+            };
+            auto keyof = [&](float v) -> float {
+                if constexpr (METRIC == M_L2) return -2.0f * v;
+                else return -score(v);
+            };
+            unsigned long long gm[2][4];
+            unsigned long long anym = 0ull;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&ltau[qt * 32 + 8 * g4 + 4 * static_cast<int>(half)]);
+                    const bool h0 = score(qt == 0 ? acc0[4 * g4 + 0] : acc1[4 * g4 + 0]) >= t4.x;
+                    const bool h1 = score(qt == 0 ? acc0[4 * g4 + 1] : acc1[4 * g4 + 1]) >= t4.y;
+                    const bool h2 = score(qt == 0 ? acc0[4 * g4 + 2] : acc1[4 * g4 + 2]) >= t4.z;
+                    const bool h3 = score(qt == 0 ? acc0[4 * g4 + 3] : acc1[4 * g4 + 3]) >= t4.w;
+                    gm[qt][g4] = __ballot(h0) | __ballot(h1) | __ballot(h2) | __ballot(h3);
+                    anym |= gm[qt][g4];
+                }
+            }
+            if (anym == 0ull) return;
+            const uint32_t row = x0 + col;
+            const bool valid = row < x_hi;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (gm[qt][g4] == 0ull) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g4 + j;
+                        const float v = qt == 0 ? acc0[r] : acc1[r];
+                        const uint32_t cell = static_cast<uint32_t>(qt) * 32u + static_cast<uint32_t>(j + 8 * g4);
+                        const bool hit = valid && score(v) >= ltau[cell + 4u * half];
+                        if (hit) {
+                            const uint32_t pos = atomicAdd(&lcnt[cell + 4u * half], 1u);
+                            if (pos < a.cap) {
+                                const size_t o = lane_base + static_cast<size_t>(cell) * stride_q + pos;
+                                a.cand[o] = row;
+                                if (a.cand_keys != nullptr) a.cand_keys[o] = keyof(v);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        half8_t gnext[8];
+        load_chunk(x_first, 0u, gnext);
+        stage(0u, gnext);
+        uint32_t buf = 0;
+        float xn_next = 0.0f;
+        if constexpr (METRIC != M_IP) xn_next = a.xnorm2[x_first + col < a.n ? x_first + col : a.n - 1u];
+        for (uint32_t x0 = x_first; x0 < x_hi; x0 += xs) {
+            const float xn = xn_next;
+            const uint32_t x1 = x0 + xs < x_hi ? x0 + xs : x_first; // past the end: a harmless re-read of the first tile
+            if constexpr (METRIC != M_IP) xn_next = a.xnorm2[x1 + col < a.n ? x1 + col : a.n - 1u];
+            float16v_t acc0, acc1;
+            {
+                const float c0 = METRIC == M_L2 ? -0.5f * xn : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { acc0[i] = c0; acc1[i] = c0; }
+            }
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                // the next chunk (of this tile, or the first of the next) is in flight during this chunk's MFMAs
+                if (c + 1 < KCH) load_chunk(x0, static_cast<uint32_t>(c + 1), gnext);
+                else load_chunk(x1, 0u, gnext);
+                lds_order();
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    const half8_t bs = fragment(buf, s2);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr0[c * 8 + s2], bs, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr1[c * 8 + s2], bs, acc1, 0, 0, 0);
+                }
+                stage(buf ^ 1u, gnext);
+                lds_order();
+                buf ^= 1u;
+            }
+            epilogue(x0, xn, acc0, acc1);
+        }
+    }
+    lds_order();
+    if (q0 + lane < a.nq) a.cnt[static_cast<size_t>(q0 + lane) * a.n_slices + slice] = lcnt[lane];
+}
+
+// what the host needs to size the pass: which padded dimensions the threshold kernels take and how many waves per SIMD they run at
+bool flat_thresh_supports(uint32_t dpad) { return dpad <= 128u || (dpad % 128u == 0u && dpad <= 768u); }
+uint32_t flat_thresh_waves_per_simd(uint32_t dpad) { return dpad <= 128u ? 2u : 1u; }
+
 hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t stream) {
     const uint32_t ks = a.dpad >> 4;
-    if (ks < 1 || ks > 8) return hipErrorInvalidValue;
+    if (ks < 1 || !flat_thresh_supports(a.dpad)) return hipErrorInvalidValue;
     const dim3 grid((a.nq + 63) / 64, a.n_slices);
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(64), 0, stream, a);
         return hipGetLastError();
     };
+    if (ks > 8) {
+#define SVSX_THRESH_BIG(M)                                        \
+    switch (a.dpad / 128u) {                                      \
+        case 2: return go(flat_thresh_big_kernel<M, 2>);          \
+        case 3: return go(flat_thresh_big_kernel<M, 3>);          \
+        case 4: return go(flat_thresh_big_kernel<M, 4>);          \
+        case 5: return go(flat_thresh_big_kernel<M, 5>);          \
+        default: return go(flat_thresh_big_kernel<M, 6>);         \
+    }
+        switch (metric) {
+            case M_L2: SVSX_THRESH_BIG(M_L2)
+            case M_IP: SVSX_THRESH_BIG(M_IP)
+            case M_COS: SVSX_THRESH_BIG(M_COS)
+        }
+#undef SVSX_THRESH_BIG
+        return hipErrorInvalidValue;
+    }
 #define SVSX_THRESH_KERNEL flat_thresh_kernel
 #define SVSX_THRESH_CASE(M)                                   \
     switch (ks) {                                             \

@@ -37,6 +37,9 @@ struct FlatProofArgs {
 hipError_t launch_flat_certify(const FlatProofArgs& a, hipStream_t stream);
 // the overflow gate with the re-rank capacity of a kk-entry shortlist (max(2048, 32 kk) candidates per query)
 hipError_t launch_flat_gate_kk(const uint32_t* cnt, uint32_t nq, uint32_t n_slices, uint32_t cap, uint32_t kk, uint32_t* block_gate, hipStream_t stream);
+// which padded dimensions the threshold pipeline takes (d <= 128, or a multiple of 128 up to 768) and at how many waves per SIMD
+bool flat_thresh_supports(uint32_t dpad);
+uint32_t flat_thresh_waves_per_simd(uint32_t dpad);
 hipError_t launch_norm_range(const float* norm2, uint32_t n, uint32_t* d_max_min_bits, hipStream_t stream); // [0] = max bits (init 0), [1] = min bits (init ~0)
 
 } // namespace svsx

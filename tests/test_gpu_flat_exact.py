@@ -83,6 +83,22 @@ def test_rows_float16_cannot_hold(svs, oracle, metric):
     assert redone == 20
 
 
+@pytest.mark.parametrize("metric,d", [(L2, 256), (COS, 200), (IP, 768)])
+def test_clusters_in_more_than_128_dimensions(svs, oracle, metric, d):
+    """the chunked threshold kernel (128 < d <= 768) under the same attack: a cluster of 400 rows 1e-5 apart, queries aimed at it and elsewhere."""
+    rng = np.random.default_rng(31)
+    n = 66_000
+    x = deep_like(n, d, 12, seed=81, normalize=False)
+    x[500:900] = x[7] + np.float32(1e-5) * rng.standard_normal((400, d)).astype(np.float32)
+    q = np.concatenate([x[7:8] * np.float32(1.5 if metric == IP else 1.0) + np.float32(1e-3) * rng.standard_normal((1, d)).astype(np.float32),
+                        deep_like(40, d, 12, seed=82, normalize=False)]).astype(np.float32)
+    idx = svs.FlatIndex(x, _fn(svs, metric))
+    ids, dists, redone = _search_counted(idx, q, 10)
+    want_i, want_d = oracle.flat_search(metric, x, q, 10)
+    _assert_equal(ids, dists, want_i, want_d, (metric, d))
+    assert redone <= 4, redone
+
+
 @pytest.mark.parametrize("n", [3000, 70_000])
 def test_queries_float16_cannot_hold(svs, oracle, n):
     """a query component beyond the float16 range turns the query's shadow into +-inf and every float16 key into NaN / inf: nothing can be

@@ -576,10 +576,11 @@ def test_malformed_graph_is_rejected(svs):
         svs.VamanaIndex(g, x, svs.DistanceL2(), [0])
 
 
-@pytest.mark.parametrize("metric,d", [(L2, 96), (IP, 100), (COS, 32), (L2, 128)])
+@pytest.mark.parametrize("metric,d", [(L2, 96), (IP, 100), (COS, 32), (L2, 128), (L2, 160), (IP, 256), (COS, 300), (L2, 768), (COS, 700)])
 def test_flat_search_threshold_pipeline(svs, oracle, metric, d):
-    """n >= 65536 and d <= 128 take the sample-threshold-append pipeline (svsx_flat.hip stage 1b / 3b): same answers as the
-    oracle's exhaustive search, ties by lower id."""
+    """n >= 65536 and d <= 768 take the sample-threshold-append pipeline (svsx_flat.hip stage 1b / 3b; beyond d = 128 the kernel that takes the
+    dimension in chunks of 128, rows of the float16 shadow padded to a multiple of 128): same answers as the oracle's exhaustive search,
+    ties by lower id."""
     fn = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}[metric]
     n, nq = 70_000, 100
     x = deep_like(n, d, 12, seed=31, normalize=metric == L2)

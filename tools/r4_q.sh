@@ -1,8 +1,6 @@
 #!/bin/bash
-R=$PWD; O=$R/gpurun_out/r04h3; mkdir -p $O; rm -rf $O/*
-for V in base h3c base h3c; do
-  if [ $V = base ]; then unset SVSX_LIB; else export SVSX_LIB=$R/variants/$V/libsvsx.so; fi
-  echo "== $V" >> $O/host_rate.jsonl
-  timeout 300 python tools/host_rate.py --windows 128,23 >> $O/host_rate.jsonl 2>/dev/null
-done
-cut -c1-230 $O/host_rate.jsonl
+R=$PWD; O=$R/gpurun_out/r04big; mkdir -p $O; rm -rf $O/*
+timeout 900 python -m pytest tests/test_gpu_flat_exact.py tests/test_gpu_parity.py tests/test_gpu_configs.py -q -k "flat" > $O/flat_tests.log 2>&1; echo "flat tests rc=$?" >> $O/out.txt
+timeout 200 python tools/flat_check.py 200000 768 4096 100 l2 >> $O/out.txt 2>/dev/null
+timeout 200 python tools/flat_check.py 2000000 768 4096 10 cos >> $O/out.txt 2>/dev/null
+tail -4 $O/flat_tests.log; cat $O/out.txt
