@@ -598,7 +598,7 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
 // a B tile arrives chunk by chunk -- 32 rows x 256 B through registers into LDS, fragments re-read from there, like the d <= 128 kernel
 // with KS = 8 -- and the accumulators run across the chunks, so one epilogue follows 16 KCH MFMAs instead of 12-16.
 template <int METRIC, int KCH>
-__global__ __launch_bounds__(64, 1) void flat_thresh_big_kernel(const FlatThreshArgs a) {
+__global__ __launch_bounds__(64, KCH <= 2 ? 2 : 1) void flat_thresh_big_kernel(const FlatThreshArgs a) {
     __shared__ uint32_t lcnt[64];
     __shared__ __align__(16) float ltau[64];
     constexpr uint32_t CHB = 256u;        // bytes of one row's chunk (128 float16)
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(64, 1) void flat_thresh_big_kernel(const FlatThresh
 
 // what the host needs to size the pass: which padded dimensions the threshold kernels take and how many waves per SIMD they run at
 bool flat_thresh_supports(uint32_t dpad) { return dpad <= 128u || (dpad % 128u == 0u && dpad <= 768u); }
-uint32_t flat_thresh_waves_per_simd(uint32_t dpad) { return dpad <= 128u ? 2u : 1u; }
+uint32_t flat_thresh_waves_per_simd(uint32_t dpad) { return dpad <= 256u ? 2u : 1u; } // two chunks of A fragments still leave room for two waves
 
 hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t stream) {
     const uint32_t ks = a.dpad >> 4;
