@@ -27,7 +27,7 @@ def shadow_keys(metric, q, x):
 def proof_bound(metric, q, tau, xmax2, xmin2, d, q_star=None):
     """Best reference distance a row with key >= tau can have (L2: a lower bound of the squared distance; IP / cosine: an upper bound of the
     similarity), or None where the kernel refuses to prove anything.  float64, same constants as flat_certify_kernel."""
-    dpad = (d + 15) & ~15
+    dpad = (d + 127) & ~127 if 128 < d <= 768 else (d + 15) & ~15  # the shadow's row padding (svsx_api.hip)
     nq = float(np.sqrt((q.astype(np.float64) ** 2).sum()))
     dqs = 0.0 if q_star is None else float(np.sqrt(((q_star.astype(np.float64) - q.astype(np.float64)) ** 2).sum()))
     ab = np.sqrt(dpad) * TWO25
@@ -63,6 +63,7 @@ def data_sets():
     yield "cluster below float16 resolution", x, (x[:8] + np.float32(1e-3) * rng.standard_normal((8, 48))).astype(np.float32)
     x = rng.standard_normal((2000, 40)).astype(np.float32) * np.exp(rng.uniform(-6, 6, (2000, 1))).astype(np.float32)
     yield "row norms over five decades", x, rng.standard_normal((8, 40)).astype(np.float32)
+    yield "200 dimensions (shadow padded to 256)", rng.standard_normal((2500, 200)).astype(np.float32), rng.standard_normal((8, 200)).astype(np.float32)
     yield "int8-valued rows and queries", rng.integers(-128, 128, (3000, 100)).astype(np.float32), rng.integers(-128, 128, (8, 100)).astype(np.float32)
 
 
