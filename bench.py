@@ -303,6 +303,17 @@ def build_or_load_graph(svs, x, n, d, R, local_rank, cache, distance=None, alpha
     return graph, entry, time.time() - t0
 
 
+def sharded_shard_size(args, world, total_hbm):
+    """Vectors per shard of the `sharded_search` point: --c5-n if given, else BASELINE config 5's 12 500 000 at EVERY N (the
+    1 -> N curve must be one workload) -- 8 / N shards per GPU, with their inline records where those fit (N >= 2: 37 GB per shard), with
+    128-byte code rows where they do not (N = 1: all eight shards on one GPU are 77 GB + 12.8 GB).  1 000 000 only if even that does not fit."""
+    if args.c5_n:
+        return args.c5_n
+    per = max(1, 8 // world)
+    floor_bytes = per * 12_500_000 * (96 * 4 + 64 * 4 + 128 + 64) * 1.15  # vectors, graph, code rows, slack
+    return 12_500_000 if floor_bytes < 0.8 * total_hbm else 1_000_000
+
+
 def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reuse_shard0, steps, warmup):
     """SURVEY 8(e) as a measurement inside the default line: a FIXED set of 8 shards of --c5-n vectors (contiguous id ranges, global
     ids), 8 / N per GPU, every rank passes the same query batch to svsx_sharded_search_device: per-shard searches, local merge, ONE
@@ -321,7 +332,12 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
     # --c5-n 0 (default): BASELINE config 5's own shard, 12 500 000 vectors, whenever the 8 / N shards of a GPU fit its HBM with their inline
     # records (N >= 2: 37 GB per shard), else -- one GPU holding all eight -- 1 000 000 vectors per shard so that the default N = 1 line stays
     # within minutes (the 100 M index on one GPU is `--config c5`: profiles/r03_bench_c5_100M_8shards_1gpu.json)
-    n5 = args.c5_n or (12_500_000 if world >= 2 else 1_000_000)
+    total_hbm = torch.cuda.get_device_properties(device).total_memory
+    n5 = sharded_shard_size(args, world, total_hbm)
+    gs5 = (R + 15) // 16 * 16
+    mode5 = args.bound_codes
+    if mode5 == 2 and per * n5 * (d * 4 + gs5 * 4 + gs5 * 36 + 64) > 0.75 * total_hbm - torch.cuda.memory_allocated(device):
+        mode5 = 1  # the inline records of this GPU's shards do not fit next to their vectors: 128-byte code rows (the same choice `--config c5` makes)
     t0 = time.time()
     keep, indexes = [], []
     for s_ in range(per):
@@ -333,8 +349,8 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
             graph, entry, _ = build_or_load_graph(svs, x, n5, d, R, local_rank, "")
             d_entry = torch.tensor([entry], dtype=torch.int32, device=device)
             index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n5, d, np.float32, device=local_rank, id_offset=sid * n5)
-            if args.bound_codes:
-                index.build_bound_codes(args.bound_codes)
+            if mode5:
+                index.build_bound_codes(mode5)
             sh = dict(x=x, graph=graph, entry=entry, d_entry=d_entry, index=index, sid=sid, n=n5)
         keep.append(sh)
         indexes.append(sh["index"])
@@ -382,11 +398,11 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
     info = ns.info()
     res = {"shards_total": total, "shards_per_gpu": per, "vectors_per_shard": n5, "n_gpus": world, "batch": nq, "window_per_shard": args.window,
            "merged_answers_per_s": nq * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "steps": steps, "recall_at_10": recall_at(gt, out_i, k),
-           "rccl_communicator": info["communicator"], "rccl_ranks": info["world"], "build_seconds_this_rank": t_build,
+           "rccl_communicator": info["communicator"], "rccl_ranks": info["world"], "build_seconds_this_rank": t_build, "bound_codes": mode5,
            "path": "svsx_sharded_search_device (libsvsx: per-shard search -> local merge -> ONE ncclAllGather -> world-way merge, one stream)",
            "scaling": "strong (the set of 8 shards is fixed as N grows)",
-           "shard_size_note": ("BASELINE config 5's shard size" if n5 == 12_500_000 else
-                               f"{n5} vectors per shard: all eight shards of a one-GPU run with 12.5 M vectors take 8 x 29 s to build (that run is --config c5)")}
+           "shard_size_note": ("BASELINE config 5's shard size at every N (inline records where the GPU's shards fit with them, 128-byte code rows where not: bound_codes)"
+                               if n5 == 12_500_000 else f"{n5} vectors per shard (--c5-n, or 12.5 M-vector shards do not fit this GPU)")}
     ns.close()
     return res
 
@@ -514,7 +530,8 @@ def main():
     ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
     ap.add_argument("--bound-codes", type=int, default=2, help="result-neutral lower-bound rejection: 2 graph-inline records (default), 1 128-B code rows, 0 off")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph(s) here (lets a profiler run skip the build)")
-    ap.add_argument("--c5-n", type=int, default=0, help="vectors per shard of the sharded_c5 point (0 = 12 500 000 at N >= 2, 1 000 000 at N = 1; -1 = skip the point)")
+    ap.add_argument("--c5-n", type=int, default=0, help="vectors per shard of the sharded_search point (0 = BASELINE config 5's 12 500 000 at every N; -1 = skip the point)")
+    ap.add_argument("--sharded-timeout", type=float, default=0.0, help="watchdog of the sharded_search point in seconds (0 = scaled with shards per GPU x shard size); when it fires the line is printed with sharded_search.failed and the run exits 3")
     ap.add_argument("--c4-n", type=int, default=10_000_000, help="vectors of the config-4 point (10 M = BASELINE config 4; falls back to 2 M when time or memory is short; 0 = skip)")
     ap.add_argument("--budget-s", type=float, default=1500.0, help="wall-clock budget of the whole run: the long extras (config 4 at 10 M) are sized against what is left")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational points (sharded_c5, other configs, 4x batch)")
@@ -729,50 +746,22 @@ def main():
                                "4 096 queries start as soon as their bytes have crossed PCIe, the rest is copied while they run (DESIGN.md section 1, "
                                "profiles/r03_notes.md section 5, profiles/r04_notes.md section 6)")
 
-    # ---- the sharded search of SURVEY 8(e), measured in the same run (every rank takes part) -----------------------------------------
-    sharded = None
-    if not c5 and not args.no_extras and args.c5_n >= 0:
-        import threading
-
-        def give_up():  # a collective that never returns must not cost the headline line
-            if rank == 0:
-                v = world * nq * args.steps / elapsed
-                _emit(json.dumps({"metric": "QPS at recall@10>=0.9 (batch=10k); achieved HBM GB/s vs roofline", "value": v, "unit": "queries/s", "n_gpus": world,
-                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-                                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                                  "config": {"workload": f"deep-1M-like d=96 float32 L2, batch={nq}, search_window={args.window}, k=10", "recall_at_10": recall,
-                                             "sharded_c5": {"error": "timed out"}, "note": "emergency line: the sharded extra did not return"}}))
-            os._exit(0)
-
-        dog = threading.Timer(240.0, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            sh0 = dict(shards[0], n=n)
-            sharded = sharded_c5_point(args, svs, q if rank == 0 else deep_like_device(nq, d, 24, seed=2, device=device), k, R, d, rank, world, local_rank, device,
-                                       sh0 if rank == 0 else None, max(3, args.steps // 2), args.warmup)
-        except Exception as e:  # informational: never fail the line over it
-            sharded = {"error": f"{type(e).__name__}: {e}"}
-            log(f"[bench] rank {rank}: sharded_c5 point failed: {e}")
-        dog.cancel()
-    if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
-        return
 
     # practical roof: device-to-device copy bandwidth on this box (read + write bytes / time)
-    cp_src = torch.empty(1 << 28, dtype=torch.float32, device=device)  # 1 GiB
-    cp_dst = torch.empty_like(cp_src)
-    cp_dst.copy_(cp_src)
-    torch.cuda.synchronize()
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c0.record()
-    for _ in range(5):
+    copy_gbs = float("nan")
+    if rank == 0:
+        cp_src = torch.empty(1 << 28, dtype=torch.float32, device=device)  # 1 GiB
+        cp_dst = torch.empty_like(cp_src)
         cp_dst.copy_(cp_src)
-    c1.record()
-    torch.cuda.synchronize()
-    copy_gbs = 5 * 2 * cp_src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-    del cp_src, cp_dst
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            cp_dst.copy_(cp_src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * cp_src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del cp_src, cp_dst
 
     ms_per_step = 1e3 * elapsed / args.steps
     merged_qps = nq * args.steps / elapsed
@@ -862,6 +851,45 @@ def main():
                     "Random 128-byte gathers top out at ~49 G lines/s = 6.3 TB/s on this GPU (tools/ubench/gather_bench).",
         },
     }
+
+    # ---- the sharded search of SURVEY 8(e), measured in the same run (every rank takes part).  The line above is complete without it, so a
+    # collective that never returns costs the run its exit code, not its headline: the watchdog prints the line with
+    # sharded_search.failed = true and leaves with status 3 (ADVICE r3 / VERDICT r4: no silent rc 0).
+    sharded = None
+    if not c5 and not args.no_extras and args.c5_n >= 0:
+        import threading
+
+        n5_plan, per_plan = sharded_shard_size(args, world, total_hbm), max(1, 8 // world)
+        # builds dominate: ~29 s per 12.5 M-vector shard + generation, records / code rows, exact ground truth; comm set-up and the searches on top
+        dog_s = args.sharded_timeout or (240.0 + 75.0 * per_plan * n5_plan / 12_500_000)
+
+        def give_up():
+            if rank == 0:
+                result["config"]["sharded_c5"] = {"error": f"timed out after {dog_s:.0f} s", "vectors_per_shard": n5_plan, "shards_per_gpu": per_plan}
+                result["sharded_search"] = {"metric": "merged answers per second over a FIXED set of 8 database shards (SURVEY 8e; strong scaling in N)", "value": None,
+                                            "unit": "queries/s", "n_gpus": world, "vectors_per_shard": n5_plan, "failed": True,
+                                            "error": f"the sharded point did not return within {dog_s:.0f} s (watchdog); every other field of this line was measured before it started"}
+                result["config"]["note"] = "emergency line: printed by the watchdog of the sharded point; informational extras (other configs, CPU leg) were not reached"
+                _emit(json.dumps(result))
+            os._exit(3)
+
+        dog = threading.Timer(dog_s, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sh0 = dict(shards[0], n=n)
+            sharded = sharded_c5_point(args, svs, q if rank == 0 else deep_like_device(nq, d, 24, seed=2, device=device), k, R, d, rank, world, local_rank, device,
+                                       sh0 if rank == 0 else None, max(3, args.steps // 2), args.warmup)
+        except Exception as e:  # recorded with failed = true; at N > 1 the run then exits 3 after the line
+            sharded = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[bench] rank {rank}: sharded_c5 point failed: {e}")
+        dog.cancel()
+    if rank != 0:
+        if use_dist:
+            dist.destroy_process_group()
+        if world > 1 and isinstance(sharded, dict) and "error" in sharded:
+            sys.exit(3)
+        return
 
     if sharded is not None:
         result["config"]["sharded_c5"] = sharded

@@ -32,6 +32,10 @@
 #define SVSX_CODE_BATCH 2
 #endif
 
+// SVSX_EARLY_BLOCK (default 0; -DSVSX_EARLY_BLOCK=1 for A/B builds): see "Next block, requested early" in search_kernel
+#ifndef SVSX_EARLY_BLOCK
+#define SVSX_EARLY_BLOCK 0
+#endif
 // SVSX_MERGE_V2 (default 0): 1 = lane-parallel merge insert (wave_merge_insert2) for A/B builds.  Measured (profiles/r03_notes.md): its LDS
 // round trips cost what the scalar loop's VALU <-> SALU hand-overs cost (config 2: 1.084 vs 1.070 ms), so the loop form stays.
 #ifndef SVSX_MERGE_V2
@@ -45,10 +49,10 @@
 namespace svsx {
 
 // Occupancy floors (amdgpu_waves_per_eu) of the inline-record kernel families: the register allocator otherwise settles some instantiations
-// just over a VGPR bracket, and a resident wave lost costs more than the few registers buy.  Chosen per family so that no instantiation
-// spills (tools/kernel_regs.py); 0 = no floor.  (Round 3's "early block" experiment, for which the floors were first introduced, lives in
-// experiments/r3_early_block/.)
-template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BIG> constexpr int occupancy_floor() {
+// just over a VGPR bracket (123 -> 175 VGPRs on the d = 768 int8 kernel once the early-block state was added), and a resident wave lost
+// costs more than the few registers buy.  Chosen per family so that no instantiation spills (tools/kernel_regs.py); 0 = no floor.  The
+// same families can carry the early block (SVSX_EARLY_BLOCK, off by default -- measured: profiles/r03_notes.md).
+template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BIG> constexpr int early_block_floor() {
     if (GENERAL || CODES < 2) return 0;
     if (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         // configs 2, 3, 5 (static 96 / 128, 32-byte records): <= 80 VGPRs -- the scalar registers allow 6 waves; float16 rows of 96 need 88
@@ -73,7 +77,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
 #elif defined(SVSX_WAVES_PER_EU)
 #define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(SVSX_WAVES_PER_EU)))
 #else
-#define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(occupancy_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() > 0 ? occupancy_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() : 1)))
+#define SVSX_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(early_block_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() > 0 ? early_block_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() : 1)))
 #endif
 
 // BIG: search buffers of 129 .. 512 (BIG = 1) and 513 .. 1024 entries (BIG = 2) get their own instantiations, so that the 4- / 8- /
@@ -153,8 +157,6 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     if constexpr (!GENERAL) {
         if (a.cancel != nullptr && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return; // extensions.h:575-578
     }
-    // inline records: the bits of a buffer word that name the row (below the degree class, see the main loop)
-    [[maybe_unused]] const uint32_t idmask = (FAT && a.fat_degshift != 0u) ? ((1u << a.fat_degshift) - 1u) : kIdMask;
     const uint32_t fmask = a.filter_entries - 1u;
     const uint32_t fshift = static_cast<uint32_t>(__builtin_ctz(a.filter_entries | 0x80000000u));
     for (uint32_t i = lane; i < filt_bytes / 4u; i += 64) reinterpret_cast<uint32_t*>(filt)[i] = 0xFFFFFFFFu;
@@ -179,6 +181,23 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     int code_qq = 0;
     float code_eq = 0.0f;
     uint32_t n_code_rej = 0;
+    // Early block (inline records only).  The node expanded NEXT is the buffer's best unvisited entry unless one of this expansion's
+    // candidates lands in front of it.  The record bound that is taken against `worst` anyway is taken a second time against that entry's
+    // distance: when every candidate that goes on to the exact path is PROVEN farther (strictly -- equal distances insert behind), the next
+    // expansion is already decided, and the 18 lines of its adjacency block are requested now, while this expansion's rows are in flight --
+    // the two dependent memory round trips of an expansion overlap, at no extra traffic (the block is always used).  A hint only: the block
+    // is loaded again (from L2) by the next iteration, so results cannot depend on it.
+    constexpr bool EARLY = SVSX_EARLY_BLOCK != 0 && early_block_floor<DT, METRIC, QMODE, DS, GENERAL, CODES, BIG>() > 0;
+    [[maybe_unused]] uint32_t early_sink = 0u, early_sink2 = 0u;
+    // static-dimension kernels with 32-byte records have the registers to KEEP the early block (id + 2 planes per lane): the next iteration
+    // then starts on data that is already there instead of an L2 round trip
+    constexpr bool EARLY_KEEP = EARLY && RW == 2 && DS == 96 && BIG == 0 && DT == DT_F32; // d = 128 and float16 rows would spill
+    [[maybe_unused]] uint32_t kept_node = kInvalidId, kept_nid = kInvalidId;
+    [[maybe_unused]] uint4 kept_rec[RW];
+    if constexpr (EARLY_KEEP) {
+#pragma unroll
+        for (int p = 0; p < RW; ++p) kept_rec[p] = make_uint4(0u, 0u, 0u, 0u);
+    }
 #if defined(SVSX_DIAG) && SVSX_DIAG == 2
     // phase profile of an expansion (tools/diag_phases.py): shader-clock stamps at 0 loop top, 1 node known, 2 adjacency block arrived, 3 bound +
     // filter + compaction done, 4 distances of a pass known (row wait + arithmetic), 5 inserts done; stats words 1..5 = cycles between them
@@ -196,7 +215,9 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
 #define SVSX_PHASE_STAMP(i)
 #endif
 #ifdef SVSX_DIAG
-    // diagnostic builds only (tools/build_variant.sh diag -DSVSX_DIAG=1; tools/timeline.py): stats words 4 / 5 = wall_clock64 (100 MHz) at wave start / end
+    // diagnostic builds only (tools/build_variant.sh diag -DSVSX_DIAG=1; tools/timeline.py): stats words 3 / 4 / 5 = expansions whose next
+    // block was requested early, wall_clock64 (100 MHz) at wave start / end
+    uint32_t diag_early = 0u, diag_have = 0u;
     const uint32_t diag_t0 = static_cast<uint32_t>(wall_clock64());
 #endif
     if constexpr (CODES == 1) {
@@ -343,8 +364,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     uint32_t n_early = 0;
     // distance of the candidate whose id each lane-group holds; every lane of the wave participates.
     // `thr`: +inf while the buffer is not full, else worst * (1 + 4e-5).
-    auto group_distance = [&](uint32_t cid, bool active, float thr, auto&& hook) -> float {
-        const unsigned char* row = data + static_cast<size_t>(active ? cid : 0u) * static_cast<uint32_t>(a.row_bytes); // one v_mad_u64_u32: a row is shorter than 4 GB
+    auto group_distance = [&](uint32_t cid, bool active, float thr) -> float {
+        const unsigned char* row = data + static_cast<size_t>(active ? cid : 0u) * a.row_bytes;
         float fmain = 0.0f, fnrm = 0.0f;
         int ab = 0, bb = 0;
         if constexpr (TWO_PHASE && CODES == 0) { // survivors of the bound codes are close to the worst entry: fetch whole rows
@@ -366,21 +387,13 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             // CosineSimilarityCompressed (scalar.h:155-195): the row's own norm does not depend on the query -- svsx_index_create ran the same
             // accumulator chain once per row and stored its square root (sq_row_norm_kernel), so only the dot product is accumulated here:
             // a sixth fewer vector instructions per element and no correctly rounded sqrt per candidate; same bits.
-            if constexpr (GENERAL) {
-                // indexes whose row norms were dropped (svsx_index_drop_row_norms) are served by this variant only: the norm chain runs per
-                // candidate, as the reference does it (scalar.h:175-184)
-                if (a.sq_row_norm == nullptr) {
-                    float_row_distance_bc<DT, M_COS, DS, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
-                    return finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
-                }
-            }
             const float bn = a.sq_row_norm[active ? cid : 0u]; // requested with the row
             float_row_distance_bc<DT, M_IP, DS, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
             return fmain / (bn * fx.norm); // cosine.h:334-335
         } else if constexpr (B8) {
             float_row_distance_bc<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         } else {
-            float_row_distance<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm, 0.0f, nullptr, hook);
+            float_row_distance<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         }
         return finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
     };
@@ -397,7 +410,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             const uint32_t ci = base + grp;
             const bool act = ci < a.n_entry;
             const uint32_t cid = act ? a.entry[ci] : 0u;
-            const float dist = group_distance(cid, act, __builtin_inff(), NoHook{});
+            const float dist = group_distance(cid, act, __builtin_inff());
             unsigned long long m = __ballot(act && sub == 0);
             while (m != 0ull) {
                 const int bl = __builtin_ctzll(m);
@@ -454,6 +467,40 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     bool full = buf.size == buf.capacity;
     float worst = (full && buf.capacity > 0u) ? __uint_as_float(buf.e[buf.capacity - 1].x) : 0.0f;
 
+    // Next block, requested early (inline records, single-chunk rows).  Once the distances of an expansion's LAST pass are known, the node
+    // expanded next is decided -- the best new candidate if it is strictly better than the buffer's next unvisited entry (equal distances
+    // insert behind, search_buffer.h:353-389), else that entry -- although the buffer has not been updated yet.  Its adjacency block is
+    // requested at that moment, so the HBM round trip runs under the merge insert and the `next()` scan instead of after them.  A hint
+    // only: the loop top checks `kept_node == node` (a duplicate that the insert drops can make the prediction wrong) and loads the block
+    // itself otherwise, so results cannot depend on it.  Kernels without the registers to keep the block touch its lines into L2 instead.
+    [[maybe_unused]] auto request_block = [&](uint32_t next_node) {
+#ifdef SVSX_DIAG
+        ++diag_early;
+#endif
+        if constexpr (EARLY_KEEP) { // gstride <= 64 here: one chunk, laid out [ids | plane 0 | plane 1]
+            const uint32_t* kids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(next_node) * a.fat_stride);
+            const uint4* kplanes = reinterpret_cast<const uint4*>(kids + a.gstride);
+            kept_nid = kInvalidId;
+#pragma unroll
+            for (int p = 0; p < RW; ++p) kept_rec[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < a.gstride) {
+                kept_nid = kids[lane];
+#pragma unroll
+                for (int p = 0; p < RW; ++p) kept_rec[p] = kplanes[static_cast<uint32_t>(p) * a.gstride + lane];
+            }
+            kept_node = next_node;
+        } else if constexpr (EARLY) {
+            const unsigned char* nb = a.fat + static_cast<size_t>(next_node) * a.fat_stride;
+            // one line per lane: a block of <= 64 slots is at most 64 * (4 + 16 RW) bytes = 18 / 34 / 66 lines
+            const uint32_t off = lane * 128u;
+            // plain assignments: any arithmetic on the loaded word here would make the compiler wait for it on the spot
+            if (off < a.fat_stride) early_sink = *reinterpret_cast<const uint32_t*>(nb + off);
+            if constexpr (RW == 8) {
+                if (off + 8192u < a.fat_stride) early_sink2 = *reinterpret_cast<const uint32_t*>(nb + off + 8192u);
+            }
+        }
+    };
+
     // ---- main loop (greedy_search.h:153-202) --------------------------------------------------------------------
     int cancel_seen = 0;
 #if defined(SVSX_DIAG) && SVSX_DIAG == 3
@@ -466,17 +513,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         }
         SVSX_PHASE_STAMP(0);
         float node_dist;
-        const uint32_t node_word = wave_next(buf, lane, node_dist);
-        // Inline-record blocks of at most 2^26 nodes carry, above each neighbour id, ceil(degree of that neighbour / 8) (svsx_codes.hip
-        // fat_build_kernel): the id travels through the candidate buffer with it, so when the node is expanded the number of 8-slot groups
-        // of its block that hold a neighbour is known BEFORE the block is requested, and the lines behind them are never touched
-        // (0 = unknown: entry points; the whole block is read).  Mean degree 62 of 64 slots still leaves 14 % of the block lines empty.
-        const uint32_t node = FAT ? (node_word & idmask) : node_word;
-        [[maybe_unused]] uint32_t slot_limit = a.gstride;
-        if constexpr (FAT) {
-            const uint32_t cls = a.fat_degshift != 0u ? (node_word >> a.fat_degshift) : 0u; // bit 31 (visited) is already off
-            if (cls != 0u && cls * 8u < slot_limit) slot_limit = cls * 8u;
-        }
+        const uint32_t node = wave_next(buf, lane, node_dist);
         SVSX_PHASE_USE(node);
         SVSX_PHASE_STAMP(1);
         if (a.history_ids != nullptr && lane == 0 && n_exp < a.history_cap) {
@@ -484,26 +521,48 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             if (a.history_dists != nullptr) a.history_dists[static_cast<size_t>(qi) * a.history_cap + n_exp] = node_dist;
         }
         ++n_exp;
+        [[maybe_unused]] uint32_t nx_id = kInvalidId;
+        [[maybe_unused]] float nx_d = 0.0f;
         const uint32_t* grow = a.graph + static_cast<size_t>(node) * a.gstride;
-        for (uint32_t gbase = 0; gbase < (FAT ? slot_limit : a.gstride); gbase += 64) {
+        for (uint32_t gbase = 0; gbase < a.gstride; gbase += 64) {
             uint32_t nid = kInvalidId;
             [[maybe_unused]] uint4 rec[RW];
+#pragma unroll
+            for (int p = 0; p < RW; ++p) rec[p] = make_uint4(0u, 0u, 0u, 0u);
             if constexpr (FAT) {
-                // one contiguous block per chunk: [ids | plane 0 | ... | plane RW-1]; lane c owns neighbour c and its record.  Lanes beyond
-                // the node's last group of 8 slots repeat that group's last lane (same lines: no request of their own, no exec mask, no
-                // zero fill) and are turned into empty slots afterwards.
+                // one contiguous block per chunk: [ids | plane 0 | ... | plane RW-1]; lane c owns neighbour c and its record
                 const uint32_t cs = (a.gstride - gbase) < 64u ? (a.gstride - gbase) : 64u;
-                const uint32_t lim = (slot_limit - gbase) < cs ? (slot_limit - gbase) : cs; // >= 1
                 const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(gbase) * (4u + 16u * RW));
                 const uint4* planes = reinterpret_cast<const uint4*>(fids + cs);
-                const uint32_t ll = opaque_u(lane); // lane-derived offsets are recomputed here, not kept across the distance pass (opaque_u)
-                const uint32_t li = ll < lim ? ll : lim - 1u;
-                nid = fids[li];
+                bool have = false;
+                if constexpr (EARLY_KEEP) {
+                    have = kept_node == node; // the same read-only bytes, requested one expansion ago
+#ifdef SVSX_DIAG
+                    diag_have += have ? 1u : 0u;
+#endif
+                    if (have) {
+                        nid = kept_nid;
 #pragma unroll
-                for (int p = 0; p < RW; ++p) rec[p] = planes[static_cast<uint32_t>(p) * cs + li];
-                nid = ll < lim ? nid : kInvalidId;
+                        for (int p = 0; p < RW; ++p) rec[p] = kept_rec[p];
+                    }
+                    kept_node = kInvalidId;
+                }
+                if (!have && lane < cs) {
+                    nid = fids[lane];
+#pragma unroll
+                    for (int p = 0; p < RW; ++p) rec[p] = planes[static_cast<uint32_t>(p) * cs + lane];
+                }
             } else {
                 if (gbase + lane < a.gstride) nid = grow[gbase + lane];
+            }
+            if constexpr (EARLY) { // after the block loads have been issued: the LDS round trip hides behind them
+                const uint32_t upper = buf.size < buf.window ? buf.size : buf.window;
+                if (buf.best_unvisited < upper && a.gstride <= 64u && !nan_seen) { // wave_next has moved best_unvisited to the following entry
+                    const uint2 en = buf.e[buf.best_unvisited];
+                    // the same value in every lane: say so, the block address then is scalar
+                    nx_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(en.y & kIdMask)));
+                    nx_d = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(en.x))));
+                }
             }
             const uint32_t deg_here = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
             SVSX_PHASE_USE(deg_here);
@@ -516,18 +575,12 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 // bound rejected is rejected again by the bound (worst only improves) at no memory cost, so it need not be
                 // remembered -- the same table then covers the whole query almost without evictions.  A hit = this id went
                 // through the exact path earlier in this query, re-inserting it would be a no-op.
-                const uint32_t fh = nid & fmask, ftag = (nid & idmask) >> fshift; // 16-bit tags only (the host never asks for 8-bit tags with inline records); the hash bits lie below the degree class
+                const uint32_t fh = nid & fmask, ftag = nid >> fshift; // 16-bit tags only (the host never asks for 8-bit tags with inline records)
                 const bool use_filter = a.filter_entries != 0u && !nan_seen; // with a NaN in the buffer a repeated insert is no longer a no-op
-                // every lane reads its slot (an empty adjacency slot hashes to the table's last entry): no exec-masked branch in front of the
-                // bound, whose arithmetic then runs under the LDS round trip instead of after it
-                // (also when the filter is off: the table then has no entries and slot 0 aliases the compaction scratch -- the value is ignored)
-                const uint32_t fseen = static_cast<uint32_t>(filt[a.filter_entries != 0u ? fh : 0u]);
-                __builtin_amdgcn_sched_barrier(0); // the read stays in front of the bound's arithmetic (the scheduler otherwise sinks it to its use)
-                {
+                if (use_filter && keep) keep = static_cast<uint32_t>(filt[fh]) != ftag;
+                if (full) {
                     // bound of every candidate of this chunk, lane-parallel (svsx_codes.hip has the geometry).  `worst` can only
-                    // improve while this expansion's survivors are inserted, so a bound taken against it stays valid.  Evaluated
-                    // whether or not the buffer is full (`rej` counts only when it is): without a branch the filter's LDS read above and
-                    // the second record plane are awaited under this arithmetic, not in front of it.
+                    // improve while this expansion's survivors are inserted, so a bound taken against it stays valid.
                     bool rej;
                     constexpr int NW = RW * 4;  // words per record; the last one holds float16 fields
                     auto recw = [&](int w) -> uint32_t {
@@ -590,8 +643,6 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         }
                         rej = ub < worst; // false whenever anything is NaN / inf
                     }
-                    rej = rej && full;
-                    keep = keep && !(use_filter && fseen == ftag);
                     const uint32_t nrej = __popcll(__ballot(keep && rej));
                     n_code_rej += nrej;
                     n_eval += nrej;
@@ -600,12 +651,16 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 if (use_filter && keep) filt[fh] = static_cast<uint16_t>(ftag);
                 const unsigned long long km = __ballot(keep);
                 cnt = __popcll(km);
-                const uint32_t rank = prefix_count(km);
+                const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
                 lds_order();
                 if (keep) compact[rank] = nid;
                 lds_order();
-                // the passes below read compact[pass base + group] themselves: one LDS round trip per pass instead of a read-back here
-                // plus a cross-lane permute per pass
+                nid = lane < cnt ? compact[lane] : kInvalidId;
+                lds_order();
+                if constexpr (EARLY) {
+                    // nothing went on to the exact path: the buffer stays as it is and the next expansion is its next unvisited entry
+                    if (cnt == 0u && nx_id != kInvalidId) request_block(nx_id);
+                }
             } else if (a.filter_entries != 0u && !nan_seen) { // with a NaN in the buffer a repeated insert is no longer a no-op: filter off
                 // emplace_visited (greedy_search.h:191-193): drop ids already evaluated, keep adjacency order
                 bool keep = nid != kInvalidId;
@@ -622,7 +677,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 }
                 const unsigned long long km = __ballot(keep);
                 cnt = __popcll(km);
-                const uint32_t rank = prefix_count(km);
+                const uint32_t rank = __popcll(km & ((1ull << lane) - 1ull));
                 lds_order();
                 if (keep) compact[rank] = nid;
                 lds_order();
@@ -687,7 +742,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         const bool rej = isum > t * t * 1.00001f; // false for NaN / inf thresholds
                         const bool surv = act && !rej && sub == 0;
                         const unsigned long long sm = __ballot(surv);
-                        if (surv) compact[nsurv + prefix_count(sm)] = cid;
+                        if (surv) compact[nsurv + __popcll(sm & ((1ull << lane) - 1ull))] = cid;
                         nsurv += __popcll(sm);
                     }
                     }
@@ -702,28 +757,50 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             SVSX_PHASE_USE(cnt);
             SVSX_PHASE_STAMP(3);
             for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
-                const uint32_t ci = p0 + grp; // <= 63: p0 is a multiple of RPP below cnt <= 64
-                uint32_t cid; // the word that goes into the buffer (inline records: id | degree class)
-                if constexpr (FAT) cid = compact[ci];
-                else cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
+                const uint32_t ci = p0 + grp;
+                const uint32_t cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
                 const bool act = ci < cnt;
-                const uint32_t rid = FAT ? (cid & idmask) : cid; // the row it names
-                // buffers of up to 128 entries: the two entries per lane the merge insert of this pass starts from are requested inside the
-                // distance routine, just before its cross-lane reduction (nothing writes the buffer in between)
-                constexpr bool PREFETCH = !GENERAL && BIG == 0 && SVSX_MERGE_V2 == 0;
-                [[maybe_unused]] uint2 pre[2];
-                [[maybe_unused]] bool pre_valid = false;
-                const float dist = group_distance(rid, act, full ? worst * 1.00004f : __builtin_inff(), [&]() {
-                    if constexpr (PREFETCH) {
-                        if (buf.capacity <= 128u) {
-                            wave_buffer_prefetch<2>(buf, lane, pre);
-                            pre_valid = true;
+                if constexpr (EARLY) {
+                    // an earlier pass of this expansion changed the buffer: the next unvisited entry is read again (before the row loads, the
+                    // LDS round trip hides behind them)
+                    if (p0 > 0u && p0 + RPP >= cnt) {
+                        nx_id = kInvalidId;
+                        const uint32_t upper = buf.size < buf.window ? buf.size : buf.window;
+                        if (buf.best_unvisited < upper && a.gstride <= 64u && !nan_seen) {
+                            const uint2 en = buf.e[buf.best_unvisited];
+                            nx_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(en.y & kIdMask)));
+                            nx_d = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(en.x))));
                         }
                     }
-                });
+                }
+                const float dist = group_distance(cid, act, full ? worst * 1.00004f : __builtin_inff());
                 const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
                 const bool cand = act && sub == 0 && !skip;
                 unsigned long long m = __ballot(cand);
+                if constexpr (EARLY) {
+                    if (p0 + RPP >= cnt && a.gstride <= 64u && !nan_seen) { // last pass: every distance of this expansion is known
+                        uint32_t pred = nx_id;
+                        // candidates strictly better than the next unvisited entry (all of them when there is none): the best one, the earliest in
+                        // adjacency order among equals -- the order the inserts give them
+                        unsigned long long bm = nx_id != kInvalidId ? __ballot(cand && cmpf<GREATER>(dist, nx_d)) : m;
+                        if (bm != 0ull) {
+                            int bl = __builtin_ctzll(bm);
+                            bm &= bm - 1ull;
+                            float bd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), bl));
+                            while (bm != 0ull) {
+                                const int l2 = __builtin_ctzll(bm);
+                                bm &= bm - 1ull;
+                                const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dist), l2));
+                                if (cmpf<GREATER>(dj, bd)) {
+                                    bd = dj;
+                                    bl = l2;
+                                }
+                            }
+                            pred = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
+                        }
+                        if (pred != kInvalidId) request_block(pred);
+                    }
+                }
                 SVSX_PHASE_USE(m);
                 SVSX_PHASE_STAMP(4);
                 n_eval += (cnt - p0) < static_cast<uint32_t>(RPP) ? (cnt - p0) : static_cast<uint32_t>(RPP);
@@ -752,12 +829,14 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                                 else if (buf.capacity <= 384u) merged = wave_merge_insert<GREATER, 6>(buf, cand, dist, cid, lane, n_ins, worst);
                                 else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins, worst);
                             } else {
-                                merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins, worst, pre_valid ? pre : nullptr);
+                                merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins, worst);
                             }
 #endif
                         }
-                        if (merged) m = 0ull;
-                        full = buf.size == buf.capacity; // (unchanged if nothing was merged) `worst` came out of the merge
+                        if (merged) {
+                            m = 0ull;
+                            full = buf.size == buf.capacity; // `worst` came out of the merge (the entry that ended at capacity - 1)
+                        }
                     }
                 }
                 while (m != 0ull) {
@@ -767,7 +846,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     if (full && cmpf<GREATER>(worst, dd)) continue; // worst may have improved within this pass
                     const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), bl));
                     nan_seen = nan_seen || dd != dd;
-                    if (wave_insert<GREATER>(buf, dd, id, lane, nan_seen, FAT ? idmask : kIdMask)) {
+                    if (wave_insert<GREATER>(buf, dd, id, lane, nan_seen)) {
                         ++n_ins;
                         full = buf.size == buf.capacity;
                         if (full) worst = __uint_as_float(buf.e[buf.capacity - 1].x);
@@ -778,6 +857,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             }
             if (deg_here < 64u) break;
         }
+        if constexpr (EARLY) asm volatile("" ::"v"(early_sink), "v"(early_sink2)); // keeps the request; vmcnt is in order, the rows requested later have arrived by now
     }
 
 #if defined(SVSX_DIAG) && SVSX_DIAG == 3
@@ -812,7 +892,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     }
                 }
                 const unsigned long long fm = __ballot(fresh);
-                const uint32_t rank = got + prefix_count(fm);
+                const uint32_t rank = got + __popcll(fm & ((1ull << lane) - 1ull));
                 if (fresh && rank < it_bs) {
                     a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + rank] = static_cast<uint64_t>(id) + a.id_offset;
                     a.it_out_dists[static_cast<size_t>(qi) * a.it_batch + rank] = __uint_as_float(en.x);
@@ -845,7 +925,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         const bool have = j < buf.size;
         if (have) {
             const uint2 en = buf.e[j];
-            id = en.y & (FAT ? idmask : kIdMask);
+            id = en.y & kIdMask;
             dist = __uint_as_float(en.x);
         }
         const size_t o = static_cast<size_t>(qi) * a.k + j;
@@ -863,6 +943,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             st[4] = n_early;
             st[5] = n_code_rej;
 #ifdef SVSX_DIAG
+            st[2] = diag_have;
+            st[3] = diag_early;
             st[4] = diag_t0;
             st[5] = static_cast<uint32_t>(wall_clock64());
 #if SVSX_DIAG == 2

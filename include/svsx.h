@@ -135,6 +135,15 @@ typedef struct {
  * runtime VamanaIndex::build/load -> out-param (runtime/vamana_index.h:111-120) */
 int svsx_index_create(const svsx_index_desc* desc, svsx_index** out);
 int svsx_index_create_device_view(const svsx_device_index_desc* desc, svsx_index** out);
+/* Scalar-quantized rows under cosine similarity (CosineSimilarityCompressed, quantization/scalar/scalar.h:155-195) carry one float per row: the
+ * norm of the decompressed row, computed when the index (or view) is created -- by a kernel on the NULL stream, which the creating call waits
+ * for.  A view therefore needs its rows final and visible to the NULL stream when it is created (rows written on a hipStreamNonBlocking stream:
+ * synchronise that stream first, or refresh).  _refresh recomputes the norms on `hip_stream`, stream-ordered and without waiting (rows that were
+ * rewritten, or written on a side stream); searches must follow on the same stream or after the caller has synchronised it.  _drop releases
+ * them: such an index is answered by the kernel variant that takes the norm per candidate (identical results, ~14 % slower, no inline
+ * records).  Both are no-ops on any other kind of index. */
+int svsx_index_refresh_row_norms(svsx_index* index, void* hip_stream);
+int svsx_index_drop_row_norms(svsx_index* index);
 /* runtime VamanaIndex::destroy (runtime/vamana_index.h:111-120) */
 void svsx_index_destroy(svsx_index* index);
 

@@ -206,6 +206,10 @@ template <typename T, typename Dist> class VamanaIndex {
     // optional, result-neutral (svsx.h): 2 = graph-inline bound records sized from the data's spectrum (the default and the fast path of
     // bench.py), 32 / 64 / 128 = records of that size, 1 = one 128-byte code row per vector (float rows, L2, d = 96 / 128), 0 = off
     void build_bound_codes(int mode = 2) { check(svsx_index_build_bound_codes(h_, mode)); }
+    // scalar-quantized rows under cosine similarity keep one norm per row (svsx.h): recompute them in the order of `hip_stream` after rewriting
+    // rows of a device view, or release them (searches then take the norm per candidate, as the reference does; same results)
+    void refresh_row_norms(void* hip_stream = nullptr) { check(svsx_index_refresh_row_norms(h_, hip_stream)); }
+    void drop_row_norms() { check(svsx_index_drop_row_norms(h_)); }
     // runtime VamanaIndex::search(n, x, k, distances, labels, params, IDFilter* filter) (bindings/cpp/include/svs/runtime/vamana_index.h:75-83):
     // `is_member` = one bit per id ((size() + 63) / 64 words); unfilled result slots hold id all-ones / distance +inf; filter_stop and
     // filter_estimate_batch are SearchParams' fields of the same names (api_defs.h; the runtime defaults: 0 and true)

@@ -83,6 +83,7 @@ EXPORTS = [
     "svsx_last_kernel_info", "svsx_search_filtered", "svsx_search_filtered_ex", "svsx_vamana_build_device", "svsx_find_medoid_device",
     "svsx_sharded_unique_id", "svsx_sharded_create", "svsx_sharded_create_with_comm", "svsx_sharded_destroy", "svsx_sharded_info",
     "svsx_sharded_search_device", "svsx_abi_version", "svsx_flat_search_device_counted", "svsx_flat_search",
+    "svsx_index_refresh_row_norms", "svsx_index_drop_row_norms",
 ]
 
 _lib = None
@@ -123,6 +124,8 @@ def lib() -> C.CDLL:
         L.svsx_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_create_device_view.argtypes = [C.POINTER(DeviceIndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_destroy.argtypes = [C.c_void_p]
+        L.svsx_index_refresh_row_norms.argtypes = [C.c_void_p, C.c_void_p]
+        L.svsx_index_drop_row_norms.argtypes = [C.c_void_p]
         L.svsx_index_destroy.restype = None
         L.svsx_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams),
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SearchAux)]

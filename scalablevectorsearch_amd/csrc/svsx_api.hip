@@ -54,6 +54,7 @@ struct svsx_index {
     void* d_fat = nullptr;
     size_t fat_stride = 0;
     uint32_t fat_rb = 32;
+    uint32_t fat_degshift = 0; // 26 when the blocks' id words carry the neighbours' degree classes (n <= 2^26), else 0
     float* d_pca = nullptr;      // [32][dpad] leading directions (float32, row-major, zero padded) | [dpad] mean | [32] bias
     float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_delta = 0.0f, pca_eq_abs = 0.0f, pca_ref_extra = 0.0f;
     // host-pointer calls (svsx_search): persistent staging contexts, one per concurrent caller (HostCallContext below)
@@ -241,14 +242,34 @@ int svsx_abi_version(void) { return SVSX_ABI_VERSION; }
 const char* svsx_last_kernel_info(void) { return last_search_instantiation(); }
 
 // CosineSimilarityCompressed divides by the norm of the decompressed row (scalar.h:175-184, cosine.h:334-335): a property of the row alone,
-// computed once here by the search kernel's own accumulation routine (same bits) instead of once per candidate and query
-static int build_sq_row_norms(svsx_index* ix) {
+// computed once by the search kernel's own accumulation routine (same bits) instead of once per candidate and query.  Stream-ordered: the
+// kernel runs on `stream`; `wait` makes the call return only when the norms are there (index creation: the NULL stream, which joins every
+// blocking stream -- rows written on a NON-blocking stream must be complete before the view is created, or be followed by
+// svsx_index_refresh_row_norms on that stream).  No device-wide synchronisation.
+static int build_sq_row_norms(svsx_index* ix, hipStream_t stream, bool wait) {
     if (!ix->sq_enabled || ix->metric != M_COS || ix->n == 0) return SVSX_SUCCESS;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_sq_row_norm), ix->n * sizeof(float)));
+    if (!ix->d_sq_row_norm) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_sq_row_norm), ix->n * sizeof(float)));
     hipError_t e = launch_sq_row_norms(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), ix->sq_scale, ix->sq_bias,
-                                       ix->d_sq_row_norm, nullptr);
+                                       ix->d_sq_row_norm, stream);
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "row-norm kernel failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipDeviceSynchronize());
+    if (wait) HIP_TRY(hipStreamSynchronize(stream));
+    return SVSX_SUCCESS;
+}
+
+int svsx_index_refresh_row_norms(svsx_index* ix, void* hip_stream) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    HIP_TRY(hipSetDevice(ix->device));
+    return build_sq_row_norms(ix, static_cast<hipStream_t>(hip_stream), false);
+}
+
+int svsx_index_drop_row_norms(svsx_index* ix) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    HIP_TRY(hipSetDevice(ix->device));
+    if (ix->d_sq_row_norm) {
+        HIP_TRY(hipDeviceSynchronize()); // searches in flight may still read them
+        (void)hipFree(ix->d_sq_row_norm);
+        ix->d_sq_row_norm = nullptr;
+    }
     return SVSX_SUCCESS;
 }
 
@@ -298,7 +319,7 @@ int svsx_index_create(const svsx_index_desc* desc, svsx_index** out) {
     if (hipMemcpy2D(ix->d_data, ix->row_bytes, desc->data, src_stride, desc->d * es, desc->n, hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail(SVSX_RUNTIME_ERROR, "copying data to the device failed"));
 
-    if (int rc = build_sq_row_norms(ix)) return cleanup(rc);
+    if (int rc = build_sq_row_norms(ix, nullptr, true)) return cleanup(rc);
     if (flat_only) {
         *out = ix;
         return SVSX_SUCCESS;
@@ -362,7 +383,7 @@ int svsx_index_create_device_view(const svsx_device_index_desc* desc, svsx_index
     ix->id_offset = desc->id_offset;
     ix->owns = false;
     if (hipSetDevice(ix->device) != hipSuccess) { delete ix; return fail(SVSX_RUNTIME_ERROR, "hipSetDevice(%d) failed", desc->device); }
-    if (int rc = build_sq_row_norms(ix)) { svsx_index_destroy(ix); return rc; }
+    if (int rc = build_sq_row_norms(ix, nullptr, true)) { svsx_index_destroy(ix); return rc; }
     *out = ix;
     return SVSX_SUCCESS;
 }
@@ -697,7 +718,16 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb) {
     void* fat = nullptr;
     if (hipMalloc(&fat, static_cast<size_t>(n) * fat_stride + 128) != hipSuccess)
         return fail(SVSX_RUNTIME_ERROR, "hipMalloc(%zu) for the graph-inline records failed", static_cast<size_t>(n) * fat_stride);
-    hipError_t e = launch_fat_build(ix->d_graph, static_cast<uint32_t>(ix->gstride), n, rec.p, rb, fat, fat_stride, nullptr);
+    // degree-aware block loads (svsx_search_kernel.h): ids below 2^26 leave bits [26, 31) of a buffer word for ceil(degree / 8)
+    constexpr uint32_t kDegShift = 26;
+    const bool deg_aware = n <= (1u << kDegShift) && ix->gstride <= 248; // class = ceil(degree / 8) <= 31: five bits
+    DeviceBuffer cls;
+    if (deg_aware && cls.alloc(n) != hipSuccess) {
+        (void)hipFree(fat);
+        return fail(SVSX_RUNTIME_ERROR, "hipMalloc(%u) for the degree classes failed", n);
+    }
+    hipError_t e = launch_fat_build(ix->d_graph, static_cast<uint32_t>(ix->gstride), n, rec.p, rb, fat, fat_stride, deg_aware ? static_cast<uint8_t*>(cls.p) : nullptr,
+                                    kDegShift, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipFree(fat);
@@ -706,6 +736,7 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb) {
     ix->d_fat = fat;
     ix->fat_stride = fat_stride;
     ix->fat_rb = rb;
+    ix->fat_degshift = deg_aware ? kDegShift : 0u;
     ix->pca_step = stepf;
     ix->pca_tail_unit = tail_unit;
     ix->pca_delta = static_cast<float>(delta * 1.01 + 1e-9);
@@ -794,6 +825,9 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     a.q_row_bytes = q_row_bytes;
     a.nq = static_cast<uint32_t>(nq);
     a.general = ix->n_entry > 16 ? 1u : 0u; // std::sort of > 16 entry points is not a stable insertion sort
+    // scalar-quantized rows under cosine without their precomputed norms (svsx_index_drop_row_norms): the runtime-d kernel variant computes the
+    // norm per candidate, the reference's own operation order (same bits, ~14 % slower: profiles/r04_notes.md section 3)
+    if (ix->sq_enabled && ix->metric == M_COS && ix->d_sq_row_norm == nullptr) a.general = 1u;
     if (ix->d_codes && !a.general) { // result-neutral lower-bound rejection (float queries on float32 L2 rows)
         a.codes = static_cast<const unsigned char*>(ix->d_codes);
         a.code_scale = ix->code_scale;
@@ -804,6 +838,7 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
         a.fat = static_cast<const unsigned char*>(ix->d_fat);
         a.fat_stride = ix->fat_stride;
         a.fat_rb = ix->fat_rb;
+        a.fat_degshift = ix->fat_degshift;
         a.pca_pd = static_cast<uint32_t>((ix->d + 15) & ~size_t(15));
         a.pca_t = ix->d_pca;
         a.pca_mean = ix->d_pca + static_cast<size_t>(kPcaRows) * a.pca_pd;
@@ -1217,11 +1252,34 @@ int svsx_flat_search_device_counted(
     if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k, false)) return rc;
     if (nq == 0) return SVSX_SUCCESS;
     if (!d_ids64) return fail(SVSX_INVALID_ARGUMENT, "null argument");
-    if (k > 224) return fail(SVSX_INVALID_ARGUMENT, "flat search supports k <= 224 (the float16 shortlist keeps k + 32 <= 256 candidates per query in LDS: 32 spare ranks for float16 rounding)");
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    // FlatIndex::search (index/flat/flat.h:322-460) bounds neither k nor the dimension.  The float16 pipeline below keeps k + 32 <= 256 shortlist
+    // entries per query (and, beyond d = 128, the 64 queries of a wave) in LDS; what does not fit it -- k > 224, or a dimension whose 64
+    // float16 queries plus k + 8 entries exceed 160 KB (d >= ~1 200) -- is answered by the exhaustive float32 pass alone: every query
+    // against every row with the reference-order routines and a k-entry list (stage 5 of the pipeline, exact by construction; one wave per
+    // query, so it is the slow path: 10 000 x 1 M x 96 takes ~1 s instead of 4 ms).
+    auto exhaustive_only = [&]() -> int {
+        const size_t lds = ((ix->d + 15) & ~size_t(15)) * 4 + k * 8;
+        if (lds > 160 * 1024) return fail(SVSX_INVALID_ARGUMENT, "flat search: k = %zu at d = %zu needs %zu bytes of LDS for one query's list (160 KB available)", k, ix->d, lds);
+        StreamBuffer redo;
+        HIP_TRY(redo.alloc(nq * 4, stream));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(redo.p), 1, nq, stream));
+        FlatExactArgs xa;
+        memset(&xa, 0, sizeof(xa));
+        xa.r.data = ix->d_data; xa.r.row_bytes = ix->row_bytes; xa.r.d = static_cast<uint32_t>(ix->d); xa.r.sq_scale = ix->sq_scale; xa.r.sq_bias = ix->sq_bias;
+        xa.r.id_offset = ix->id_offset; xa.r.queries = d_queries; xa.r.q_row_bytes = ix->d * dtype_size(q_dtype); xa.r.q_dtype = q_dtype;
+        xa.r.nq = static_cast<uint32_t>(nq); xa.r.kk = static_cast<uint32_t>(k); xa.r.k = static_cast<uint32_t>(k);
+        xa.r.ids64 = d_ids64; xa.r.dists = d_dists;
+        xa.redo = static_cast<const uint32_t*>(redo.p); xa.n = static_cast<uint32_t>(ix->n);
+        hipError_t e = launch_flat_exact(ix->data_dtype, ix->metric, qmode, xa, stream);
+        if (e == hipSuccess && d_recomputed != nullptr) e = launch_add_word(d_recomputed, static_cast<uint32_t>(nq), stream);
+        if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "flat search launch failed: %s", hipGetErrorString(e));
+        return SVSX_SUCCESS;
+    };
+    if (k > 224) return exhaustive_only();
     // rows of the float16 shadow: padded to 16 elements, between 129 and 768 dimensions to 128 (the threshold kernel for those takes the
     // dimension in chunks of 128)
     const uint32_t dpad = static_cast<uint32_t>(ix->d > 128 && ix->d <= 768 ? (ix->d + 127) & ~size_t(127) : (ix->d + 15) & ~size_t(15));
@@ -1232,8 +1290,11 @@ int svsx_flat_search_device_counted(
             float* nrm = nullptr;
             HIP_TRY(hipMalloc(&h, (ix->n + 32) * dpad * 2 + 64)); // one tile of padding: the threshold kernel loads whole 32-row tiles
             if (hipMalloc(reinterpret_cast<void**>(&nrm), ix->n * 4) != hipSuccess) { (void)hipFree(h); return fail(SVSX_RUNTIME_ERROR, "hipMalloc failed"); }
-            hipError_t e = launch_to_half(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), dpad,
-                                          ix->sq_enabled, ix->sq_scale, ix->sq_bias, h, nrm, stream);
+            // the padding tile is read (masked) by the last tile of the threshold kernel: zeros, not whatever the allocation held
+            hipError_t e = hipMemsetAsync(static_cast<unsigned char*>(h) + ix->n * static_cast<size_t>(dpad) * 2, 0, 32 * static_cast<size_t>(dpad) * 2 + 64, stream);
+            if (e == hipSuccess)
+                e = launch_to_half(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), dpad,
+                                   ix->sq_enabled, ix->sq_scale, ix->sq_bias, h, nrm, stream);
             uint32_t* mm = nullptr; // {max, min} bits of the squared norms
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&mm), 8);
             uint32_t range[2] = {0u, 0xFFFFFFFFu};
@@ -1260,13 +1321,12 @@ int svsx_flat_search_device_counted(
         while (fixed + 64 * kk * 8 > 160 * 1024 && kk > k + 8) kk -= 4;
         if (kk < k) kk = k;
         const size_t need = fixed + 64 * kk * 8;
-        if (need > 160 * 1024)
-            return fail(SVSX_INVALID_ARGUMENT, "flat search: k = %zu at d = %zu needs %zu bytes of LDS per wave (160 KB available): lower k", k, ix->d, need);
+        if (need > 160 * 1024) return exhaustive_only(); // the 64 float16 queries of a wave + its shortlists do not fit (d >= ~1 200, or a long list at a large d)
     }
     const size_t nqb = (nq + 63) / 64;
     // one round of resident waves: LDS (64 shortlists of kk entries) bounds the waves per CU; a second round would
     // double the time, more slices than needed only add shortlist inserts (measured: 14.1 ms at 80 % of the slots)
-    const size_t flat_lds = 64 * kk * 8 + 256;
+    const size_t flat_lds = 64 * kk * 8 + 256 + (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0); // shortlists + (beyond d = 128) the wave's 64 queries
     size_t waves_per_cu = (160 * 1024) / flat_lds;
     if (waves_per_cu > 8) waves_per_cu = 8;
     if (waves_per_cu < 1) waves_per_cu = 1;

@@ -209,10 +209,22 @@ template <int DT> __global__ __launch_bounds__(64) void pca_encode_kernel(const 
     }
 }
 
+// pass 3a (indexes of at most 2^26 nodes): ceil(degree / 8) of every node -- the number of 8-slot groups of its block that hold a neighbour
+__global__ __launch_bounds__(256) void degree_class_kernel(const uint32_t* __restrict__ graph, uint32_t gstride, uint32_t n, uint8_t* __restrict__ cls) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t* row = graph + static_cast<size_t>(v) * gstride;
+    uint32_t deg = 0;
+    for (uint32_t j = 0; j < gstride; ++j) deg += row[j] != kInvalidId ? 1u : 0u; // rows are packed from slot 0; counting all slots does not rely on it
+    cls[v] = static_cast<uint8_t>((deg + 7u) >> 3);
+}
+
 // pass 3: node v -> per chunk of <= 64 slots [ids | plane 0 | ... | plane RW-1]; plane p = bytes [16p, 16p + 16) of each
-// neighbour's record, so that one load instruction of the search kernel reads one contiguous plane
+// neighbour's record, so that one load instruction of the search kernel reads one contiguous plane.  With `cls` the id word of a neighbour
+// carries that neighbour's degree class in bits [degshift, 31): the search kernel finds it in the candidate buffer when the neighbour is
+// expanded and requests only the lines of the block that hold neighbours (svsx_search_kernel.h, main loop).
 __global__ __launch_bounds__(64) void fat_build_kernel(const uint32_t* __restrict__ graph, uint32_t gstride, uint32_t n, const uint4* __restrict__ records,
-                                                       uint32_t rw, unsigned char* __restrict__ fat, size_t fat_stride) {
+                                                       uint32_t rw, unsigned char* __restrict__ fat, size_t fat_stride, const uint8_t* __restrict__ cls, uint32_t degshift) {
     const uint32_t lane = threadIdx.x;
     for (uint32_t v = blockIdx.x; v < n; v += gridDim.x) {
         unsigned char* out = fat + static_cast<size_t>(v) * fat_stride;
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(64) void fat_build_kernel(const uint32_t* __restric
             uint4* planes = reinterpret_cast<uint4*>(ids + cs);
             if (lane < cs) {
                 const uint32_t nb = graph[static_cast<size_t>(v) * gstride + gbase + lane];
-                ids[lane] = nb;
+                ids[lane] = (nb != kInvalidId && cls != nullptr) ? (nb | (static_cast<uint32_t>(cls[nb]) << degshift)) : nb;
                 for (uint32_t p = 0; p < rw; ++p) {
                     uint4 r = make_uint4(0, 0, 0, 0);
                     if (nb != kInvalidId) r = records[static_cast<size_t>(nb) * rw + p];
@@ -271,9 +283,13 @@ hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream) { return launc
 hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream) { return launch_by_dtype(a, true, stream); }
 
 hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, uint32_t record_bytes, void* d_fat, size_t fat_stride,
-                            hipStream_t stream) {
+                            uint8_t* d_class_scratch, uint32_t degshift, hipStream_t stream) {
+    if (d_class_scratch != nullptr) {
+        hipLaunchKernelGGL(degree_class_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_graph, gstride, n, d_class_scratch);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(fat_build_kernel, dim3(grid_for(n)), dim3(64), 0, stream, d_graph, gstride, n, static_cast<const uint4*>(d_records), record_bytes / 16u,
-                       static_cast<unsigned char*>(d_fat), fat_stride);
+                       static_cast<unsigned char*>(d_fat), fat_stride, static_cast<const uint8_t*>(d_class_scratch), degshift);
     return hipGetLastError();
 }
 

@@ -60,6 +60,14 @@ __device__ __forceinline__ int opaque_i(int v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+// A copy of `v` the optimizer knows nothing about.  Used on the lane index inside the search kernel's main loop: address terms derived from
+// such a copy (lane * 4, lane * 16 as a 64-bit pair, lane | 64 ...) are recomputed where they are used (one instruction each) instead of being
+// hoisted out of the loop and kept in registers across the distance pass -- the kernel sits at its 80-register bracket (6 waves per SIMD) and
+// spilled exactly those constants, with the reload in front of the adjacency block's loads.
+__device__ __forceinline__ uint32_t opaque_u(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ float add_xor1f(float v) { return opaque_f(v + xor1f(v)); }
 __device__ __forceinline__ float add_xor2f(float v) { return opaque_f(v + xor2f(v)); }
 __device__ __forceinline__ int add_xor1i(int v) { return opaque_i(v + xor1i(v)); }
@@ -137,6 +145,92 @@ template <int E> __device__ __forceinline__ float reduce_slots(float (&v)[E]) {
     }
 }
 
+// float32 rows of a static dimension that is a multiple of 16, slot-cyclic mapping, written on explicit register PAIRS (round 5).  The same
+// operations in the same order as float_row_distance below -- lane-slot e of block i goes through acc_step into s[i & 3][e], then
+// (s0 + s1) + (s2 + s3), the remaining 16-blocks into s0, reduce_slots -- but two adjacent lane-slots share one v_pk_add_f32 / v_pk_fma_f32
+// (each half is the same IEEE operation), and a pair is two CONSECUTIVE registers of the 16-byte row load and of the 16-byte query read.
+// Left to itself the SLP vectorizer paired lane-slot e of block i with lane-slot e of block i + 2 and spent 26 v_mov per 16-row pass
+// gathering the operands (87 vector instructions per pass at d = 96; 49 in this form).
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+template <int METRIC> __device__ __forceinline__ void acc_step2(f2_t& s, f2_t& n, f2_t q, f2_t x) {
+    if constexpr (METRIC == M_L2) {
+        const f2_t c = q - x;
+        s = __builtin_elementwise_fma(c, c, s);
+    } else {
+        s = __builtin_elementwise_fma(q, x, s);
+        if constexpr (METRIC == M_COS) n = __builtin_elementwise_fma(x, x, n);
+    }
+}
+
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `before_reduce` runs between the last accumulate step and the cross-lane reduction: the search kernel requests the buffer entries of the
+// coming merge insert there (an LDS round trip under ~20 instructions that do not depend on it).
+template <int METRIC, int DS, typename HOOK = NoHook>
+__device__ __forceinline__ void float_row_distance_f32_pairs(const unsigned char* __restrict__ row, const float* __restrict__ qf, int sub, float& out_main, float& out_nrm,
+                                                             HOOK&& before_reduce = NoHook{}) {
+    static_assert(DS >= 16 && (DS & 15) == 0, "whole 16-blocks");
+    constexpr int NB = DS >> 4, NB64 = (DS >> 6) * 4;
+    const float4* lane_row = reinterpret_cast<const float4*>(row) + sub; // block i = 4 float4; lane `sub` owns lane-slots 4 sub .. 4 sub + 3
+    const float4* lane_q = reinterpret_cast<const float4*>(qf) + sub;
+    float4 x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) x[i] = lane_row[4 * i]; // every load of the row before the first use; inactive groups read row 0
+    // the query's blocks come from LDS four ahead of their use, two at a time: at most 16 registers of query are live while the row is in
+    // flight, and no read waits on the arithmetic of the block before it (the scheduler, left alone, issued them one by one, each
+    // followed by its own wait: five dependent LDS round trips per pass)
+#ifndef SVSX_QA
+#define SVSX_QA 4
+#endif
+    constexpr int QA = NB < SVSX_QA ? NB : SVSX_QA;
+    float4 q[NB];
+#pragma unroll
+    for (int i = 0; i < QA; ++i) q[i] = lane_q[4 * i];
+    __builtin_amdgcn_sched_barrier(0);
+    f2_t s[4][2], n[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j][0] = f2_t{0.0f, 0.0f}; s[j][1] = f2_t{0.0f, 0.0f};
+        n[j][0] = f2_t{0.0f, 0.0f}; n[j][1] = f2_t{0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < NB; i0 += 2) {
+#pragma unroll
+        for (int i = i0; i < i0 + 2 && i < NB; ++i) {
+            if (NB64 > 0 && i == NB64) { // the 64-blocks are done: (s0 + s1) + (s2 + s3), the rest goes into s0
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    s[0][h] = (s[0][h] + s[1][h]) + (s[2][h] + s[3][h]);
+                    if constexpr (METRIC == M_COS) n[0][h] = (n[0][h] + n[1][h]) + (n[2][h] + n[3][h]);
+                }
+            }
+            const int j = i < NB64 ? (i & 3) : 0;
+            acc_step2<METRIC>(s[j][0], n[j][0], f2_t{q[i].x, q[i].y}, f2_t{x[i].x, x[i].y});
+            acc_step2<METRIC>(s[j][1], n[j][1], f2_t{q[i].z, q[i].w}, f2_t{x[i].z, x[i].w});
+        }
+#pragma unroll
+        for (int i = i0 + QA; i < i0 + QA + 2 && i < NB; ++i) q[i] = lane_q[4 * i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (NB64 == NB && NB64 > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            s[0][h] = (s[0][h] + s[1][h]) + (s[2][h] + s[3][h]);
+            if constexpr (METRIC == M_COS) n[0][h] = (n[0][h] + n[1][h]) + (n[2][h] + n[3][h]);
+        }
+    }
+    before_reduce();
+    float v[4] = {s[0][0].x, s[0][0].y, s[0][1].x, s[0][1].y};
+    out_main = reduce_slots<4>(v);
+    if constexpr (METRIC == M_COS) {
+        float w[4] = {n[0][0].x, n[0][0].y, n[0][1].x, n[0][1].y};
+        out_nrm = reduce_slots<4>(w);
+    } else {
+        out_nrm = 0.0f;
+    }
+}
+
 // Float-path distance of one candidate row against the query held (as f32, zero padded to 16) in LDS.
 // All 64 lanes execute this in lock-step; `active` only predicates the global loads.
 //   DS > 0: compile-time dimension (fully unrolled, all row loads issued up front); DS == 0: runtime d.
@@ -144,12 +238,19 @@ template <int E> __device__ __forceinline__ float reduce_slots(float (&v)[E]) {
 // PRUNE (squared L2, runtime dimension only): after every 64-element block the partial sum is a lower bound of the
 // distance; groups whose bound already exceeds `thr` (= worst * (1 + 4e-5), see l2_row_distance_two_phase) stop
 // fetching, and the loop ends once every group of the wave has stopped.  out_main = +inf for a rejected group.
-template <int DT, int METRIC, int DS, bool DECOMP, bool PRUNE = false>
+template <int DT, int METRIC, int DS, bool DECOMP, bool PRUNE = false, typename HOOK = NoHook>
 __device__ __forceinline__ void float_row_distance(
     const unsigned char* __restrict__ row, bool active, const float* __restrict__ qf, int d_runtime, int sub,
-    float sq_scale, float sq_bias, float& out_main, float& out_nrm, float thr = 0.0f, bool* rejected_out = nullptr
+    float sq_scale, float sq_bias, float& out_main, float& out_nrm, float thr = 0.0f, bool* rejected_out = nullptr, HOOK&& before_reduce = NoHook{}
 ) {
     static_assert(!PRUNE || (METRIC == M_L2 && DS == 0 && !DECOMP), "partial-distance rejection: runtime-d squared L2 only");
+#ifndef SVSX_F32_PAIRS
+#define SVSX_F32_PAIRS 1
+#endif
+    if constexpr (SVSX_F32_PAIRS != 0 && DT == DT_F32 && DS >= 16 && DS <= 256 && (DS & 15) == 0 && !DECOMP && !PRUNE) {
+        float_row_distance_f32_pairs<METRIC, DS>(row, qf, sub, out_main, out_nrm, before_reduce);
+        return;
+    }
     constexpr int E = Elem<DT>::E;
     constexpr int CB = E * Elem<DT>::BYTES; // bytes per chunk
     const int d = DS > 0 ? DS : d_runtime;
@@ -285,6 +386,7 @@ __device__ __forceinline__ void float_row_distance(
             if constexpr (METRIC == M_COS) n[0][e] = in ? tn : n[0][e];
         }
     }
+    before_reduce();
     out_main = reduce_slots<E>(s[0]);
     if constexpr (METRIC == M_COS) out_nrm = reduce_slots<E>(n[0]);
     else out_nrm = 0.0f;
@@ -726,6 +828,12 @@ struct WaveBuffer {
 
 __device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 
+// number of set bits of a wave mask below this lane: v_mbcnt_lo + v_mbcnt_hi.  (Written as popcount(mask & ((1 << lane) - 1)) the compiler
+// keeps the 64-bit lane mask in a register pair for the whole kernel -- and spills it around the distance pass.)
+__device__ __forceinline__ uint32_t prefix_count(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
 // Ordering of the cross-lane dependent accesses to the buffer.  In LDS a wave's operations execute in program order and a compiler
 // fence is all it takes; for a buffer in HBM the wave's own stores must have completed before other lanes reload them: a
 // workgroup-scope fence (s_waitcnt vmcnt(0); the wave's lanes share one L1, so no invalidate is needed).
@@ -739,7 +847,9 @@ __device__ __forceinline__ void buf_order(const WaveBuffer& b) {
 // is whatever std::lower_bound's probe sequence finds (libstdc++ bits/stl_algobase.h __lower_bound: half = len >> 1, probe
 // first + half) -- replayed here step by step, followed by the reference's backward duplicate walk (search_buffer.h:377-389).
 template <bool GREATER>
-__device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id, uint32_t lane, bool unordered = false) {
+// `idmask`: the bits of an entry's second word that identify the row (the inline-record kernels keep a degree class above them; a row
+// reached as an entry point carries none, so ids are compared below it).
+__device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id, uint32_t lane, bool unordered = false, uint32_t idmask = kIdMask) {
     if (unordered) {
         uint32_t first = 0, len = b.size;
         while (len > 0u) {
@@ -759,7 +869,7 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
                 --back;
                 const uint2 en = b.e[back];
                 if (cmpf<GREATER>(__uint_as_float(en.x), d)) break;
-                if ((en.y & kIdMask) == id) return false;
+                if (((en.y ^ id) & idmask) == 0u) return false;
             } while (back != 0u);
         }
         buf_order(b);
@@ -797,7 +907,7 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
         // distance (every comparison false) all of them.  (Written as `== d || d is NaN`: the form with two more
         // compares per entry cost 5 % of the bench kernel.)
         const bool dnan = d != d;
-        const bool same = (v0 && (d0 == d || dnan) && (e0.y & kIdMask) == id) || (v1 && (d1 == d || dnan) && (e1.y & kIdMask) == id);
+        const bool same = (v0 && (d0 == d || dnan) && ((e0.y ^ id) & idmask) == 0u) || (v1 && (d1 == d || dnan) && ((e1.y ^ id) & idmask) == 0u);
         const unsigned long long m0 = __ballot(bf0), m1 = __ballot(bf1);
         if (__ballot(same) != 0ull) return false;
         const uint32_t pos = static_cast<uint32_t>(__popcll(m0) + __popcll(m1)); // sorted: the "before" entries are a prefix
@@ -821,7 +931,7 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
         const float ed = __uint_as_float(en.x);
         const bool before = valid && !cmpf<GREATER>(d, ed);
         const unsigned long long m = __ballot(before);
-        const bool same = valid && (ed == d || d != d) && ((en.y & kIdMask) == id); // ids only among the entries equal to d (all, if d is NaN)
+        const bool same = valid && (ed == d || d != d) && (((en.y ^ id) & idmask) == 0u); // ids only among the entries equal to d (all, if d is NaN)
         dup = dup || (__ballot(same) != 0ull);
         const uint32_t cnt = __popcll(m);
         pos += cnt;
@@ -860,12 +970,24 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
 // Preconditions: capacity <= 64 EPL (EPL entries per lane), no NaN distance in the buffer, candidate distances finite (empty slots
 // are modelled as +-inf sentinels; comparisons must be a strict weak order).  Returns false -- with LDS untouched -- if a candidate duplicates a buffer entry (same id at equal
 // distance, search_buffer.h:377-389); the caller then takes the sequential path for this pass.
+// `pre` (optional): the lane's EPL entries as wave_buffer_prefetch read them earlier in the pass -- nothing writes the buffer between the two.
+template <int EPL> __device__ __forceinline__ void wave_buffer_prefetch(const WaveBuffer& b, uint32_t lane, uint2 (&pre)[EPL]) {
+    lane = opaque_u(lane);
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const uint32_t i = lane + 64u * t;
+        pre[t] = b.e[i < b.capacity ? i : b.capacity]; // unconditional (slots beyond `size` are masked by the merge; [capacity] is the spare slot)
+    }
+}
+
 template <bool GREATER, int EPL>
-__device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted, float& worst_out) {
+__device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted, float& worst_out,
+                                                  const uint2* pre = nullptr) {
     // EPL buffer entries per lane (capacity <= 64 EPL).  Written to stay off the scalar unit (one SALU issue slot per CU per
     // cycle is the scarce resource of this kernel): no boolean mask algebra -- validity is folded into sentinel values, counters
     // advance with carry-in adds, the tie rule of the candidate ranks is one 64-bit compare of (order key, lane).
     constexpr float kPast = GREATER ? -__builtin_inff() : __builtin_inff(); // no candidate compares better than an empty slot
+    lane = opaque_u(lane);
     uint2 e[EPL];
     float dv[EPL];
     uint32_t c[EPL];
@@ -873,7 +995,13 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     for (int t = 0; t < EPL; ++t) {
         const uint32_t i = lane + 64u * t;
         e[t] = make_uint2(__float_as_uint(kPast), kInvalidId);
-        if (i < b.size) e[t] = b.e[i];
+        if (pre != nullptr) {
+            const bool in = i < b.size;
+            e[t].x = in ? pre[t].x : e[t].x;
+            e[t].y = in ? pre[t].y : e[t].y;
+        } else if (i < b.size) {
+            e[t] = b.e[i];
+        }
         dv[t] = __uint_as_float(e[t].x);
         c[t] = 0u;
     }
@@ -901,15 +1029,11 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
         const uint32_t le = 64u * EPL - after; // old entries that stay before j (empty slots always count as "after")
         const unsigned long long kjl = (static_cast<unsigned long long>(kj) << 32) | static_cast<uint32_t>(bl);
         rank += kjl < mykey ? 1u : 0u; // new entries before mine: better, or equal and earlier in adjacency order
-        // lane bl keeps its own count: one v_writelane instead of compare + select.  (inline asm: the compiler's hazard recogniser does not
-        // look inside, so the wait states a lane select / source written by the scalar unit needs are spelled out)
-        // (the lane select goes through m0 -- one constant-bus operand per instruction on gfx9 -- which is saved and restored around it:
-        // m0 is a reserved register, a clobber on it would not be honoured)
+        // lane bl keeps its own count: a select under the one-bit mask the loop has in scalar registers anyway (round 4 used v_writelane,
+        // whose lane select has to go through m0 on gfx9: save, set, wait states, write, restore -- five instructions)
         {
-            uint32_t m0_save;
-            asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                         : "+v"(oldle), "=&s"(m0_save)
-                         : "s"(le), "s"(bl));
+            uint32_t tmp;
+            asm volatile("v_mov_b32 %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, %3" : "+v"(oldle), "=&v"(tmp) : "s"(le), "s"(1ull << bl));
         }
         minpos = le < minpos ? le : minpos;
     }
@@ -936,29 +1060,12 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
     buf_order(b);
     n_inserted += static_cast<uint32_t>(__popcll(__ballot(placed)));
-    const uint32_t old_size = b.size;
     b.size = (b.size + ncand < b.capacity) ? b.size + ncand : b.capacity;
     b.best_unvisited = minpos < b.best_unvisited ? minpos : b.best_unvisited;
-    if (b.size == b.capacity) {
-        // the entry that ends at position capacity - 1 is in some lane's registers: the caller's `worst` without an LDS round trip
-        float wv = 0.0f;
-        bool hit = false;
-#pragma unroll
-        for (int t = 0; t < EPL; ++t) {
-            const uint32_t i = lane + 64u * t;
-            if (i < old_size && i + c[t] + 1u == b.capacity) {
-                wv = dv[t];
-                hit = true;
-            }
-        }
-        if (placed && pn + 1u == b.capacity) {
-            wv = dist;
-            hit = true;
-        }
-        const unsigned long long hm = __ballot(hit);
-        if (hm != 0ull) worst_out = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), __builtin_ctzll(hm)));
-        else worst_out = __uint_as_float(b.e[b.capacity - 1].x); // not reached: exactly one entry ends there
-    }
+    // the entry that ended at position capacity - 1: read back after the writes above (LDS is in order within a wave); the caller uses it
+    // an adjacency block or a row wait later, so the round trip is never waited for (round 4 took it out of the merge's registers:
+    // 17 instructions on the critical path of a lone wave)
+    if (b.size == b.capacity) worst_out = __uint_as_float(b.e[b.capacity - 1u].x);
     return true;
 }
 
@@ -983,7 +1090,7 @@ __device__ __forceinline__ bool wave_merge_insert2(WaveBuffer& b, bool cand, flo
     const unsigned long long cm = __ballot(cand);
     const uint32_t m = static_cast<uint32_t>(__popcll(cm));
     if (m > 16u) return false; // more candidates than scratch slots (cannot happen: 64 / G <= 16 rows per pass)
-    const uint32_t slot = static_cast<uint32_t>(__popcll(cm & ((1ull << lane) - 1ull)));
+    const uint32_t slot = prefix_count(cm);
     // total-order key of my own distance (+0.0 first: -0 and +0 compare equal as floats), ascending = better first
     const uint32_t fb = __float_as_uint(dist + 0.0f);
     uint32_t key = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
@@ -1070,23 +1177,39 @@ __device__ __forceinline__ bool wave_merge_insert2(WaveBuffer& b, bool cand, flo
 
 // SearchBuffer::next (search_buffer.h:294-304): returns the node id, marks it visited, advances best_unvisited.
 __device__ __forceinline__ uint32_t wave_next(WaveBuffer& b, uint32_t lane, float& node_dist) {
+    // the entry itself and the first 64 slots of the scan for the next unvisited one are requested together (round 5: one LDS round trip
+    // instead of two dependent ones); slots beyond `upper` are read (clamped to the spare slot at [capacity]) and masked
+    lane = opaque_u(lane);
+    const uint32_t upper = b.size < b.window ? b.size : b.window;
+    uint32_t nb = b.best_unvisited + 1;
     const uint2 en = b.e[b.best_unvisited];
+    uint32_t flag = kVisitedBit;
+    {
+        const uint32_t i = nb + lane;
+        if (!b.hbm) flag = b.e[i < b.capacity ? i : b.capacity].y;
+        else if (i < upper) flag = b.e[i].y;
+    }
     buf_order(b);
     if (lane == 0) b.e[b.best_unvisited].y = en.y | kVisitedBit;
     buf_order(b);
     node_dist = __uint_as_float(en.x);
-    const uint32_t upper = b.size < b.window ? b.size : b.window;
-    uint32_t nb = b.best_unvisited + 1;
-    while (nb < upper) {
-        const uint32_t i = nb + lane;
-        bool unvisited = false;
-        if (i < upper) unvisited = (b.e[i].y & kVisitedBit) == 0u;
-        const unsigned long long m = __ballot(unvisited);
-        if (m != 0ull) {
-            nb += static_cast<uint32_t>(__builtin_ctzll(m));
-            break;
+    {
+        const unsigned long long m = __ballot(nb + lane < upper && (flag & kVisitedBit) == 0u);
+        if (m != 0ull) nb += static_cast<uint32_t>(__builtin_ctzll(m));
+        else nb += 64;
+        if (m == 0ull) {
+            while (nb < upper) {
+                const uint32_t i = nb + lane;
+                bool unvisited = false;
+                if (i < upper) unvisited = (b.e[i].y & kVisitedBit) == 0u;
+                const unsigned long long m2 = __ballot(unvisited);
+                if (m2 != 0ull) {
+                    nb += static_cast<uint32_t>(__builtin_ctzll(m2));
+                    break;
+                }
+                nb += 64;
+            }
         }
-        nb += 64;
     }
     b.best_unvisited = nb < upper ? nb : upper;
     return en.y & kIdMask;

@@ -45,6 +45,7 @@ struct SearchArgs {
     const unsigned char* fat;
     size_t fat_stride;        // bytes per node
     uint32_t fat_rb;          // record bytes: 32 / 64 / 128
+    uint32_t fat_degshift;    // 0, or 26: the id words of the blocks carry ceil(degree(neighbour) / 8) in bits [26, 31) (indexes of <= 2^26 nodes)
     const float* pca_t;       // [128][pca_pd] leading directions, row-major float32 (rows >= dc are zero), pca_pd = d rounded up to 16
     const float* pca_mean;    // [pca_pd] (zeros unless L2)
     const float* pca_bias;    // [128] per-coordinate code bias (L2)
@@ -194,8 +195,9 @@ struct PcaArgs {
 };
 hipError_t launch_pca_stats(const PcaArgs& a, hipStream_t stream);
 hipError_t launch_pca_encode(const PcaArgs& a, hipStream_t stream);
+// d_class_scratch: n bytes, or nullptr = plain id words (degshift ignored)
 hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t n, const void* d_records, uint32_t record_bytes, void* d_fat, size_t fat_stride,
-                            hipStream_t stream);
+                            uint8_t* d_class_scratch, uint32_t degshift, hipStream_t stream);
 float pca_key_to_float(uint32_t key);
 hipError_t launch_set_word(int* d_word, int value, hipStream_t stream); // one agent-scope store (cancellation)
 // name of the search_kernel instantiation launch_search picked last on this thread (tests assert which one ran)

@@ -247,6 +247,20 @@ int svsx_sharded_search_device(
         hipError_t e_ = (expr);                                                                                              \
         if (e_ != hipSuccess) return svsx::set_error(SVSX_RUNTIME_ERROR, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+    // An error return below leaves work queued on the caller's stream and on the internal ones without ev_last recorded behind it: the next
+    // call would neither chain behind that work nor know that the staging is still being written.  Every exit that is not the
+    // successful one therefore drains the three streams before the staging is handed on.
+    struct DrainOnError {
+        svsx_sharded* s;
+        hipStream_t stream;
+        bool ok = false;
+        ~DrainOnError() {
+            if (ok) return;
+            for (hipStream_t st : s->side) (void)hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(stream);
+            s->have_last = false;
+        }
+    } drain{s, stream};
     // the staging may still be in use by the previous call (made on another stream): chain behind it
     if (s->have_last) SH_TRY(hipStreamWaitEvent(stream, s->ev_last, 0));
     const bool fan_out = n_local > 1;
@@ -297,6 +311,7 @@ int svsx_sharded_search_device(
         for (int c = 0; c < nchunk; ++c) SH_TRY(hipStreamWaitEvent(stream, s->ev_done[c], 0));
     SH_TRY(hipEventRecord(s->ev_last, stream));
     s->have_last = true;
+    drain.ok = true;
 #undef SH_TRY
     return SVSX_SUCCESS;
 }

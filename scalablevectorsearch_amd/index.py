@@ -143,7 +143,23 @@ class VamanaIndex:
         self.data_dtype = np.dtype(data_dtype)
         self.entry_points = None
         self._params = VamanaSearchParameters()
+        if sq is not None:
+            # the library took the row norms of a scalar-quantized cosine index on the NULL stream; tensors produced on another torch stream
+            # are only guaranteed complete in THAT stream's order: take the norms again there (include/svsx.h, svsx_index_refresh_row_norms)
+            import torch
+
+            cur = torch.cuda.current_stream(device)
+            if cur != torch.cuda.default_stream(device):
+                self.refresh_row_norms(cur.cuda_stream)
         return self
+
+    def refresh_row_norms(self, stream: int = 0) -> None:
+        """Recompute the per-row norms of a scalar-quantized cosine index on `stream` (after rewriting rows of a device view)."""
+        _lib.check(_lib.lib().svsx_index_refresh_row_norms(self._h, C.c_void_p(stream)))
+
+    def drop_row_norms(self) -> None:
+        """Release the per-row norms: searches then take the norm per candidate (same results, slower; the reference's own form)."""
+        _lib.check(_lib.lib().svsx_index_drop_row_norms(self._h))
 
     def __del__(self):
         h = getattr(self, "_h", None)

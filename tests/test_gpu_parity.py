@@ -111,6 +111,26 @@ def test_search_scalar_quantized(svs, oracle, small_world, metric, code):
         assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("code", [I8, U8])
+def test_sq_cosine_row_norms_dropped_and_refreshed(svs, oracle, small_world, code):
+    """svsx_index_drop_row_norms / _refresh_row_norms (include/svsx.h): without the precomputed norms the kernel takes the norm of the decompressed
+    row per candidate (scalar.h:175-184) -- same ids, same distance bits -- and a refresh brings the fast path back with the same answer."""
+    sw = small_world
+    codes, scale, bias = oracle.sq_compress(sw["x"], code)
+    idx = svs.VamanaIndex(sw["graph"], codes, svs.DistanceCosineSimilarity(), sw["entry"], sq=(scale, bias))
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(24, 24))
+    ids, dists, _ = oracle.search(COS, codes, sw["graph"], sw["entry"], sw["q"], 10, 24, 24, sq=(scale, bias), stats=True)
+    for step in ("norms", "dropped", "refreshed"):
+        if step == "dropped":
+            idx.drop_row_norms()
+        if step == "refreshed":
+            idx.refresh_row_norms()
+        res = idx.search(sw["q"], 10, sp)
+        assert (res.indices == ids.astype(np.uint64)).all(), step
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all(), step
+        assert ("general=1" in idx.last_kernel_info()) == (step == "dropped"), (step, idx.last_kernel_info())
+
+
 @pytest.mark.parametrize("d", [100, 223, 40])
 def test_search_ragged_dims(svs, oracle, d):
     from oracle.oracle import L2 as OL2

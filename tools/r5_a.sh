@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 5, call a: parity subset on the restructured kernel, A/B against the round-4 library (config 2, config-4 shape), phase profiles old / new
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+O=gpurun_out/r05a; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_bound_codes.py tests/test_gpu_parity.py -m gpu -x -q > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
+timeout 600 python tools/ab_libs.py --libs prod=variants/prod/libsvsx.so,new= --script tools/time_c2.py --repeat 2 -- --nq 10000,40000 --windows 128,23 > $O/ab_c2.txt 2>&1
+SVSX_LIB=variants/old_diag2/libsvsx.so timeout 300 python tools/diag_phases.py > $O/phases_c2_old.txt 2>&1
+SVSX_LIB=variants/new_diag2/libsvsx.so timeout 300 python tools/diag_phases.py > $O/phases_c2_new.txt 2>&1
+timeout 900 python tools/ab_libs.py --libs prod=variants/prod/libsvsx.so,new= --script tools/time_c4.py --repeat 1 -- --windows 285,128 > $O/ab_c4.txt 2>&1
+SVSX_LIB=variants/old_diag2/libsvsx.so timeout 300 python tools/time_c4.py --phases --windows 285 > $O/phases_c4_old.txt 2>&1
+SVSX_LIB=variants/new_diag2/libsvsx.so timeout 300 python tools/time_c4.py --phases --windows 285 > $O/phases_c4_new.txt 2>&1
+tail -3 $O/pytest.log; cat $O/ab_c2.txt $O/phases_c2_old.txt $O/phases_c2_new.txt $O/ab_c4.txt $O/phases_c4_old.txt $O/phases_c4_new.txt | tail -40
