@@ -316,6 +316,30 @@ int svsx_search_filtered_ex(
     const uint64_t* id_bitmap, float filter_stop, int filter_estimate_batch, uint64_t* ids64, float* dists
 );
 
+/* Range search: the runtime's VamanaIndex::range_search(n, x, radius, ResultsAllocator, params, IDFilter* filter)
+ * (bindings/cpp/include/svs/runtime/vamana_index.h:85-92; algorithm bindings/cpp/src/vamana_index_impl.h:220-326).  Per query a BatchIterator
+ * is advanced in batches of max(search_window_size, 10); its results come in distance order, every one closer than `radius` (svs::distance
+ * comparator of the index's metric: < for L2, > for inner product / cosine) and -- with a filter -- a member of it is kept, and the query ends at
+ * its first out-of-range neighbour or when the iterator is done.  All queries advance together, one kernel launch per round.
+ * When the counts are known `allocate(user, counts, nq)` is called ONCE (ResultsAllocator::allocate, api_defs.h:194-207) and must return
+ * storage for sum(counts) labels and distances; they are filled query by query, in the order found (labels are global ids, id_offset included).
+ * id_bitmap: NULL = no filter, else bit i of (n + 63) / 64 words = IDFilter::is_member(i), local ids.  Host pointers, synchronous. */
+typedef struct {
+    uint64_t* labels;
+    float* distances;
+} svsx_range_storage;
+typedef svsx_range_storage (*svsx_results_allocator)(void* user, const size_t* result_counts, size_t nq);
+int svsx_range_search(
+    const svsx_index* index, const void* queries, int q_dtype, size_t nq, float radius, const svsx_search_params* params,
+    const uint64_t* id_bitmap, svsx_results_allocator allocate, void* user
+);
+
+/* The runtime's VamanaIndex::get_distance(id, query, &distance) (runtime/vamana_index.h:94-96; index/vamana/index.h:915-933 ->
+ * extensions::get_distance_ext, extensions.h:643-662): distance::compute(fix_argument(query), data[id]) with the index's own kernels -- the
+ * value a search reports for that row, bit for bit (scalar-quantized indexes: the compressed distance).  `id` is global (id_offset included).
+ * Host pointers, synchronous. */
+int svsx_get_distance(const svsx_index* index, uint64_t id, const void* query, int q_dtype, double* distance);
+
 /* Bound codes (no reference counterpart; result-neutral).  The search kernel turns them into a rigorous BOUND of the distance (lower
  * bound for L2, upper bound for inner product / cosine) and drops candidates that SearchBuffer::can_skip (search_buffer.h:338-340) would
  * drop anyway before their full row is fetched -- ids and distances returned are unchanged, only the number of 128-byte lines requested

@@ -222,6 +222,37 @@ template <typename T, typename Dist> class VamanaIndex {
         check(svsx_search_filtered_ex(h_, queries, dtype_of<Q>(), result.n_queries(), result.n_neighbors(), &p, is_member.data(), filter_stop,
                                       filter_estimate_batch ? 1 : 0, reinterpret_cast<uint64_t*>(result.indices), result.distances));
     }
+    // runtime VamanaIndex::range_search(n, x, radius, ResultsAllocator, params, IDFilter* filter) (runtime/vamana_index.h:85-92): FAISS-style
+    // result -- lims[q] .. lims[q + 1] index labels / distances of query q.  `is_member`: empty = no filter, else one bit per id.
+    struct RangeResult {
+        std::vector<size_t> lims;
+        std::vector<uint64_t> labels;
+        std::vector<float> distances;
+    };
+    template <typename Q>
+    RangeResult range_search(const Q* queries, size_t nq, float radius, const VamanaSearchParameters& sp, std::span<const uint64_t> is_member = {}) const {
+        svsx_search_params p{sp.buffer_config_.get_search_window_size(), sp.buffer_config_.get_total_capacity(),
+                             sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
+        if (!is_member.empty() && is_member.size() * 64 < size()) throw ANNException(SVSX_INVALID_ARGUMENT, "is_member must hold one bit per vector");
+        RangeResult r;
+        auto allocate = [](void* user, const size_t* counts, size_t n) -> svsx_range_storage {
+            auto* out = static_cast<RangeResult*>(user);
+            out->lims.assign(n + 1, 0);
+            for (size_t i = 0; i < n; ++i) out->lims[i + 1] = out->lims[i] + counts[i];
+            out->labels.resize(out->lims[n]);
+            out->distances.resize(out->lims[n]);
+            return svsx_range_storage{out->labels.data(), out->distances.data()};
+        };
+        check(svsx_range_search(h_, queries, dtype_of<Q>(), nq, radius, &p, is_member.empty() ? nullptr : is_member.data(), allocate, &r));
+        if (r.lims.empty()) r.lims.assign(nq + 1, 0);
+        return r;
+    }
+    // VamanaIndex::get_distance(id, query) (index/vamana/index.h:915-933; runtime/vamana_index.h:94-96)
+    template <typename Q> double get_distance(size_t id, const Q* query) const {
+        double d = 0.0;
+        check(svsx_get_distance(h_, id, query, dtype_of<Q>(), &d));
+        return d;
+    }
     const svsx_index* handle() const { return h_; }
     size_t size() const { uint64_t info[6]; check(svsx_index_info(h_, info)); return info[0]; }
 

@@ -222,8 +222,29 @@ float svso_distance(int metric, const void* a, int adt, const void* b, int bdt, 
         if (metric == SVSO_COS) return m / (sqrtf(nb) * a_norm); /* cosine.h:334-335 */
         return m;
     }
-    if (status) *status = -1;
-    return NAN;
+    /* Everything else -- the six (query, data) pairs utils/search_index.cpp:147-162 offers that have no AVX-512 specialisation: int8 x uint8,
+     * int8 x float, int8 x float16, uint8 x int8, uint8 x float, uint8 x float16 -- is answered by the reference's scalar loops generic_l2
+     * (euclidean.h:206-215), generic_ip (inner_product.h:167-176), generic_cosine_similarity (cosine.h:185-200): one float accumulator in
+     * element order.  They are instantiated through L2Impl<..>::compute etc. (SVS_NOINLINE, euclidean.h:217-223) in the kernel translation unit,
+     * which cmake/multi-arch.cmake builds with -march=cascadelake and GCC's default -ffp-contract=fast: `result += temp * temp` is ONE fma there.
+     * PARITY UNPINNED: these headers cannot be compiled here (euclidean.h -> lib/saveload.h -> toml++), so that reading is taken from the build
+     * files, not from a run; tests/test_contraction_choices.py holds inputs on which the other reading gives other bits. */
+    {
+        float result = 0.0f, accum = 0.0f;
+        for (size_t i = 0; i < d; ++i) {
+            const float ai = load_as_float(a, adt, i), bi = load_as_float(b, bdt, i);
+            if (metric == SVSO_L2) {
+                const float temp = ai - bi;
+                result = fmaf(temp, temp, result);
+            } else {
+                if (metric == SVSO_COS) accum = fmaf(bi, bi, accum);
+                result = fmaf(ai, bi, result);
+            }
+        }
+        if (status) *status = 1; /* answered by the scalar loop */
+        if (metric == SVSO_COS) return result / (a_norm * sqrtf(accum)); /* cosine.h:199 */
+        return result;
+    }
 }
 
 int svso_distance_batch(int metric, const void* a, int adt, size_t na, const void* b, int bdt, size_t nb, size_t d, float* out) {
@@ -235,7 +256,7 @@ int svso_distance_batch(int metric, const void* a, int adt, size_t na, const voi
         for (size_t j = 0; j < nb; ++j) {
             int st;
             out[i * nb + j] = svso_distance(metric, ai, adt, (const char*)b + j * d * sb, bdt, d, an, &st);
-            if (st) return st;
+            if (st < 0) return st;
         }
     }
     return 0;
@@ -548,7 +569,7 @@ static int greedy_search_core(
         int st = 0;
         if (!ix->sq_enabled) {
             (void)svso_distance(ix->metric, fq.q, fq.q_dtype, ix->data, ix->data_dtype, 0, 1.0f, &st);
-            if (st) { free(fq.owned); return -1; }
+            if (st < 0) { free(fq.owned); return -1; }
         }
     }
     float* scratch = NULL;

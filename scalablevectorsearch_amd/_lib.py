@@ -66,6 +66,15 @@ def _aux_init(self, *a, **kw):
 SearchAux.__init__ = _aux_init
 
 
+class RangeStorage(C.Structure):
+    """svsx_range_storage: what the results allocator of svsx_range_search hands back (runtime SearchResultsStorage, api_defs.h:194-197)."""
+
+    _fields_ = [("labels", C.c_void_p), ("distances", C.c_void_p)]
+
+
+RESULTS_ALLOCATOR = C.CFUNCTYPE(RangeStorage, C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t)
+
+
 class BuildParams(C.Structure):
     """svsx_build_params (index/vamana/build_params.h:28-75)."""
 
@@ -83,7 +92,7 @@ EXPORTS = [
     "svsx_last_kernel_info", "svsx_search_filtered", "svsx_search_filtered_ex", "svsx_vamana_build_device", "svsx_find_medoid_device",
     "svsx_sharded_unique_id", "svsx_sharded_create", "svsx_sharded_create_with_comm", "svsx_sharded_destroy", "svsx_sharded_info",
     "svsx_sharded_search_device", "svsx_abi_version", "svsx_flat_search_device_counted", "svsx_flat_search",
-    "svsx_index_refresh_row_norms", "svsx_index_drop_row_norms",
+    "svsx_index_refresh_row_norms", "svsx_index_drop_row_norms", "svsx_range_search", "svsx_get_distance",
 ]
 
 _lib = None
@@ -124,8 +133,6 @@ def lib() -> C.CDLL:
         L.svsx_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_create_device_view.argtypes = [C.POINTER(DeviceIndexDesc), C.POINTER(C.c_void_p)]
         L.svsx_index_destroy.argtypes = [C.c_void_p]
-        L.svsx_index_refresh_row_norms.argtypes = [C.c_void_p, C.c_void_p]
-        L.svsx_index_drop_row_norms.argtypes = [C.c_void_p]
         L.svsx_index_destroy.restype = None
         L.svsx_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams),
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SearchAux)]
@@ -151,6 +158,14 @@ def lib() -> C.CDLL:
         L.svsx_index_build_bound_codes.argtypes = [C.c_void_p, C.c_int]
         L.svsx_search_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.svsx_search_filtered_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(SearchParams), C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        try:  # entry points added within ABI 3 (round 5): an older build of the library (SVSX_LIB=variants/...: A/B timing) simply lacks them
+            L.svsx_index_refresh_row_norms.argtypes = [C.c_void_p, C.c_void_p]
+            L.svsx_index_drop_row_norms.argtypes = [C.c_void_p]
+            L.svsx_range_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.POINTER(SearchParams), C.c_void_p, RESULTS_ALLOCATOR, C.c_void_p]
+            L.svsx_get_distance.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        except AttributeError:
+            if not os.environ.get("SVSX_LIB"):
+                raise
         L.svsx_vamana_build_device.argtypes = [C.c_void_p, C.POINTER(BuildParams), C.c_void_p]
         L.svsx_find_medoid_device.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.svsx_sharded_unique_id.argtypes = [C.c_void_p]

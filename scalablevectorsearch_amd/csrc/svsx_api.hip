@@ -1465,6 +1465,40 @@ int svsx_flat_search_device_counted(
     return SVSX_SUCCESS;
 }
 
+int svsx_get_distance(const svsx_index* ix, uint64_t id, const void* query, int q_dtype, double* distance) {
+    if (int rc = check_search_args(ix, query, q_dtype, 1, 1, false)) return rc;
+    if (!distance) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    const uint64_t local = id - ix->id_offset;
+    if (id < ix->id_offset || local >= ix->n) // index/vamana/index.h:916-919
+        return fail(SVSX_INVALID_ARGUMENT, "ID %llu is out of bounds for index of size %zu!", static_cast<unsigned long long>(id), static_cast<size_t>(ix->n));
+    const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
+    if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d%s) pair", q_dtype, ix->data_dtype, ix->sq_enabled ? ", SQ" : "");
+    HIP_TRY(hipSetDevice(ix->device));
+    CallStream cs;
+    HIP_TRY(cs.create());
+    const size_t q_row = ix->d * dtype_size(q_dtype);
+    StreamBuffer dq, dc, di, dd;
+    HIP_TRY(dq.alloc(q_row, cs.s));
+    HIP_TRY(dc.alloc(8, cs.s));
+    HIP_TRY(di.alloc(8, cs.s));
+    HIP_TRY(dd.alloc(4, cs.s));
+    HIP_TRY(hipMemcpyAsync(dq.p, query, q_row, hipMemcpyHostToDevice, cs.s));
+    HIP_TRY(hipMemcpyAsync(dc.p, &local, 8, hipMemcpyHostToDevice, cs.s));
+    // one query, one candidate: the exact-order re-rank kernel of the flat search is the index's distance kernel applied to chosen rows
+    RerankArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.data = ix->d_data; ra.row_bytes = ix->row_bytes; ra.d = static_cast<uint32_t>(ix->d); ra.sq_scale = ix->sq_scale; ra.sq_bias = ix->sq_bias;
+    ra.id_offset = ix->id_offset; ra.queries = dq.p; ra.q_row_bytes = q_row; ra.q_dtype = q_dtype; ra.nq = 1; ra.kk = 1; ra.k = 1;
+    ra.cand_ids = static_cast<const uint64_t*>(dc.p); ra.ids64 = static_cast<uint64_t*>(di.p); ra.dists = static_cast<float*>(dd.p);
+    const hipError_t e = launch_rerank(ix->data_dtype, ix->metric, qmode, ra, cs.s);
+    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "distance kernel launch failed: %s", hipGetErrorString(e));
+    float f = 0.0f;
+    HIP_TRY(hipMemcpyAsync(&f, dd.p, 4, hipMemcpyDeviceToHost, cs.s));
+    HIP_TRY(hipStreamSynchronize(cs.s));
+    *distance = static_cast<double>(f);
+    return SVSX_SUCCESS;
+}
+
 int svsx_prune_device(
     const svsx_index* ix, const int32_t* d_node_ids, const int32_t* d_pool_ids, const float* d_pool_dists, size_t n_nodes,
     size_t pool_size, size_t max_out, float alpha, int32_t* d_out, size_t out_stride, void* hip_stream
@@ -1962,6 +1996,98 @@ extern "C" int svsx_search_filtered_ex(
     for (size_t lo = 0; lo < heavy.size(); lo += per_group) {
         std::vector<size_t> grp(heavy.begin() + lo, heavy.begin() + std::min(heavy.size(), lo + per_group));
         if (int rc = run_group(grp, 0, nullptr)) return rc;
+    }
+    return SVSX_SUCCESS;
+}
+
+// Runtime VamanaIndex::range_search (bindings/cpp/src/vamana_index_impl.h:220-326) inside the library: every query owns a BatchIterator that is
+// advanced in batches of max(window, 10); a query ends at its first out-of-range neighbour or when its iterator is done.  All queries of a group
+// advance together (one launch per round); a query whose buffer would outgrow the group's budget (a radius that takes in a large part of the
+// index) is replayed in a small group of its own -- its rounds depend on nothing but its own results.
+extern "C" int svsx_range_search(
+    const svsx_index* ix, const void* queries, int q_dtype, size_t nq, float radius, const svsx_search_params* params,
+    const uint64_t* id_bitmap, svsx_results_allocator allocate, void* user
+) {
+    if (int rc = check_search_args(ix, queries, q_dtype, nq, 1)) return rc;
+    if (!(radius > 0.0f)) return fail(SVSX_INVALID_ARGUMENT, "radius must be greater than 0"); // vamana_index_impl.h:227-230
+    if (!allocate) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    if (nq == 0) return SVSX_SUCCESS;
+    const size_t sws = params ? params->search_window_size : 0;
+    const size_t batch = std::max<size_t>(sws, 10); // :271-274
+    const size_t q_row = ix->d * dtype_size(q_dtype);
+    const bool greater = ix->metric != M_L2;         // svs::distance::comparator: std::less for L2, std::greater for inner product / cosine
+    std::vector<std::vector<std::pair<uint64_t, float>>> found(nq);
+    auto run_group = [&](const std::vector<size_t>& qidx, size_t cap_limit, std::vector<size_t>* postponed) -> int {
+        const size_t m = qidx.size();
+        std::vector<unsigned char> qbuf(m * q_row);
+        for (size_t i = 0; i < m; ++i) memcpy(&qbuf[i * q_row], static_cast<const unsigned char*>(queries) + qidx[i] * q_row, q_row);
+        svsx_batch_iterator* it = nullptr;
+        if (int rc = svsx_iterator_create(ix, qbuf.data(), q_dtype, m, ~size_t(0), &it)) return rc;
+        std::vector<char> active(m, 1);
+        std::vector<size_t> grown(m, 0);
+        std::vector<uint32_t> per_query(m), counts(m), meta(m * 8);
+        std::vector<uint64_t> b_ids(m * batch);
+        std::vector<float> b_dists(m * batch);
+        int rc = SVSX_SUCCESS;
+        size_t n_active = m;
+        while (n_active > 0 && rc == SVSX_SUCCESS) {
+            for (size_t i = 0; i < m; ++i) {
+                if (active[i] && postponed != nullptr && grown[i] + batch > cap_limit) {
+                    found[qidx[i]].clear();
+                    postponed->push_back(qidx[i]);
+                    active[i] = 0;
+                    --n_active;
+                }
+                if (active[i]) grown[i] += batch;
+                per_query[i] = active[i] ? static_cast<uint32_t>(batch) : 0xFFFFFFFFu;
+            }
+            if (n_active == 0) break;
+            rc = svsx_iterator_next(it, batch, per_query.data(), b_ids.data(), b_dists.data(), counts.data());
+            if (rc != SVSX_SUCCESS) break;
+            rc = svsx_iterator_state(it, meta.data());
+            if (rc != SVSX_SUCCESS) break;
+            for (size_t i = 0; i < m; ++i) {
+                if (!active[i]) continue;
+                bool in_range = true;
+                for (size_t j = 0; j < counts[i]; ++j) {
+                    const float dd = b_dists[i * batch + j];
+                    in_range = greater ? dd > radius : dd < radius;
+                    if (!in_range) break; // the iterator's results are ordered by distance (:291-293)
+                    const uint64_t id = b_ids[i * batch + j];
+                    const uint64_t local = id - ix->id_offset;
+                    if (id_bitmap == nullptr || (local < ix->n && ((id_bitmap[local >> 6] >> (local & 63)) & 1ull))) found[qidx[i]].emplace_back(id, dd);
+                }
+                const bool done = meta[i * 8 + 4] == ix->n || (meta[i * 8 + 6] & 2u) != 0u;
+                if (!in_range || done) {
+                    active[i] = 0;
+                    --n_active;
+                }
+            }
+        }
+        svsx_iterator_destroy(it);
+        return rc;
+    };
+    constexpr size_t kBudgetEntries = size_t(128) << 20;
+    std::vector<size_t> all(nq), heavy;
+    for (size_t i = 0; i < nq; ++i) all[i] = i;
+    const size_t cap_limit = std::min<size_t>(ix->n + batch, std::max<size_t>(kBudgetEntries / nq, 1024));
+    if (int rc = run_group(all, cap_limit, &heavy)) return rc;
+    const size_t per_group = std::max<size_t>(1, kBudgetEntries / std::max<size_t>(ix->n, 1));
+    for (size_t lo = 0; lo < heavy.size(); lo += per_group) {
+        std::vector<size_t> grp(heavy.begin() + lo, heavy.begin() + std::min(heavy.size(), lo + per_group));
+        if (int rc = run_group(grp, 0, nullptr)) return rc;
+    }
+    std::vector<size_t> result_counts(nq);
+    size_t total = 0;
+    for (size_t i = 0; i < nq; ++i) total += (result_counts[i] = found[i].size());
+    const svsx_range_storage st = allocate(user, result_counts.data(), nq);
+    if (total != 0 && (!st.labels || !st.distances)) return fail(SVSX_INVALID_ARGUMENT, "the results allocator returned no storage for %zu results", total);
+    for (size_t q = 0, ofs = 0; q < nq; ++q) {
+        for (const auto& [id, dd] : found[q]) {
+            st.labels[ofs] = id;
+            st.distances[ofs] = dd;
+            ++ofs;
+        }
     }
     return SVSX_SUCCESS;
 }

@@ -252,6 +252,13 @@ hipError_t launch_set_word(int* d_word, int value, hipStream_t stream) {
     return hipGetLastError();
 }
 
+__global__ void add_word_kernel(uint32_t* w, uint32_t v) { atomicAdd(w, v); }
+
+hipError_t launch_add_word(uint32_t* d_word, uint32_t value, hipStream_t stream) {
+    hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, stream, d_word, value);
+    return hipGetLastError();
+}
+
 float pca_key_to_float(uint32_t k) {
     const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
     float f;

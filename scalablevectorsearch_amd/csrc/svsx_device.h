@@ -37,6 +37,18 @@ template <typename To, typename From> __device__ __forceinline__ To bit_cast_(Fr
     return __builtin_bit_cast(To, v);
 }
 
+// The wave mask of a predicate.  HIP's __ballot goes through an integer compare of the zero-extended predicate (v_cndmask 0 / 1 + v_cmp_ne per
+// call: two vector instructions for a mask that already sits in a scalar register pair); the builtin is the mask itself.  The search kernel
+// takes ~12 ballots per expansion and is bound by the vector ALU's issue slots while the machine is full.
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// tell the compiler that a 64-bit value is the same in every lane (folds away when it already knows)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(v))));
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(v >> 32))));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 // quad-local lane exchange through DPP (no LDS traffic): lane ^ 1 and lane ^ 2.
 // (every lane of the wave is active wherever these are used, and a quad permutation never reads out of bounds, so the `old` operand is
 // never seen: mov_dpp leaves it undefined, which spares the v_mov 0 that update_dpp(0, ...) costs per exchange)
@@ -335,7 +347,7 @@ __device__ __forceinline__ void float_row_distance(
                             rejected = true;
                             active = false; // no further loads for this group
                         }
-                        if (__ballot(active) == 0ull) break;
+                        if (wave_ballot(active) == 0ull) break;
                     }
                 }
             }
@@ -446,7 +458,7 @@ __device__ __forceinline__ float l2_row_distance_two_phase(
     const float partial = reduce_slots<E>(p); // identical on all lanes of the group
     rejected = partial > thr;
     const bool need = active && !rejected;
-    if (__ballot(need) == 0ull) return __builtin_inff();
+    if (wave_ballot(need) == 0ull) return __builtin_inff();
     if constexpr (NB64 > 4) { // d = 128: the second 64-block continues the four accumulators before the combine
         float x[4][E];
 #pragma unroll
@@ -627,6 +639,91 @@ __device__ __forceinline__ void float_row_distance_bc(
     if constexpr (METRIC == M_COS) out_nrm = tree(n);
     else out_nrm = 0.0f;
 }
+
+// Block-cyclic mapping on EIGHT lanes per row (round 5; 8-bit rows of a static dimension that is a multiple of 64: the 768-byte rows of config 4).
+// Lane (j = sub & 3, h = sub >> 2) owns lane-slots 8h .. 8h + 7 of the accumulator vector s_j and streams the 16-element blocks 4t + j: eight
+// bytes per block, so ALL loads of a row (DS / 64 x 8 bytes per lane: 24 registers at d = 768) are in flight before the first use -- the
+// four-lane form keeps four 16-byte loads in flight and pays three dependent HBM round trips per 768-byte row, the largest term of config 4's
+// phase profile (profiles/r05_notes.md) -- and a pass of 8 rows costs half the vector instructions of a pass of 16, which matters when an
+// expansion leaves ~9 candidates per adjacency chunk.  Arithmetic: every lane-slot is its own fma chain over t (acc_step, the reference's
+// operation order), (s0 + s1) + (s2 + s3) across j by the same two quad exchanges, then the reduce tree t[e] = v[e + 8] + v[e] (the partner
+// half sits four lanes up: one row shift), u, w, sum lane-local -- operation for operation float_row_distance_bc, same bits.
+template <int CTRL> __device__ __forceinline__ float add_dpp(float v) {
+    return opaque_f(v + bit_cast_<float>(__builtin_amdgcn_mov_dpp(bit_cast_<int>(v), CTRL, 0xf, 0xf, true)));
+}
+
+// the row's loads (all of them) and the arithmetic are separate calls: the search kernel requests the rows of pass p + 1 before it computes
+// pass p (Bc8Row<DS> = the 8-byte pieces of one lane)
+template <int DS> struct Bc8Row { uint2 raw[DS >> 6]; };
+
+template <int DS> __device__ __forceinline__ Bc8Row<DS> bc8_load(const unsigned char* __restrict__ row, int sub) {
+    static_assert(DS >= 64 && (DS & 63) == 0, "whole 64-element blocks");
+    const unsigned char* lane_row = row + 16 * (sub & 3) + 8 * (sub >> 2);
+    Bc8Row<DS> r;
+#pragma unroll
+    for (int t = 0; t < (DS >> 6); ++t) r.raw[t] = *reinterpret_cast<const uint2*>(lane_row + 64 * t); // inactive groups read row 0
+    return r;
+}
+
+template <int DT, int METRIC, int DS, bool DECOMP>
+__device__ __forceinline__ void bc8_compute(const Bc8Row<DS>& r, const float* __restrict__ qf, int sub, float sq_scale, float sq_bias, float& out_main, float& out_nrm) {
+    static_assert(DT == DT_I8 || DT == DT_U8, "8-bit rows");
+    constexpr int N64 = DS >> 6;
+    const float* lane_q = qf + 16 * (sub & 3) + 8 * (sub >> 2);
+    float s[8], n[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.0f; n[e] = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < N64; ++t) {
+#pragma unroll
+        for (int g4 = 0; g4 < 2; ++g4) {
+            const float4 qv = *reinterpret_cast<const float4*>(lane_q + 64 * t + 4 * g4);
+            const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            const uint32_t w = g4 == 0 ? r.raw[t].x : r.raw[t].y;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t byte = (w >> (8 * b)) & 0xFFu;
+                float xv;
+                if constexpr (DT == DT_I8) xv = static_cast<float>(static_cast<int>(static_cast<int8_t>(byte)));
+                else xv = static_cast<float>(byte);
+                if constexpr (DECOMP) {
+                    const float tt = sq_scale * xv;
+                    xv = tt + sq_bias;
+                }
+                acc_step<METRIC>(s[4 * g4 + b], n[4 * g4 + b], q[b], xv);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { // (s0 + s1) + (s2 + s3): j = lane & 3, two quad exchanges
+        s[e] = add_xor2f(add_xor1f(s[e]));
+        if constexpr (METRIC == M_COS) n[e] = add_xor2f(add_xor1f(n[e]));
+    }
+    auto tree = [](float (&v)[8]) -> float {
+        float t[8], u[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = add_dpp<0x104>(v[e]); // row_shl:4 -- lane i takes lane i + 4: v[e + 8] + v[e] in the h = 0 lanes (the others are not used)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = t[e + 4] + t[e];
+        const float w0 = u[0] + u[2];
+        const float w1 = u[1] + u[3];
+        return w0 + w1;
+    };
+    out_main = tree(s);
+    if constexpr (METRIC == M_COS) out_nrm = tree(n);
+    else out_nrm = 0.0f;
+}
+
+template <int DT, int METRIC, int DS, bool DECOMP>
+__device__ __forceinline__ void float_row_distance_bc8(
+    const unsigned char* __restrict__ row, const float* __restrict__ qf, int sub, float sq_scale, float sq_bias, float& out_main, float& out_nrm
+) {
+    const Bc8Row<DS> r = bc8_load<DS>(row, sub);
+    bc8_compute<DT, METRIC, DS, DECOMP>(r, qf, sub, sq_scale, sq_bias, out_main, out_nrm);
+}
+
+// Which 8-bit float-path kernels take the eight-lane mapping
+template <int DT, int DS> constexpr bool use_bc8() { return (DT == DT_I8 || DT == DT_U8) && DS >= 256 && (DS & 63) == 0; }
 
 #ifndef SVSX_F16_BLOCK_CYCLIC
 #define SVSX_F16_BLOCK_CYCLIC 1
@@ -908,8 +1005,8 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
         // compares per entry cost 5 % of the bench kernel.)
         const bool dnan = d != d;
         const bool same = (v0 && (d0 == d || dnan) && ((e0.y ^ id) & idmask) == 0u) || (v1 && (d1 == d || dnan) && ((e1.y ^ id) & idmask) == 0u);
-        const unsigned long long m0 = __ballot(bf0), m1 = __ballot(bf1);
-        if (__ballot(same) != 0ull) return false;
+        const unsigned long long m0 = wave_ballot(bf0), m1 = wave_ballot(bf1);
+        if (wave_ballot(same) != 0ull) return false;
         const uint32_t pos = static_cast<uint32_t>(__popcll(m0) + __popcll(m1)); // sorted: the "before" entries are a prefix
         buf_order(b);
         if (v0 && i0 >= pos) b.e[i0 + 1u] = e0;
@@ -930,9 +1027,9 @@ __device__ __forceinline__ bool wave_insert(WaveBuffer& b, float d, uint32_t id,
         if (valid) en = b.e[i];
         const float ed = __uint_as_float(en.x);
         const bool before = valid && !cmpf<GREATER>(d, ed);
-        const unsigned long long m = __ballot(before);
+        const unsigned long long m = wave_ballot(before);
         const bool same = valid && (ed == d || d != d) && (((en.y ^ id) & idmask) == 0u); // ids only among the entries equal to d (all, if d is NaN)
-        dup = dup || (__ballot(same) != 0ull);
+        dup = dup || (wave_ballot(same) != 0ull);
         const uint32_t cnt = __popcll(m);
         pos += cnt;
         const uint32_t nvalid = (b.size - base) < 64u ? (b.size - base) : 64u;
@@ -981,8 +1078,8 @@ template <int EPL> __device__ __forceinline__ void wave_buffer_prefetch(const Wa
 }
 
 template <bool GREATER, int EPL>
-__device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted, float& worst_out,
-                                                  const uint2* pre = nullptr) {
+__device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, unsigned long long cand_mask, bool cand, float dist, uint32_t id, uint32_t lane, uint32_t& n_inserted,
+                                                  float& worst_out, const uint2* pre = nullptr) { // cand_mask: the wave mask of `cand`
     // EPL buffer entries per lane (capacity <= 64 EPL).  Written to stay off the scalar unit (one SALU issue slot per CU per
     // cycle is the scarce resource of this kernel): no boolean mask algebra -- validity is folded into sentinel values, counters
     // advance with carry-in adds, the tie rule of the candidate ranks is one 64-bit compare of (order key, lane).
@@ -1012,7 +1109,7 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     const unsigned long long mykey = (static_cast<unsigned long long>(key) << 32) | lane;
     uint32_t rank = 0, minpos = 0xFFFFFFFFu;
     int oldle = 0;
-    unsigned long long m = __ballot(cand);
+    unsigned long long m = cand_mask;
     const uint32_t ncand = static_cast<uint32_t>(__popcll(m));
     while (m != 0ull) { // 9 vector instructions per candidate (the VALU issue port bounds this kernel)
         const int bl = __builtin_ctzll(m);
@@ -1024,7 +1121,7 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
         for (int t = 0; t < EPL; ++t) {
             const bool lt = cmpf<GREATER>(dj, dv[t]);
             c[t] += lt ? 1u : 0u;
-            after += static_cast<uint32_t>(__popcll(__ballot(lt)));
+            after += static_cast<uint32_t>(__popcll(wave_ballot(lt)));
         }
         const uint32_t le = 64u * EPL - after; // old entries that stay before j (empty slots always count as "after")
         const unsigned long long kjl = (static_cast<unsigned long long>(kj) << 32) | static_cast<uint32_t>(bl);
@@ -1041,13 +1138,9 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     // duplicate needs an old entry of EQUAL distance, and the last old entry that stays before candidate j -- index le_j - 1 -- is one if
     // any is.  One lane-parallel LDS read per pass instead of an id compare per candidate and entry; any tie sends the pass down the
     // sequential path, which does the exact id walk.
-    {
-        bool tie = false;
-        if (cand && oldle > 0) {
-            const float prev = __uint_as_float(b.e[oldle - 1].x);
-            tie = prev == dist;
-        }
-        if (__ballot(tie) != 0ull) return false;
+    {   // every lane reads (lanes without a candidate: entry 0); the three single compares meet as masks
+        const float prev = __uint_as_float(b.e[oldle > 0 ? oldle - 1 : 0].x);
+        if ((wave_ballot(prev == dist) & wave_ballot(oldle > 0) & cand_mask) != 0ull) return false;
     }
     buf_order(b);
 #pragma unroll
@@ -1059,7 +1152,7 @@ __device__ __forceinline__ bool wave_merge_insert(WaveBuffer& b, bool cand, floa
     const bool placed = cand && pn < b.capacity;
     if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
     buf_order(b);
-    n_inserted += static_cast<uint32_t>(__popcll(__ballot(placed)));
+    n_inserted += static_cast<uint32_t>(__popcll(cand_mask & wave_ballot(pn < b.capacity)));
     b.size = (b.size + ncand < b.capacity) ? b.size + ncand : b.capacity;
     b.best_unvisited = minpos < b.best_unvisited ? minpos : b.best_unvisited;
     // the entry that ended at position capacity - 1: read back after the writes above (LDS is in order within a wave); the caller uses it
@@ -1087,7 +1180,7 @@ __device__ __forceinline__ bool wave_merge_insert2(WaveBuffer& b, bool cand, flo
     constexpr float kPast = GREATER ? -__builtin_inff() : __builtin_inff(); // no candidate compares better than an empty slot
     uint2* cs = reinterpret_cast<uint2*>(scratch);
     uint32_t* le_s = scratch + 32;
-    const unsigned long long cm = __ballot(cand);
+    const unsigned long long cm = wave_ballot(cand);
     const uint32_t m = static_cast<uint32_t>(__popcll(cm));
     if (m > 16u) return false; // more candidates than scratch slots (cannot happen: 64 / G <= 16 rows per pass)
     const uint32_t slot = prefix_count(cm);
@@ -1123,14 +1216,14 @@ __device__ __forceinline__ bool wave_merge_insert2(WaveBuffer& b, bool cand, flo
         const unsigned long long kjl = (static_cast<unsigned long long>(cj.y) << 32) | j;
         rank += kjl < mykey ? 1u : 0u; // candidates before mine: better, or equal and earlier in adjacency order
     }
-    if (__ballot(tieacc == 0u) != 0ull) return false;
+    if (wave_ballot(tieacc == 0u) != 0ull) return false;
     // le[r] for r in [c_{i-1}, c_i) is i: written by the lane that owns entry i (usually one r, at most m)
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
         const int carry = t == 0 ? 0 : __builtin_amdgcn_readlane(static_cast<int>(c[t - 1]), 63); // entry 64 t - 1 lives in lane 63
         uint32_t r = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(carry, static_cast<int>(c[t]), 0x138, 0xf, 0xf, false)); // wave_shr:1
         const uint32_t i = lane + 64u * t;
-        while (__ballot(r < c[t]) != 0ull) {
+        while (wave_ballot(r < c[t]) != 0ull) {
             if (r < c[t]) le_s[r] = i;
             ++r;
         }
@@ -1149,7 +1242,7 @@ __device__ __forceinline__ bool wave_merge_insert2(WaveBuffer& b, bool cand, flo
     const bool placed = cand && pn < b.capacity;
     if (placed) b.e[pn] = make_uint2(__float_as_uint(dist), id);
     buf_order(b);
-    n_inserted += static_cast<uint32_t>(__popcll(__ballot(placed)));
+    n_inserted += static_cast<uint32_t>(__popcll(wave_ballot(placed)));
     b.size = (old_size + m < b.capacity) ? old_size + m : b.capacity;
     b.best_unvisited = minpos < b.best_unvisited ? minpos : b.best_unvisited;
     if (b.size == b.capacity) {
@@ -1168,7 +1261,7 @@ __device__ __forceinline__ bool wave_merge_insert2(WaveBuffer& b, bool cand, flo
             wv = dist;
             hit = true;
         }
-        const unsigned long long hm = __ballot(hit);
+        const unsigned long long hm = wave_ballot(hit);
         if (hm != 0ull) worst_out = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), __builtin_ctzll(hm)));
         else worst_out = __uint_as_float(b.e[b.capacity - 1].x); // not reached: exactly one entry ends there
     }
@@ -1194,7 +1287,7 @@ __device__ __forceinline__ uint32_t wave_next(WaveBuffer& b, uint32_t lane, floa
     buf_order(b);
     node_dist = __uint_as_float(en.x);
     {
-        const unsigned long long m = __ballot(nb + lane < upper && (flag & kVisitedBit) == 0u);
+        const unsigned long long m = wave_ballot(nb + lane < upper) & wave_ballot(static_cast<int>(flag) >= 0); // bit 31 = visited
         if (m != 0ull) nb += static_cast<uint32_t>(__builtin_ctzll(m));
         else nb += 64;
         if (m == 0ull) {
@@ -1202,7 +1295,7 @@ __device__ __forceinline__ uint32_t wave_next(WaveBuffer& b, uint32_t lane, floa
                 const uint32_t i = nb + lane;
                 bool unvisited = false;
                 if (i < upper) unvisited = (b.e[i].y & kVisitedBit) == 0u;
-                const unsigned long long m2 = __ballot(unvisited);
+                const unsigned long long m2 = wave_ballot(unvisited);
                 if (m2 != 0ull) {
                     nb += static_cast<uint32_t>(__builtin_ctzll(m2));
                     break;
@@ -1212,7 +1305,9 @@ __device__ __forceinline__ uint32_t wave_next(WaveBuffer& b, uint32_t lane, floa
         }
     }
     b.best_unvisited = nb < upper ? nb : upper;
-    return en.y & kIdMask;
+    // every lane read the same entry: say so (the block address, the chunk loop's bound and everything after them then stay in scalar registers;
+    // left to the uniformity analysis, an LDS read is a per-lane value and the whole expansion turns into exec-masked vector code)
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(en.y & kIdMask)));
 }
 
 __device__ __forceinline__ bool wave_done(const WaveBuffer& b) {
@@ -1265,7 +1360,7 @@ __device__ __noinline__ void wave_std_sort(WaveBuffer& b, uint2* stack, uint32_t
             const uint32_t i = base + lane;
             bool t = false;
             if (i + 1 < n) t = b.e[i].x == b.e[i + 1].x || __uint_as_float(b.e[i].x) == __uint_as_float(b.e[i + 1].x);
-            tie = tie || (__ballot(t) != 0ull);
+            tie = tie || (wave_ballot(t) != 0ull);
         }
         if (!tie) return;
     }

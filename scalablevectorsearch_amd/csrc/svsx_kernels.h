@@ -200,6 +200,7 @@ hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t 
                             uint8_t* d_class_scratch, uint32_t degshift, hipStream_t stream);
 float pca_key_to_float(uint32_t key);
 hipError_t launch_set_word(int* d_word, int value, hipStream_t stream); // one agent-scope store (cancellation)
+hipError_t launch_add_word(uint32_t* d_word, uint32_t value, hipStream_t stream); // *d_word += value (counters)
 // name of the search_kernel instantiation launch_search picked last on this thread (tests assert which one ran)
 const char* last_search_instantiation();
 

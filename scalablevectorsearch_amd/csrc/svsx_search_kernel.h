@@ -60,7 +60,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
     // windows 513 .. 1024 with 128-byte records (config 4 at recall >= 0.9): 143 VGPRs instead of 181, no scratch -> 3 waves per SIMD instead of 2
     if (DS == 768 && BIG == 2 && CODES == 4 && (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS)) return 3;
     if (DS == 768 && BIG <= 1) { // config 4 and its inner-product sibling
-        if (QMODE == QM_SQ_IP) return BIG == 1 ? 4 : 5;
+        if (QMODE == QM_SQ_IP) return 4; // (5 before the passes were pipelined: the rows of the next pass now wait in 24 registers)
         if (QMODE == QM_SQ_COS) return SVSX_SQCOS_FLOOR;
     }
     return 0;
@@ -89,7 +89,11 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     constexpr int FDC = RW * 16 - (METRIC == M_L2 ? 4 : 6);       // coded coordinates per record
     constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     constexpr bool B8 = !INTPATH && use_block_cyclic<DT>();  // 8-bit rows on the float path: block-cyclic mapping
-    constexpr int G = (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
+#ifndef SVSX_BC8
+#define SVSX_BC8 1
+#endif
+    constexpr bool BC8 = SVSX_BC8 != 0 && B8 && !GENERAL && use_bc8<DT, DS>(); // 8-bit rows of a long static dimension: eight lanes per row (float_row_distance_bc8)
+    constexpr int G = BC8 ? 8 : (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
     constexpr int RPP = 64 / G;                        // rows per pass
 
     const uint32_t lane = threadIdx.x;
@@ -117,10 +121,11 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     uint8_t* filt8 = reinterpret_cast<uint8_t*>(filt);
     const bool tag8 = a.filter_tag8 != 0u;
     const uint32_t filt_bytes = a.filter_entries * (tag8 ? 1u : 2u);
-    uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids
+    uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids; inline-record kernels: one slot per adjacency slot
+    const uint32_t compact_bytes = FAT ? ((a.gstride + 63u) & ~63u) * 4u : 256u;
     // FAT: the query's own record codes; 32-byte records keep them in SGPRs afterwards, so the 128 bytes alias the compaction scratch
-    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + (CODES >= 3 ? 256u : 0u));
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + 256u + (CODES >= 3 ? 128u : 0u)); // GENERAL only
+    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + (CODES >= 3 ? compact_bytes : 0u));
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + compact_bytes + (CODES >= 3 ? 128u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -350,7 +355,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         if constexpr (TWO_PHASE && CODES == 0) { // survivors of the bound codes are close to the worst entry: fetch whole rows
             bool rejected = false;
             const float dd = l2_row_distance_two_phase<DT, (DS > 64 && DS <= 128 && (DS & 15) == 0) ? DS : 96>(row, active, qf, sub, thr, rejected);
-            n_early += __popcll(__ballot(active && rejected && sub == 0));
+            n_early += __popcll(wave_ballot(active && rejected && sub == 0));
             return dd;
         } else if constexpr (QMODE == QM_FLOAT && METRIC == M_L2 && DT == DT_F32 && (DS == 0 || (CODES == 0 && DS > 64))) {
             // runtime dimension, and the plain static kernels of more than one 64-block that the two-phase form does not cover (100, 160, 200,
@@ -358,7 +363,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             // it the static forms were 8-13 % slower than round 2's runtime-d kernel on the same graphs (profiles/r03_notes.md section 8)
             bool rejected = false;
             float_row_distance<DT, METRIC, 0, false, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm, thr, &rejected);
-            n_early += __popcll(__ballot(active && rejected && sub == 0));
+            n_early += __popcll(wave_ballot(active && rejected && sub == 0));
             return fmain;
         } else if constexpr (INTPATH) {
             int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
@@ -375,8 +380,11 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 }
             }
             const float bn = a.sq_row_norm[active ? cid : 0u]; // requested with the row
-            float_row_distance_bc<DT, M_IP, DS, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+            if constexpr (BC8) float_row_distance_bc8<DT, M_IP, DS, true>(row, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+            else float_row_distance_bc<DT, M_IP, DS, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
             return fmain / (bn * fx.norm); // cosine.h:334-335
+        } else if constexpr (BC8) {
+            float_row_distance_bc8<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         } else if constexpr (B8) {
             float_row_distance_bc<DT, METRIC, DS, QMODE == QM_SQ_COS>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
         } else {
@@ -398,7 +406,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             const bool act = ci < a.n_entry;
             const uint32_t cid = act ? a.entry[ci] : 0u;
             const float dist = group_distance(cid, act, __builtin_inff(), NoHook{});
-            unsigned long long m = __ballot(act && sub == 0);
+            unsigned long long m = wave_ballot(act && sub == 0);
             while (m != 0ull) {
                 const int bl = __builtin_ctzll(m);
                 m &= m - 1ull;
@@ -419,7 +427,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         const uint32_t i = i0 + lane;
                         bool before = false;
                         if (i < buf.size) before = !cmpf<GREATER>(dd, __uint_as_float(buf.e[i].x));
-                        pos += __popcll(__ballot(before));
+                        pos += __popcll(wave_ballot(before));
                     }
                     buf_order(buf);
                     for (int i = static_cast<int>(buf.size) - 1; i >= static_cast<int>(pos); --i) {
@@ -443,7 +451,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 if (!buf.hbm) buf.e[i] = en;
                 nan_seen = nan_seen || __uint_as_float(en.x) != __uint_as_float(en.x);
             }
-            nan_seen = __ballot(nan_seen) != 0ull; // a NaN left in the buffer by an earlier call
+            nan_seen = wave_ballot(nan_seen) != 0ull; // a NaN left in the buffer by an earlier call
             buf_order(buf);
             wave_std_sort<GREATER>(buf, sort_stack, lane, true);
         } else if (append_then_sort) {
@@ -485,31 +493,63 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         }
         ++n_exp;
         const uint32_t* grow = a.graph + static_cast<size_t>(node) * a.gstride;
-        for (uint32_t gbase = 0; gbase < (FAT ? slot_limit : a.gstride); gbase += 64) {
+        [[maybe_unused]] uint32_t fat_total = 0; // inline records: survivors of the chunks so far (they share compact[])
+        // One loop for both kernel families: a chunk of the adjacency row (load, bound, filter, compaction), then the distance passes.
+        // Inline-record kernels go round the chunk part until the row is exhausted and run their passes ONCE, over compact[0 .. cnt) = the
+        // survivors of all chunks in adjacency order.  (A two-chunk row -- R = 128 -- used to run its passes chunk by chunk: two half-empty
+        // passes where one would do.  The bound of the second chunk is now taken against a `worst` that the first chunk's inserts have not
+        // improved yet, which only makes it reject less.)  Other kernels: passes after every chunk, lane c of `nid` holds candidate c.
+        // (Written as one loop, not as a lambda called from two places: with the buffer state captured by reference the uniformity analysis
+        // gave up on it and the expansion turned into exec-masked vector code, +30 % vector instructions.)
+        uint32_t gbase = 0;
+        const uint32_t row_slots = FAT ? slot_limit : a.gstride;
+        // one contiguous block per chunk of <= 64 slots: [ids | plane 0 | ... | plane RW-1]; lane c owns neighbour c and its record.  Lanes beyond
+        // the node's last group of 8 slots repeat that group's last lane (same lines: no request of their own, no exec mask, no zero fill)
+        // and are turned into empty slots.  (A lambda that only reads what it captures: see the note on lambdas above.)
+        [[maybe_unused]] uint32_t nid_next = kInvalidId;
+        [[maybe_unused]] uint4 rec_next[RW];
+        [[maybe_unused]] auto fat_load = [&](const uint32_t base, uint32_t& out_id, uint4 (&out_rec)[RW]) {
+            const uint32_t cs = (a.gstride - base) < 64u ? (a.gstride - base) : 64u;
+            const uint32_t lim = (slot_limit - base) < cs ? (slot_limit - base) : cs; // >= 1
+            const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(base) * (4u + 16u * RW));
+            const uint4* planes = reinterpret_cast<const uint4*>(fids + cs);
+            const uint32_t ll = opaque_u(lane); // lane-derived offsets are recomputed here, not kept across the distance pass (opaque_u)
+            const uint32_t li = ll < lim ? ll : lim - 1u;
+            const uint32_t w = fids[li];
+#pragma unroll
+            for (int p = 0; p < RW; ++p) out_rec[p] = planes[static_cast<uint32_t>(p) * cs + li];
+            out_id = ll < lim ? w : kInvalidId;
+        };
+        // (8-bit rows only: the float32 / float16 kernels of d = 96 / 128 sit at their 80-register bracket and would spill the nine registers)
+        constexpr bool NEXT_CHUNK = FAT && (DT == DT_I8 || DT == DT_U8) && RW <= 4; // (128-byte records: 33 registers, spills at the 5-wave floor)
+        if constexpr (NEXT_CHUNK) {
+            if (row_slots != 0u) fat_load(0u, nid_next, rec_next);
+        }
+        while (gbase < row_slots) {
+            uint32_t cnt;
+            bool last_chunk;
             uint32_t nid = kInvalidId;
             [[maybe_unused]] uint4 rec[RW];
             if constexpr (FAT) {
-                // one contiguous block per chunk: [ids | plane 0 | ... | plane RW-1]; lane c owns neighbour c and its record.  Lanes beyond
-                // the node's last group of 8 slots repeat that group's last lane (same lines: no request of their own, no exec mask, no
-                // zero fill) and are turned into empty slots afterwards.
-                const uint32_t cs = (a.gstride - gbase) < 64u ? (a.gstride - gbase) : 64u;
-                const uint32_t lim = (slot_limit - gbase) < cs ? (slot_limit - gbase) : cs; // >= 1
-                const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(gbase) * (4u + 16u * RW));
-                const uint4* planes = reinterpret_cast<const uint4*>(fids + cs);
-                const uint32_t ll = opaque_u(lane); // lane-derived offsets are recomputed here, not kept across the distance pass (opaque_u)
-                const uint32_t li = ll < lim ? ll : lim - 1u;
-                nid = fids[li];
+                // this chunk's block was requested one trip earlier (or before the loop); the next chunk's -- the degree class says whether
+                // the row has one -- is requested now, so a two-chunk row (R = 128) pays one memory round trip for its blocks, not two
+                if constexpr (NEXT_CHUNK) {
+                    nid = nid_next;
 #pragma unroll
-                for (int p = 0; p < RW; ++p) rec[p] = planes[static_cast<uint32_t>(p) * cs + li];
-                nid = ll < lim ? nid : kInvalidId;
+                    for (int p = 0; p < RW; ++p) rec[p] = rec_next[p];
+                    if (gbase + 64u < row_slots) fat_load(gbase + 64u, nid_next, rec_next);
+                } else {
+                    fat_load(gbase, nid, rec);
+                }
             } else {
                 if (gbase + lane < a.gstride) nid = grow[gbase + lane];
             }
-            const uint32_t deg_here = __popcll(__ballot(nid != kInvalidId)); // ids are packed from slot 0
+            const unsigned long long valid_m = wave_ballot(nid != kInvalidId);
+            const uint32_t deg_here = __popcll(valid_m); // ids are packed from slot 0
             SVSX_PHASE_USE(deg_here);
             SVSX_PHASE_STAMP(2);
             n_slots += deg_here;
-            uint32_t cnt = deg_here;
+            cnt = deg_here;
             if constexpr (FAT) {
                 bool keep = nid != kInvalidId;
                 // visited filter (greedy_search.h:191-193), here holding only the ids whose rows were really fetched: a candidate the
@@ -521,6 +561,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 // every lane reads its slot (an empty adjacency slot hashes to the table's last entry): no exec-masked branch in front of the
                 // bound, whose arithmetic then runs under the LDS round trip instead of after it
                 // (also when the filter is off: the table then has no entries and slot 0 aliases the compaction scratch -- the value is ignored)
+                unsigned long long km;
                 const uint32_t fseen = static_cast<uint32_t>(filt[a.filter_entries != 0u ? fh : 0u]);
                 __builtin_amdgcn_sched_barrier(0); // the read stays in front of the bound's arithmetic (the scheduler otherwise sinks it to its use)
                 {
@@ -529,6 +570,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     // whether or not the buffer is full (`rej` counts only when it is): without a branch the filter's LDS read above and
                     // the second record plane are awaited under this arithmetic, not in front of it.
                     bool rej;
+                    unsigned long long rej_m; // wave mask of the ONE compare that decides (see wave_ballot: masks are combined in scalar registers)
                     constexpr int NW = RW * 4;  // words per record; the last one holds float16 fields
                     auto recw = [&](int w) -> uint32_t {
                         const uint4& r = rec[w >> 2];
@@ -568,6 +610,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         const float bb = (t > 0.0f ? t : 0.0f) * 0.99999f;
                         const float rhs = wp - bb * bb + e * (r2 + e) * 1.00001f;
                         rej = fi * fat_s2m > rhs; // false for NaN / inf thresholds
+                        rej_m = wave_ballot(fi * fat_s2m > rhs);
                     } else {
                         // q . z <= s^2 I + ||uhat|| ex + eq (ny + ex) + tq tx,  I = sum cq cx (exact);  all record fields are upper bounds
                         int dot = 0;
@@ -589,20 +632,25 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                             ub += static_cast<float>(d + 2) * 6.1e-8f * fat_nq * (ny + ex + tx + a.pca_ref_extra);
                         }
                         rej = ub < worst; // false whenever anything is NaN / inf
+                        rej_m = wave_ballot(ub < worst);
                     }
                     rej = rej && full;
+                    rej_m = full ? rej_m : 0ull;
                     keep = keep && !(use_filter && fseen == ftag);
-                    const uint32_t nrej = __popcll(__ballot(keep && rej));
-                    n_code_rej += nrej;
-                    n_eval += nrej;
+                    const unsigned long long live_m = valid_m & ~(use_filter ? wave_ballot(fseen == ftag) : 0ull); // what the reference would evaluate
+                    if (a.stats != nullptr) { // counters only
+                        const uint32_t nrej = __popcll(live_m & rej_m);
+                        n_code_rej += nrej;
+                        n_eval += nrej;
+                    }
                     keep = keep && !rej;
+                    km = live_m & ~rej_m; // == the wave mask of `keep`
                 }
                 if (use_filter && keep) filt[fh] = static_cast<uint16_t>(ftag);
-                const unsigned long long km = __ballot(keep);
                 cnt = __popcll(km);
                 const uint32_t rank = prefix_count(km);
                 lds_order();
-                if (keep) compact[rank] = nid;
+                if (keep) compact[fat_total + rank] = nid;
                 lds_order();
                 // the passes below read compact[pass base + group] themselves: one LDS round trip per pass instead of a read-back here
                 // plus a cross-lane permute per pass
@@ -620,7 +668,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         filt[h] = static_cast<uint16_t>(tag);
                     }
                 }
-                const unsigned long long km = __ballot(keep);
+                const unsigned long long km = wave_ballot(keep);
                 cnt = __popcll(km);
                 const uint32_t rank = prefix_count(km);
                 lds_order();
@@ -686,7 +734,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         const float t = (sthr + ex) * tscale;
                         const bool rej = isum > t * t * 1.00001f; // false for NaN / inf thresholds
                         const bool surv = act && !rej && sub == 0;
-                        const unsigned long long sm = __ballot(surv);
+                        const unsigned long long sm = wave_ballot(surv);
                         if (surv) compact[nsurv + prefix_count(sm)] = cid;
                         nsurv += __popcll(sm);
                     }
@@ -699,31 +747,84 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     cnt = nsurv;
                 }
             }
+            last_chunk = deg_here < 64u || gbase + 64u >= row_slots;
+            gbase += 64u;
+            if constexpr (FAT) {
+                fat_total += cnt;
+                if (!last_chunk) continue;
+                cnt = fat_total;
+            }
             SVSX_PHASE_USE(cnt);
             SVSX_PHASE_STAMP(3);
+            // Eight-lane 8-bit rows with inline records (config 4): the rows of pass p + 1 are requested before pass p is computed -- the list of
+            // candidates is fixed for the expansion (compact[]), so the requests do not depend on the inserts in between -- and a pass waits
+            // for memory only where the arithmetic and the merge of the pass before it were shorter than the round trip.
+            constexpr bool PIPE = BC8 && FAT && (QMODE == QM_SQ_COS || QMODE == QM_SQ_IP);
+            [[maybe_unused]] Bc8Row<(BC8 ? DS : 64)> row_next;
+            [[maybe_unused]] uint32_t cid_next = 0u;
+            [[maybe_unused]] float bn_next = 0.0f;
+            [[maybe_unused]] auto pipe_request = [&](const uint32_t base) { // reads only (see the note on lambdas above)
+                const uint32_t cj = base + grp;
+                cid_next = compact[cj];
+                const uint32_t rj = cj < cnt ? (cid_next & idmask) : 0u;
+                row_next = bc8_load<(BC8 ? DS : 64)>(data + static_cast<size_t>(rj) * static_cast<uint32_t>(a.row_bytes), sub);
+                if constexpr (QMODE == QM_SQ_COS) bn_next = a.sq_row_norm[rj];
+            };
+            if constexpr (PIPE) {
+                if (cnt != 0u) pipe_request(0u);
+            }
             for (uint32_t p0 = 0; p0 < cnt; p0 += RPP) {
-                const uint32_t ci = p0 + grp; // <= 63: p0 is a multiple of RPP below cnt <= 64
+                const uint32_t ci = p0 + grp; // < round_up(cnt, RPP) <= the slots of the row
                 uint32_t cid; // the word that goes into the buffer (inline records: id | degree class)
-                if constexpr (FAT) cid = compact[ci];
+                if constexpr (PIPE) cid = cid_next;
+                else if constexpr (FAT) cid = compact[ci];
                 else cid = static_cast<uint32_t>(__shfl(static_cast<int>(nid), static_cast<int>(ci)));
                 const bool act = ci < cnt;
                 const uint32_t rid = FAT ? (cid & idmask) : cid; // the row it names
+                [[maybe_unused]] float pipe_dist = 0.0f;
+                [[maybe_unused]] uint2 pre_big[8];
+                [[maybe_unused]] bool pre_big_valid = false;
+                if constexpr (PIPE) {
+                    const Bc8Row<(BC8 ? DS : 64)> row_cur = row_next;
+                    const float bn_cur = bn_next;
+                    if (p0 + RPP < cnt) pipe_request(p0 + RPP);
+                    if constexpr (BIG == 1 && !GENERAL) { // the merge's entries (up to 8 per lane: buffers of 129 .. 512) arrive under the arithmetic
+                        wave_buffer_prefetch<8>(buf, lane, pre_big);
+                        pre_big_valid = true;
+                    }
+                    float fmain = 0.0f, fnrm = 0.0f;
+                    if constexpr (QMODE == QM_SQ_COS) {
+                        bc8_compute<DT, M_IP, (BC8 ? DS : 64), true>(row_cur, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+                        pipe_dist = fmain / (bn_cur * fx.norm); // cosine.h:334-335
+                    } else {
+                        bc8_compute<DT, METRIC, (BC8 ? DS : 64), false>(row_cur, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+                        pipe_dist = finish_distance<METRIC, QMODE>(fmain, fnrm, 0, 0, fx, a.sq_scale);
+                    }
+                }
                 // buffers of up to 128 entries: the two entries per lane the merge insert of this pass starts from are requested inside the
                 // distance routine, just before its cross-lane reduction (nothing writes the buffer in between)
                 constexpr bool PREFETCH = !GENERAL && BIG == 0 && SVSX_MERGE_V2 == 0;
                 [[maybe_unused]] uint2 pre[2];
                 [[maybe_unused]] bool pre_valid = false;
-                const float dist = group_distance(rid, act, full ? worst * 1.00004f : __builtin_inff(), [&]() {
-                    if constexpr (PREFETCH) {
-                        if (buf.capacity <= 128u) {
-                            wave_buffer_prefetch<2>(buf, lane, pre);
-                            pre_valid = true;
+                float dist;
+                if constexpr (PIPE) {
+                    dist = pipe_dist;
+                } else {
+                    dist = group_distance(rid, act, full ? worst * 1.00004f : __builtin_inff(), [&]() {
+                        if constexpr (PREFETCH) {
+                            if (buf.capacity <= 128u) {
+                                wave_buffer_prefetch<2>(buf, lane, pre);
+                                pre_valid = true;
+                            }
                         }
-                    }
-                });
+                    });
+                }
                 const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
                 const bool cand = act && sub == 0 && !skip;
-                unsigned long long m = __ballot(cand);
+                // the wave mask of `cand`, combined in scalar registers from the masks of its single compares
+                constexpr unsigned long long kFirstOfGroup = G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
+                unsigned long long m = wave_ballot(ci < cnt) & kFirstOfGroup & ~(full ? wave_ballot(cmpf<GREATER>(worst, dist)) : 0ull);
+                m = uniform_u64(m); // a wave mask is uniform by construction; said explicitly, the buffer state derived from it stays in scalar registers
                 SVSX_PHASE_USE(m);
                 SVSX_PHASE_STAMP(4);
                 n_eval += (cnt - p0) < static_cast<uint32_t>(RPP) ? (cnt - p0) : static_cast<uint32_t>(RPP);
@@ -732,7 +833,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     // entries (possible when the visited filter is off or evicted) take the one-by-one path below
                     if (m != 0ull && buf.capacity <= (BIG == 2 ? 1024u : BIG == 1 ? 512u : 128u)) {
                         // one test for NaN and +-inf candidates: either sends the pass down the sequential path, which keeps `nan_seen`
-                        const bool finite = __ballot(cand && !(__builtin_fabsf(dist) < __builtin_inff())) == 0ull;
+                        const bool finite = (m & wave_ballot(!(__builtin_fabsf(dist) < __builtin_inff()))) == 0ull;
                         bool merged = false;
                         if (!nan_seen && finite) {
 #if SVSX_MERGE_V2
@@ -746,13 +847,16 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                             }
 #else
                             if constexpr (BIG == 2) {
-                                merged = wave_merge_insert<GREATER, 16>(buf, cand, dist, cid, lane, n_ins, worst);
+                                merged = wave_merge_insert<GREATER, 16>(buf, m, cand, dist, cid, lane, n_ins, worst);
                             } else if constexpr (BIG == 1) {
-                                if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, cand, dist, cid, lane, n_ins, worst);
-                                else if (buf.capacity <= 384u) merged = wave_merge_insert<GREATER, 6>(buf, cand, dist, cid, lane, n_ins, worst);
-                                else merged = wave_merge_insert<GREATER, 8>(buf, cand, dist, cid, lane, n_ins, worst);
+                                // entries per lane: the loop over the candidates costs two vector instructions per entry register and candidate
+                                if (buf.capacity <= 192u) merged = wave_merge_insert<GREATER, 3>(buf, m, cand, dist, cid, lane, n_ins, worst, pre_big_valid ? pre_big : nullptr);
+                                else if (buf.capacity <= 256u) merged = wave_merge_insert<GREATER, 4>(buf, m, cand, dist, cid, lane, n_ins, worst, pre_big_valid ? pre_big : nullptr);
+                                else if (buf.capacity <= 320u) merged = wave_merge_insert<GREATER, 5>(buf, m, cand, dist, cid, lane, n_ins, worst, pre_big_valid ? pre_big : nullptr); // config 4's window 285
+                                else if (buf.capacity <= 384u) merged = wave_merge_insert<GREATER, 6>(buf, m, cand, dist, cid, lane, n_ins, worst, pre_big_valid ? pre_big : nullptr);
+                                else merged = wave_merge_insert<GREATER, 8>(buf, m, cand, dist, cid, lane, n_ins, worst, pre_big_valid ? pre_big : nullptr);
                             } else {
-                                merged = wave_merge_insert<GREATER, 2>(buf, cand, dist, cid, lane, n_ins, worst, pre_valid ? pre : nullptr);
+                                merged = wave_merge_insert<GREATER, 2>(buf, m, cand, dist, cid, lane, n_ins, worst, pre_valid ? pre : nullptr);
                             }
 #endif
                         }
@@ -776,7 +880,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 SVSX_PHASE_USE(buf.best_unvisited);
                 SVSX_PHASE_STAMP(5);
             }
-            if (deg_here < 64u) break;
+            if constexpr (FAT) break; // the passes ran over all chunks: nothing (the next-chunk registers included) lives past this point
+            else if (last_chunk) break;
         }
     }
 
@@ -803,7 +908,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 const uint32_t id = valid ? (en.y & kIdMask) : kInvalidId;
                 bool fresh = valid;
                 for (uint32_t y0 = 0; y0 < n_old; y0 += 64) {
-                    if (__ballot(fresh) == 0ull) break;
+                    if (wave_ballot(fresh) == 0ull) break;
                     uint32_t yv = kInvalidId;
                     if (y0 + lane < n_old) yv = yl[y0 + lane];
                     for (int t = 0; t < 64; ++t) {
@@ -811,7 +916,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         fresh = fresh && (v != id);
                     }
                 }
-                const unsigned long long fm = __ballot(fresh);
+                const unsigned long long fm = wave_ballot(fresh);
                 const uint32_t rank = got + prefix_count(fm);
                 if (fresh && rank < it_bs) {
                     a.it_out_ids[static_cast<size_t>(qi) * a.it_batch + rank] = static_cast<uint64_t>(id) + a.id_offset;
@@ -904,7 +1009,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       64 * 4 /* compaction / merge scratch */ + (CODES >= 3 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
+                       (CODES >= 2 ? ((static_cast<size_t>(a.gstride) + 63) & ~size_t(63)) * 4 : 64 * 4) /* compaction / merge scratch */ + (CODES >= 3 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #ifdef SVSX_DIAG
     size_t lds_request = lds;

@@ -153,6 +153,15 @@ class VamanaIndex:
                 self.refresh_row_norms(cur.cuda_stream)
         return self
 
+    def get_distance(self, id: int, query) -> float:
+        """VamanaIndex::get_distance (index/vamana/index.h:915-933): the index's own distance between stored vector `id` and `query`."""
+        q = np.ascontiguousarray(np.asarray(query).reshape(-1))
+        if q.shape[0] != self.d:
+            raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Incompatible dimensions. Query has {q.shape[0]} while the index expects {self.d}.")
+        out = C.c_double()
+        _lib.check(_lib.lib().svsx_get_distance(self._h, int(id), q.ctypes.data, dtype_code(q), C.byref(out)))
+        return out.value
+
     def refresh_row_norms(self, stream: int = 0) -> None:
         """Recompute the per-row norms of a scalar-quantized cosine index on `stream` (after rewriting rows of a device view)."""
         _lib.check(_lib.lib().svsx_index_refresh_row_norms(self._h, C.c_void_p(stream)))

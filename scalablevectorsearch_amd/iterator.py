@@ -253,6 +253,30 @@ def range_search(index, queries, radius: float, search_parameters: VamanaSearchP
     queries = np.ascontiguousarray(np.atleast_2d(queries))
     nq = queries.shape[0]
     sp = search_parameters or index.get_search_parameters()
+    if make_iterator is None and extra_search_buffer_capacity is None and hasattr(index, "_h"):
+        # the library's own loop (svsx_range_search, include/svsx.h); the Python loop below is its mirror and runs over any iterator class
+        import ctypes as C
+
+        from .index import dtype_code
+
+        out = {}
+
+        def allocate(_user, counts, n):
+            c = np.array([counts[i] for i in range(n)], np.int64)
+            out["lims"] = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
+            out["labels"] = np.empty(int(c.sum()), np.uint64)
+            out["distances"] = np.empty(int(c.sum()), np.float32)
+            return _lib.RangeStorage(out["labels"].ctypes.data, out["distances"].ctypes.data)
+
+        bitmap = None
+        if is_member is not None:
+            bits = np.zeros((index.size() + 63) // 64 * 64, np.uint8)
+            bits[: index.size()] = np.asarray(is_member, dtype=bool)[: index.size()]
+            bitmap = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64)
+        spc = sp._c()
+        _lib.check(_lib.lib().svsx_range_search(index._h, queries.ctypes.data, dtype_code(queries), nq, float(radius), C.byref(spc),
+                                               None if bitmap is None else bitmap.ctypes.data, _lib.RESULTS_ALLOCATOR(allocate), None))
+        return out["lims"], out["labels"], out["distances"]
     batch = max(sp.buffer_config.get_search_window_size(), 10)
     greater = int(index.distance.metric) != 0
     it = (make_iterator or BatchIterator)(index, queries, extra_search_buffer_capacity)

@@ -60,6 +60,18 @@ int main(int argc, char**) {
             index2.search(filtered.view(), q2.data(), sp2, std::span<const uint64_t>(even.data(), even.size()));
             std::printf("filtered: %zu %zu %zu %zu\n", filtered.index(0, 0), filtered.index(0, 1), filtered.index(0, 2), filtered.index(0, 3));
             if (!(filtered.index(0, 0) == 40 && filtered.index(0, 1) == 42 && filtered.index(0, 2) == 38 && filtered.index(0, 3) == 44)) return 13;
+            {   // runtime range_search / get_distance through the C ABI (svsx_range_search, svsx_get_distance): points within radius 2.5^2 + slack of x = 40.2
+                const auto rr = index2.range_search(q2.data(), 1, 7.0f, sp2);
+                std::printf("range: %zu results\n", rr.labels.size());
+                if (rr.lims.size() != 2 || rr.lims[1] != rr.labels.size() || rr.labels.empty() || rr.labels[0] != 40) return 15;
+                for (size_t j = 0; j < rr.labels.size(); ++j) {
+                    if (!(rr.distances[j] < 7.0f)) return 16;
+                    if (static_cast<float>(index2.get_distance(rr.labels[j], q2.data())) != rr.distances[j]) return 17;
+                }
+                const auto rf = index2.range_search(q2.data(), 1, 7.0f, sp2, std::span<const uint64_t>(even.data(), even.size()));
+                for (const uint64_t id : rf.labels) if (id & 1u) return 18;
+                if (rf.labels.empty() || rf.labels.size() >= rr.labels.size()) return 19;
+            }
             // VamanaIndex::calibrate (search-buffer part, calibrate.h:249-343): exact top-4 by brute force as the groundtruth, target recall 1
             std::vector<std::pair<float, size_t>> all;
             for (size_t i = 0; i < n2; ++i) {

@@ -502,13 +502,23 @@ def test_cancel_flag_device_and_host(svs, oracle, small_world):
     assert (hid == full).all()
 
 
-def test_flat_search_k_limit(svs):
+def test_flat_search_beyond_the_shortlist_limits(svs, oracle):
+    """FlatIndex::search (flat.h:322-460) bounds neither k nor the dimension: what the float16 shortlist pipeline cannot hold in LDS -- k > 224, or
+    64 float16 queries of d >= ~1 200 -- is answered by the exhaustive float32 pass alone (round 5; before: SVSX_INVALID_ARGUMENT)."""
     x = deep_like(500, 32, 8, seed=3)
     f = svs.FlatIndex(x, svs.DistanceL2())
     assert f.search(x[:4], 224).indices.shape == (4, 224)
-    with pytest.raises(svs.SvsxError) as e:
-        f.search(x[:4], 225)
-    assert e.value.code == 2 and "k <= 224" in e.value.message
+    for k in (225, 400, 500):
+        res = f.search(x[:6], k)
+        ids, dists = oracle.flat_search(L2, x, x[:6], k)
+        assert (res.indices == ids.astype(np.uint64)).all(), k
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all(), k
+    xw = deep_like(300, 1536, 16, seed=4)   # 64 queries x 1 536 float16 = 192 KB: more than a wave's LDS
+    fw = svs.FlatIndex(xw, svs.DistanceIP())
+    res = fw.search(xw[:5], 10)
+    ids, dists = oracle.flat_search(IP, xw, xw[:5], 10)
+    assert (res.indices == ids.astype(np.uint64)).all()
+    assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
 
 
 def test_gpu_builder_at_scale_against_the_oracle_builder(svs, oracle):

@@ -221,10 +221,23 @@ def test_range_and_filtered_search_on_gpu(svs, oracle, small_world):
     fake = _FakeIndex(oracle, L2, sw["x"], sw["graph"], sw["entry"], window=20)
     member = (np.arange(sw["x"].shape[0]) % 3) == 0
     for radius in (0.9, 1.1):
-        a = svs.range_search(idx, q, radius, is_member=member)
-        b = svs.range_search(fake, q, radius, is_member=member, make_iterator=_OracleBatchIterator)
-        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (_bits(a[2]) == _bits(b[2])).all()
-        assert a[0][-1] > 0
+        for mem in (member, None):
+            a = svs.range_search(idx, q, radius, is_member=mem)                                      # svsx_range_search: the loop inside the library
+            a2 = svs.range_search(idx, q, radius, is_member=mem, make_iterator=svs.BatchIterator)    # the Python mirror over the library's iterator
+            b = svs.range_search(fake, q, radius, is_member=mem, make_iterator=_OracleBatchIterator)  # the Python mirror over the oracle's iterator
+            for r in (a, a2):
+                assert (r[0] == b[0]).all() and (r[1] == b[1]).all() and (_bits(r[2]) == _bits(b[2])).all()
+            assert a[0][-1] > 0
+    with pytest.raises(svs.SvsxError):
+        svs.range_search(idx, q, 0.0)
+    # VamanaIndex::get_distance (index.h:915-933): the value a search reports for that row, bit for bit
+    res = idx.search(q, 5, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
+    for i in range(4):
+        for j in range(5):
+            dd = idx.get_distance(int(res.indices[i, j]), q[i])
+            assert np.float32(dd).view(np.uint32) == res.distances[i, j].view(np.uint32)
+    with pytest.raises(svs.SvsxError):
+        idx.get_distance(sw["x"].shape[0], q[0])
     for k, stop in ((10, 0.0), (25, 0.0), (10, 0.5)):
         a = svs.filtered_search(idx, q, k, member, filter_stop=stop, filter_estimate_batch=False)
         b = svs.filtered_search(fake, q, k, member, filter_stop=stop, make_iterator=_OracleBatchIterator, filter_estimate_batch=False)
