@@ -1067,6 +1067,9 @@ def main():
             # both numbers next to each other: the measured ratio uses the CPUs the cgroup grants; a fully used host under LINEAR scaling
             # (an upper bound for a memory-bound graph search) would shrink it by cores_present / cores
             cb["gpu_over_full_host_if_linear"] = cb["gpu_over_cpu"] * cb["cores"] / max(cb["cores_present"], 1)
+            cb["full_host_note"] = (f"MEASURED: {cb['cores']} threads (the container's CPU quota) of {cb['cores_present']} logical CPUs.  gpu_over_full_host_if_linear is an "
+                                    "EXTRAPOLATION (the measured rate scaled linearly to every CPU of the host), not a measurement: the north star's >= 10x "
+                                    "over the host CPU is established only against the CPUs this container may use")
             cm = cpu_baseline(sh["x"], q, sh["graph"], sh["entry"], R, k, matched["window"], ids_matched)
             matched["cpu_qps"] = cm["value"]
             matched["cpu_cores"] = cm["cores"]

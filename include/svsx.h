@@ -321,14 +321,14 @@ int svsx_search_filtered_ex(
  * is advanced in batches of max(search_window_size, 10); its results come in distance order, every one closer than `radius` (svs::distance
  * comparator of the index's metric: < for L2, > for inner product / cosine) and -- with a filter -- a member of it is kept, and the query ends at
  * its first out-of-range neighbour or when the iterator is done.  All queries advance together, one kernel launch per round.
- * When the counts are known `allocate(user, counts, nq)` is called ONCE (ResultsAllocator::allocate, api_defs.h:194-207) and must return
- * storage for sum(counts) labels and distances; they are filled query by query, in the order found (labels are global ids, id_offset included).
+ * When the counts are known `allocate(user, counts, nq, &storage)` is called ONCE (ResultsAllocator::allocate, api_defs.h:194-207) and must hand
+ * back storage for sum(counts) labels and distances; they are filled query by query, in the order found (labels are global ids, id_offset included).
  * id_bitmap: NULL = no filter, else bit i of (n + 63) / 64 words = IDFilter::is_member(i), local ids.  Host pointers, synchronous. */
 typedef struct {
     uint64_t* labels;
     float* distances;
 } svsx_range_storage;
-typedef svsx_range_storage (*svsx_results_allocator)(void* user, const size_t* result_counts, size_t nq);
+typedef void (*svsx_results_allocator)(void* user, const size_t* result_counts, size_t nq, svsx_range_storage* out); /* fills *out (an out-parameter: callable from ctypes / cgo / JNI) */
 int svsx_range_search(
     const svsx_index* index, const void* queries, int q_dtype, size_t nq, float radius, const svsx_search_params* params,
     const uint64_t* id_bitmap, svsx_results_allocator allocate, void* user

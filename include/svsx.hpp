@@ -235,13 +235,13 @@ template <typename T, typename Dist> class VamanaIndex {
                              sp.search_buffer_visited_set_ ? 1 : 0, sp.prefetch_lookahead_, sp.prefetch_step_};
         if (!is_member.empty() && is_member.size() * 64 < size()) throw ANNException(SVSX_INVALID_ARGUMENT, "is_member must hold one bit per vector");
         RangeResult r;
-        auto allocate = [](void* user, const size_t* counts, size_t n) -> svsx_range_storage {
+        auto allocate = [](void* user, const size_t* counts, size_t n, svsx_range_storage* storage) {
             auto* out = static_cast<RangeResult*>(user);
             out->lims.assign(n + 1, 0);
             for (size_t i = 0; i < n; ++i) out->lims[i + 1] = out->lims[i] + counts[i];
             out->labels.resize(out->lims[n]);
             out->distances.resize(out->lims[n]);
-            return svsx_range_storage{out->labels.data(), out->distances.data()};
+            *storage = svsx_range_storage{out->labels.data(), out->distances.data()};
         };
         check(svsx_range_search(h_, queries, dtype_of<Q>(), nq, radius, &p, is_member.empty() ? nullptr : is_member.data(), allocate, &r));
         if (r.lims.empty()) r.lims.assign(nq + 1, 0);

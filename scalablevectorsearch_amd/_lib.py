@@ -72,7 +72,7 @@ class RangeStorage(C.Structure):
     _fields_ = [("labels", C.c_void_p), ("distances", C.c_void_p)]
 
 
-RESULTS_ALLOCATOR = C.CFUNCTYPE(RangeStorage, C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t)
+RESULTS_ALLOCATOR = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(RangeStorage))
 
 
 class BuildParams(C.Structure):

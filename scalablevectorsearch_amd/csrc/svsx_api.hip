@@ -107,8 +107,8 @@ namespace {
 size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : dt == DT_F16 ? 2 : (dt == DT_I8 || dt == DT_U8) ? 1 : 0; }
 
 // Which kernel family serves (query dtype, data dtype) -- the reference's AVX-512 specialisation table
-// (euclidean.h:318-358 and the VNNI pairs :291-313); everything else has only a scalar loop there and is
-// rejected here.
+// (euclidean.h:318-358 and the VNNI pairs :291-313); everything else has only a scalar loop there (generic_l2 and its
+// siblings: utils/search_index.cpp:147-162 offers six such pairs) and takes the scalar-loop kernels here (QM_SCALAR, round 5).
 int select_qmode(int metric, int q_dtype, int data_dtype, int sq_enabled) {
     if (sq_enabled) {
         if (data_dtype != DT_I8 && data_dtype != DT_U8) return -1;
@@ -118,7 +118,7 @@ int select_qmode(int metric, int q_dtype, int data_dtype, int sq_enabled) {
     if ((q_dtype == DT_I8 && data_dtype == DT_I8) || (q_dtype == DT_U8 && data_dtype == DT_U8)) return QM_INT;
     if (q_dtype == DT_F32) return QM_FLOAT;
     if (q_dtype == DT_F16 && (data_dtype == DT_F32 || data_dtype == DT_F16)) return QM_FLOAT;
-    return -1;
+    return QM_SCALAR;
 }
 
 size_t padded_row_bytes(size_t d, int dt) { return ((d + 15) & ~size_t(15)) * dtype_size(dt); }
@@ -237,7 +237,7 @@ int validate_common(int metric, int dtype, size_t n, size_t d) {
 extern "C" {
 
 const char* svsx_last_error(void) { return g_error.c_str(); }
-const char* svsx_version(void) { return "svsx 0.4.0 (gfx950)"; }
+const char* svsx_version(void) { return "svsx 0.5.0 (gfx950)"; }
 int svsx_abi_version(void) { return SVSX_ABI_VERSION; }
 const char* svsx_last_kernel_info(void) { return last_search_instantiation(); }
 
@@ -828,6 +828,8 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
     // scalar-quantized rows under cosine without their precomputed norms (svsx_index_drop_row_norms): the runtime-d kernel variant computes the
     // norm per candidate, the reference's own operation order (same bits, ~14 % slower: profiles/r04_notes.md section 3)
     if (ix->sq_enabled && ix->metric == M_COS && ix->d_sq_row_norm == nullptr) a.general = 1u;
+    // the scalar-loop type pairs exist as the runtime-d variant only; no bound records either (their slack terms are derived for the SIMD tree)
+    if (select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled) == QM_SCALAR) a.general = 1u;
     if (ix->d_codes && !a.general) { // result-neutral lower-bound rejection (float queries on float32 L2 rows)
         a.codes = static_cast<const unsigned char*>(ix->d_codes);
         a.code_scale = ix->code_scale;
@@ -1254,6 +1256,8 @@ int svsx_flat_search_device_counted(
     if (!d_ids64) return fail(SVSX_INVALID_ARGUMENT, "null argument");
     const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
     if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
+    if (qmode == QM_SCALAR)
+        return fail(SVSX_NOT_IMPLEMENTED, "flat search serves the (query, data) type pairs with a SIMD kernel in the reference; (%d, %d) has the scalar loop only: graph search and svsx_distance_batch cover it", q_dtype, ix->data_dtype);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     // FlatIndex::search (index/flat/flat.h:322-460) bounds neither k nor the dimension.  The float16 pipeline below keeps k + 32 <= 256 shortlist
@@ -1477,6 +1481,22 @@ int svsx_get_distance(const svsx_index* ix, uint64_t id, const void* query, int 
     CallStream cs;
     HIP_TRY(cs.create());
     const size_t q_row = ix->d * dtype_size(q_dtype);
+    if (qmode == QM_SCALAR) { // the scalar-loop pairs: the distance plugin kernel on this one row
+        StreamBuffer dq1, dd1;
+        HIP_TRY(dq1.alloc(q_row, cs.s));
+        HIP_TRY(dd1.alloc(4, cs.s));
+        HIP_TRY(hipMemcpyAsync(dq1.p, query, q_row, hipMemcpyHostToDevice, cs.s));
+        DistanceArgs da;
+        da.a = dq1.p; da.b = static_cast<const unsigned char*>(ix->d_data) + local * ix->row_bytes; da.b_row_bytes = ix->row_bytes; da.a_dtype = q_dtype;
+        da.na = 1; da.nb = 1; da.d = static_cast<uint32_t>(ix->d); da.out = static_cast<float*>(dd1.p);
+        const hipError_t e1 = launch_distance(ix->data_dtype, ix->metric, qmode, da, cs.s);
+        if (e1 != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "distance kernel launch failed: %s", hipGetErrorString(e1));
+        float f1 = 0.0f;
+        HIP_TRY(hipMemcpyAsync(&f1, dd1.p, 4, hipMemcpyDeviceToHost, cs.s));
+        HIP_TRY(hipStreamSynchronize(cs.s));
+        *distance = static_cast<double>(f1);
+        return SVSX_SUCCESS;
+    }
     StreamBuffer dq, dc, di, dd;
     HIP_TRY(dq.alloc(q_row, cs.s));
     HIP_TRY(dc.alloc(8, cs.s));
@@ -2080,7 +2100,8 @@ extern "C" int svsx_range_search(
     std::vector<size_t> result_counts(nq);
     size_t total = 0;
     for (size_t i = 0; i < nq; ++i) total += (result_counts[i] = found[i].size());
-    const svsx_range_storage st = allocate(user, result_counts.data(), nq);
+    svsx_range_storage st{nullptr, nullptr};
+    allocate(user, result_counts.data(), nq, &st);
     if (total != 0 && (!st.labels || !st.distances)) return fail(SVSX_INVALID_ARGUMENT, "the results allocator returned no storage for %zu results", total);
     for (size_t q = 0, ofs = 0; q < nq; ++q) {
         for (const auto& [id, dd] : found[q]) {

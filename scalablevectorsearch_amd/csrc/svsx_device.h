@@ -26,7 +26,9 @@ enum : int {
     QM_INT = 1,     // query and data both int8 or both uint8, exact int32 (K5, K6)
     QM_SQ_IP = 2,   // InnerProductCompressed   (quantization/scalar/scalar.h:107-153): float path + scale*ip + bias*sum(q)
     QM_SQ_COS = 3,  // CosineSimilarityCompressed (scalar.h:155-195): decompress on load, then float cosine
-    QM_SQ_L2 = 4    // EuclideanCompressed<T>   (scalar.h:58-105): query compressed to T, scale^2 * int L2
+    QM_SQ_L2 = 4,   // EuclideanCompressed<T>   (scalar.h:58-105): query compressed to T, scale^2 * int L2
+    QM_SCALAR = 5   // type pairs without an AVX-512 specialisation in the reference: its scalar loops generic_l2 / generic_ip /
+                    // generic_cosine_similarity (euclidean.h:206-215, inner_product.h:167-176, cosine.h:185-200), one float accumulator in element order
 };
 
 constexpr uint32_t kInvalidId = 0xFFFFFFFFu;
@@ -877,6 +879,41 @@ __device__ __forceinline__ QueryFix prepare_query(
         }
     }
     return fx;
+}
+
+// The reference's scalar fallback loops (QM_SCALAR): ONE lane owns one row -- a single float accumulator that takes the elements in order
+// cannot be split across lanes -- so a pass evaluates 64 rows.  `result += temp * temp` is one fma: the loops are instantiated in the kernel
+// translation unit, built -march=cascadelake with GCC's default -ffp-contract=fast (DESIGN.md section 2 has the argument; PARITY UNPINNED --
+// the reference header cannot be compiled here).  Rows and the LDS query are zero padded to 16 elements; the padding adds fma(0, 0, x) = x.
+template <int DT, int METRIC>
+__device__ __forceinline__ void scalar_row_distance(const unsigned char* __restrict__ row, const float* __restrict__ qf, int d, float& out_main, float& out_nrm) {
+    float result = 0.0f, accum = 0.0f;
+    const int nb = (d + 15) >> 4;
+    for (int b = 0; b < nb; ++b) {
+        float x[16];
+        BlockRaw<DT> raw;
+#pragma unroll
+        for (int i = 0; i < (16 * Elem<DT>::BYTES) / 16; ++i) raw.v[i] = *reinterpret_cast<const uint4*>(row + 16 * Elem<DT>::BYTES * b + 16 * i); // inactive lanes read row 0
+        block_to_float<DT>(raw, x);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 qv = *reinterpret_cast<const float4*>(qf + 16 * b + 4 * g4); // the same address in every lane: LDS broadcast
+            const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xi = x[4 * g4 + e];
+                if constexpr (METRIC == M_L2) {
+                    const float t = q[e] - xi;
+                    result = __builtin_fmaf(t, t, result);
+                } else {
+                    if constexpr (METRIC == M_COS) accum = __builtin_fmaf(xi, xi, accum);
+                    result = __builtin_fmaf(q[e], xi, result);
+                }
+            }
+        }
+    }
+    out_main = result;
+    out_nrm = accum;
 }
 
 // Final distance value for one candidate from the reduced sums.

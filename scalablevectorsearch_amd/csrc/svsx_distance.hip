@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64) void distance_kernel(const DistanceArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool INTPATH = (QMODE == QM_INT);
     constexpr bool B8 = !INTPATH && use_block_cyclic<DT>();
-    constexpr int G = (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;
+    constexpr int G = QMODE == QM_SCALAR ? 1 : (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;
     constexpr int RPP = 64 / G;
     const uint32_t lane = threadIdx.x;
     const uint32_t qi = blockIdx.x;
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(64) void distance_kernel(const DistanceArgs a) {
         const unsigned char* row = data + static_cast<size_t>(act ? j : 0u) * a.b_row_bytes;
         float fmain = 0.0f, fnrm = 0.0f;
         int ab = 0, bb = 0;
-        if constexpr (INTPATH) int_row_sums<DT>(row, act, qw, d, sub, ab, bb);
+        if constexpr (QMODE == QM_SCALAR) scalar_row_distance<DT, METRIC>(row, qf, d, fmain, fnrm);
+        else if constexpr (INTPATH) int_row_sums<DT>(row, act, qw, d, sub, ab, bb);
         else if constexpr (B8) float_row_distance_bc<DT, METRIC, 0, false>(row, act, qf, d, sub, 1.0f, 0.0f, fmain, fnrm);
         else float_row_distance<DT, METRIC, 0, false>(row, act, qf, d, sub, 1.0f, 0.0f, fmain, fnrm);
         const float r = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, 1.0f);
@@ -71,6 +72,13 @@ hipError_t launch_distance(int b_dtype, int metric, int qmode, const DistanceArg
     } else if (qmode == QM_INT) {
         if (b_dtype == DT_I8) return launch_distance_metric<DT_I8, QM_INT>(metric, a, stream);
         if (b_dtype == DT_U8) return launch_distance_metric<DT_U8, QM_INT>(metric, a, stream);
+    } else if (qmode == QM_SCALAR) {
+        switch (b_dtype) {
+            case DT_F32: return launch_distance_metric<DT_F32, QM_SCALAR>(metric, a, stream);
+            case DT_F16: return launch_distance_metric<DT_F16, QM_SCALAR>(metric, a, stream);
+            case DT_I8: return launch_distance_metric<DT_I8, QM_SCALAR>(metric, a, stream);
+            case DT_U8: return launch_distance_metric<DT_U8, QM_SCALAR>(metric, a, stream);
+        }
     }
     return hipErrorInvalidValue;
 }

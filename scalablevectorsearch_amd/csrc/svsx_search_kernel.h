@@ -93,7 +93,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
 #define SVSX_BC8 1
 #endif
     constexpr bool BC8 = SVSX_BC8 != 0 && B8 && !GENERAL && use_bc8<DT, DS>(); // 8-bit rows of a long static dimension: eight lanes per row (float_row_distance_bc8)
-    constexpr int G = BC8 ? 8 : (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
+    constexpr int G = QMODE == QM_SCALAR ? 1 : BC8 ? 8 : (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
     constexpr int RPP = 64 / G;                        // rows per pass
 
     const uint32_t lane = threadIdx.x;
@@ -365,6 +365,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             float_row_distance<DT, METRIC, 0, false, true>(row, active, qf, d, sub, a.sq_scale, a.sq_bias, fmain, fnrm, thr, &rejected);
             n_early += __popcll(wave_ballot(active && rejected && sub == 0));
             return fmain;
+        } else if constexpr (QMODE == QM_SCALAR) {
+            scalar_row_distance<DT, METRIC>(row, qf, d, fmain, fnrm);
         } else if constexpr (INTPATH) {
             int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
         } else if constexpr (B8 && QMODE == QM_SQ_COS) {
@@ -822,7 +824,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 const bool skip = full && cmpf<GREATER>(worst, dist); // can_skip (search_buffer.h:338-340)
                 const bool cand = act && sub == 0 && !skip;
                 // the wave mask of `cand`, combined in scalar registers from the masks of its single compares
-                constexpr unsigned long long kFirstOfGroup = G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
+                constexpr unsigned long long kFirstOfGroup = G == 1 ? ~0ull : G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
                 unsigned long long m = wave_ballot(ci < cnt) & kFirstOfGroup & ~(full ? wave_ballot(cmpf<GREATER>(worst, dist)) : 0ull);
                 m = uniform_u64(m); // a wave mask is uniform by construction; said explicitly, the buffer state derived from it stays in scalar registers
                 SVSX_PHASE_USE(m);
@@ -1002,7 +1004,8 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
         if (a.capacity > 128u && a.capacity <= 512u) return launch_one<DT, METRIC, QMODE, DB, GENERAL, CODES, 1>(a, stream);
         if (a.capacity > 512u && a.capacity <= 1024u) return launch_one<DT, METRIC, QMODE, DB, GENERAL, CODES, 2>(a, stream);
     }
-    snprintf(last_search_instantiation_buffer(), 96, "search_kernel<dt=%d,metric=%d,qmode=%d,ds=%d,general=%d,codes=%d>", DT, METRIC, QMODE, DS, GENERAL ? 1 : 0, CODES);
+    snprintf(last_search_instantiation_buffer(), 96, "search_kernel<dt=%d,metric=%d,qmode=%d,ds=%d,general=%d,codes=%d>%s", DT, METRIC, QMODE, DS, GENERAL ? 1 : 0, CODES,
+             QMODE == QM_SCALAR ? " scalar loop (parity unpinned)" : "");
     const int d = static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);
@@ -1030,7 +1033,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
 }
 
 template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const SearchArgs& a, hipStream_t stream) {
-    if (a.general) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results
+    if (a.general || QMODE == QM_SCALAR) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results (the scalar-loop pairs have no other variant)
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         // static dimensions: the reference's list (distance_core.h:31-32: 64, 96, 100, 128, 160, 200, 512, 768, Dynamic)
         if (a.fat != nullptr && a.fat_rb == 32) {
@@ -1112,6 +1115,7 @@ template <int DT> static hipError_t launch_search_for_rows(int metric, int qmode
         case QM_SQ_L2:
             if constexpr (DT == DT_I8 || DT == DT_U8) return launch_metric<DT, QM_SQ_L2>(metric, a, stream);
             break;
+        case QM_SCALAR: return launch_metric<DT, QM_SCALAR>(metric, a, stream);
     }
     return hipErrorInvalidValue;
 }

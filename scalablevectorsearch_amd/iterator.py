@@ -261,12 +261,13 @@ def range_search(index, queries, radius: float, search_parameters: VamanaSearchP
 
         out = {}
 
-        def allocate(_user, counts, n):
+        def allocate(_user, counts, n, storage):
             c = np.array([counts[i] for i in range(n)], np.int64)
             out["lims"] = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
             out["labels"] = np.empty(int(c.sum()), np.uint64)
             out["distances"] = np.empty(int(c.sum()), np.float32)
-            return _lib.RangeStorage(out["labels"].ctypes.data, out["distances"].ctypes.data)
+            storage[0].labels = out["labels"].ctypes.data
+            storage[0].distances = out["distances"].ctypes.data
 
         bitmap = None
         if is_member is not None:

@@ -107,7 +107,12 @@ def test_round3_entry_points_check_their_arguments_before_any_device_work(lib):
     ids = np.zeros((1, 1), np.uint64)
     d = np.zeros((1, 1), np.float32)
     assert L.svsx_search_filtered_ex(None, q.ctypes.data, 0, 1, 1, None, None, 0.0, 1, ids.ctypes.data, d.ctypes.data) == lib.NOT_INITIALIZED
-    assert L.svsx_version().startswith(b"svsx 0.4") and L.svsx_abi_version() == 3
+    dist = C.c_double(0.0)
+    assert L.svsx_get_distance(None, 0, q.ctypes.data, 0, C.byref(dist)) == lib.NOT_INITIALIZED
+    alloc = lib.RESULTS_ALLOCATOR(lambda user, counts, n, out: None)
+    assert L.svsx_range_search(None, q.ctypes.data, 0, 1, 1.0, None, None, alloc, None) == lib.NOT_INITIALIZED
+    assert L.svsx_index_refresh_row_norms(None, None) == lib.NOT_INITIALIZED and L.svsx_index_drop_row_norms(None) == lib.NOT_INITIALIZED
+    assert L.svsx_version().startswith(b"svsx 0.5") and L.svsx_abi_version() == 3
 
 
 def test_product_does_not_import_the_oracle():

@@ -185,8 +185,11 @@ def test_iterator_device_pointers_and_errors(svs, oracle, small_world):
         assert (_bits(d_d[i].cpu().numpy()) == _bits(want[i][1])).all()
     with pytest.raises(svs.SvsxError):  # detail::checkdims (iterator.h:66-74)
         idx.batch_iterator(np.zeros((2, 5), np.float32))
-    with pytest.raises(svs.SvsxError):  # scalar-fallback type pair
-        idx.batch_iterator(np.zeros((2, 96), np.int8))
+    it8 = idx.batch_iterator(np.clip(np.round(q[:2] * 400), -128, 127).astype(np.int8))  # a scalar-loop type pair (int8 queries, float32 rows): served since round 5
+    ids8, dists8, counts8 = it8.next(10)
+    want8 = [oracle.iterate(L2, sw["x"], sw["graph"], sw["entry"], np.clip(np.round(q[i] * 400), -128, 127).astype(np.int8), [10])[0][0] for i in range(2)]
+    for i in range(2):
+        assert (ids8[i] == want8[i][0].astype(np.uint64)).all() and (_bits(dists8[i]) == _bits(want8[i][1])).all()
     it2 = idx.batch_iterator(q[:2], 15000)
     ids, dists, counts = it2.next(1400)  # 16 400 entries: beyond one wave's LDS, the buffer continues in HBM (1 500 points: everything comes out)
     want2 = [oracle.iterate(L2, sw["x"], sw["graph"], sw["entry"], q[i], [1400], extra=15000) for i in range(2)]

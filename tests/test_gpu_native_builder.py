@@ -1,17 +1,16 @@
-"""The in-library builder (svsx_vamana_build_device, csrc/svsx_builder.hip = scalablevectorsearch_amd.build.build_vamana_device)
-against the round-2 torch-glue builder (build_vamana_torch_glue, kept as the checker).
-
-Graph bytes are compared with the torch-glue builder when both start from the same entry point (same algorithm, same order: the only
-legitimate difference is the float32 rounding of neighbour distances, torch ops vs the row-group routines, which can reorder near-ties) --
-reported, not asserted; what IS asserted is validity of the graph and the quality gate of SURVEY section 7 step 4."""
+"""The in-library builder (svsx_vamana_build_device, csrc/svsx_builder.hip = scalablevectorsearch_amd.build.build_vamana_device) against the
+ORACLE's sequential builder (oracle/svs_oracle_build.c: vamana_build.h / prune.h semantics).  The reference's own build depends on its thread
+schedule, so graphs are compared by validity (core/graph/graph.h:169-172) and by search quality at equal windows, not byte for byte.
+(Round 5: the checker used to be this repo's round-2 torch-glue builder -- a self-comparison.)"""
 import numpy as np
 import pytest
 import torch
 
 import scalablevectorsearch_amd as svs
-from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, build_vamana_torch_glue
+from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device
 
 pytestmark = pytest.mark.gpu
+L2, IP, COS = 0, 1, 2
 
 
 def _recall(index, q, gt, k, window):
@@ -20,18 +19,18 @@ def _recall(index, q, gt, k, window):
 
 
 @pytest.mark.parametrize("metric", ["l2", "ip", "cos"])
-def test_native_builder_valid_graph_and_quality(metric):
+def test_native_builder_valid_graph_and_quality(oracle, metric):
     from conftest import deep_like
 
-    n, d, R, k = 20000, 48, 32, 10
+    n, d, R, k = 8000, 48, 32, 10
     x = deep_like(n, d, 12, seed=3)
-    q = deep_like(500, d, 12, seed=4)
+    q = deep_like(300, d, 12, seed=4)
     fn = {"l2": svs.DistanceL2(), "ip": svs.DistanceIP(), "cos": svs.DistanceCosineSimilarity()}[metric]
+    om = {"l2": L2, "ip": IP, "cos": COS}[metric]
     alpha = 1.2 if metric == "l2" else 0.95
     dx = torch.from_numpy(x).cuda()
     bp = VamanaBuildParameters(alpha=alpha, graph_max_degree=R, window_size=2 * R, prune_to=R - 4)
-    g_ref, e_ref = build_vamana_torch_glue(dx, n, d, fn, bp)
-    g_nat, e_nat = build_vamana_device(dx, n, d, fn, bp, entry_point=e_ref)
+    g_nat, e_nat = build_vamana_device(dx, n, d, fn, bp)
     gn = g_nat.cpu().numpy()
     # valid: ids in range, packed from slot 0, no self loops, no duplicates, padding beyond R untouched
     ids = gn[:, :R]
@@ -44,12 +43,12 @@ def test_native_builder_valid_graph_and_quality(metric):
     assert (srt[:, 1:] != srt[:, :-1]).all()              # no duplicate neighbours
     deg = valid.sum(1)
     assert deg.min() >= 1 and deg.mean() > R / 3
-    same_rows = float((gn == g_ref.cpu().numpy()).all(1).mean())
-    print(f"{metric}: rows identical to the torch-glue builder: {same_rows:.4f}; mean degree {deg.mean():.1f}")
-    # quality gate: recall vs exhaustive ground truth within 1 % of the torch-glue builder's graph at the same window
-    ix_ref = svs.VamanaIndex.from_device(g_ref, dx, fn, torch.tensor([e_ref], dtype=torch.int32).cuda(), n, d, np.float32)
+    # quality gate: recall vs exhaustive ground truth within 1 % of the ORACLE builder's graph at the same window, both searched on the GPU
+    g_o, e_o = oracle.build_vamana(om, x, R=R, L=2 * R, prune_to=R - 4, alpha=alpha)
+    assert abs(float(g_o[:, 0].mean()) - float(deg.mean())) < 0.15 * float(g_o[:, 0].mean())
+    ix_ref = svs.VamanaIndex(g_o, x, fn, e_o)
     ix_nat = svs.VamanaIndex.from_device(g_nat, dx, fn, torch.tensor([e_nat], dtype=torch.int32).cuda(), n, d, np.float32)
-    gi, _ = ix_ref.flat_search_device(torch.from_numpy(q).cuda(), k)
+    gi, _ = ix_nat.flat_search_device(torch.from_numpy(q).cuda(), k)
     gt = gi.cpu().numpy()
     for w in (20, 40):
         r_ref, r_nat = _recall(ix_ref, q, gt, k, w), _recall(ix_nat, q, gt, k, w)
@@ -71,7 +70,7 @@ def test_native_medoid_matches_torch():
     assert m_nat == m_ref or abs(d_nat - d_ref) <= 1e-6 * d_ref  # a different row only on a float32 near-tie
 
 
-def test_native_builder_sq_and_small_batches():
+def test_native_builder_sq_and_small_batches(oracle):
     """scalar-quantized rows (decompressed float queries) and n smaller than the minimum batch count"""
     from conftest import deep_like
 
@@ -84,8 +83,12 @@ def test_native_builder_sq_and_small_batches():
     dx = torch.from_numpy(xq).cuda()
     bp = VamanaBuildParameters(alpha=0.95, graph_max_degree=R, window_size=2 * R, prune_to=R - 2)
     fn = svs.DistanceIP()
-    g_ref, e = build_vamana_torch_glue(dx, n, d, fn, bp, data_dtype=np.int8, sq=(scale, bias))
-    g_nat, _ = build_vamana_device(dx, n, d, fn, bp, data_dtype=np.int8, entry_point=e, sq=(scale, bias))
+    g_nat, e_nat = build_vamana_device(dx, n, d, fn, bp, data_dtype=np.int8, sq=(scale, bias))
     gn = g_nat.cpu().numpy()[:, :R]
     assert ((gn >= -1) & (gn < n)).all() and (gn >= 0).sum(1).min() >= 1
-    print("rows identical to the torch-glue builder:", float((g_nat == g_ref).all(1).float().mean()))
+    # searched on the GPU against the exhaustive answer over the same codes, the graph must navigate (the oracle builder takes no codes)
+    ix = svs.VamanaIndex.from_device(g_nat, dx, fn, torch.tensor([e_nat], dtype=torch.int32).cuda(), n, d, np.int8, sq=(scale, bias))
+    qf = deep_like(100, d, 8, seed=6)
+    gi, _ = ix.flat_search_device(torch.from_numpy(qf).cuda(), 10)
+    r = _recall(ix, qf, gi.cpu().numpy(), 10, 48)
+    assert r > 0.9, r

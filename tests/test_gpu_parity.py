@@ -47,12 +47,60 @@ def test_distance_bits_match_oracle(svs, oracle, d):
             assert not bad.any(), (d, qa, qb, m, got[bad][:4], want[bad][:4])
 
 
-def test_unsupported_pair_is_rejected(svs):
-    a = np.zeros((1, 8), np.int8)
-    b = np.zeros((1, 8), np.float32)
-    with pytest.raises(svs.SvsxError) as e:
-        svs.compute(svs.DistanceL2(), a, b)
-    assert e.value.code == 2
+# the (query, data) pairs utils/search_index.cpp:147-162 offers that have NO AVX-512 specialisation: the reference answers them with its scalar
+# loops (generic_l2 / generic_ip / generic_cosine_similarity); round 5 builds them (QM_SCALAR) against the oracle's restatement of those loops
+# (one fma per element: oracle/svs_oracle.c has the argument; parity unpinned -- the reference header does not compile here)
+SCALAR_PAIRS = [(I8, U8), (I8, F32), (I8, F16), (U8, I8), (U8, F32), (U8, F16)]
+
+
+@pytest.mark.parametrize("d", [1, 16, 17, 96, 100, 223])
+def test_scalar_loop_pairs_distance_bits_match_oracle(svs, oracle, d):
+    rng = np.random.default_rng(1000 + d)
+    for qa, qb in SCALAR_PAIRS:
+        a = _gen(rng, qa, 5, d)
+        b = _gen(rng, qb, 130, d)   # more than one 64-row pass
+        for m, f in ((L2, svs.DistanceL2()), (IP, svs.DistanceIP()), (COS, svs.DistanceCosineSimilarity())):
+            got = svs.compute(f, a, b)
+            want = oracle.distance_batch(m, a, b)
+            bad = got.view(np.uint32) != want.view(np.uint32)
+            bad &= ~(np.isnan(got) & np.isnan(want))
+            assert not bad.any(), (d, qa, qb, m, got[bad][:4], want[bad][:4])
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("qdt,ddt", SCALAR_PAIRS)
+def test_search_scalar_loop_pairs(svs, oracle, small_world, metric, qdt, ddt):
+    """graph search, BatchIterator and get_distance of the six scalar-loop pairs: ids, distance bits and tracker counts equal to the oracle;
+    svsx_last_kernel_info names the scalar loop and says that its parity is unpinned"""
+    sw = small_world
+    fn = {L2: svs.DistanceL2(), IP: svs.DistanceIP(), COS: svs.DistanceCosineSimilarity()}[metric]
+
+    def conv(a, dt):
+        if dt == F32:
+            return a
+        if dt == F16:
+            return a.astype(np.float16)
+        if dt == I8:
+            return np.clip(np.round(a * 400), -128, 127).astype(np.int8)
+        return np.clip(np.round(a * 400 + 128), 0, 255).astype(np.uint8)
+
+    x = conv(sw["x"], ddt)
+    q = conv(sw["q"], qdt)
+    idx = svs.VamanaIndex(sw["graph"], x, fn, sw["entry"])
+    for (w, c) in [(16, 16), (12, 30), (260, 260)]:
+        res, st = idx.search(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c)), stats=True)
+        ids, dists, ost = oracle.search(metric, x, sw["graph"], sw["entry"], q, 10, w, c, stats=True)
+        assert (res.indices == ids.astype(np.uint64)).all(), (metric, qdt, ddt, w)
+        assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
+        assert (st[:, :2] == ost[:, :2]).all()
+        assert "qmode=5" in idx.last_kernel_info() and "parity unpinned" in idx.last_kernel_info()
+    res = idx.search(q[:4], 3, svs.VamanaSearchParameters(svs.SearchBufferConfig(16)))
+    for i in range(4):
+        for j in range(3):
+            assert np.float32(idx.get_distance(int(res.indices[i, j]), q[i])).view(np.uint32) == res.distances[i, j].view(np.uint32)
+    with pytest.raises(svs.SvsxError) as e:   # the exhaustive search keeps to the pairs with a SIMD kernel
+        svs.FlatIndex(x, fn).search(q[:2], 3)
+    assert e.value.code == 3
 
 
 def _search_both(svs, oracle, metric, fn, x, graph, entry, q, k, w, c, sq=None):

@@ -158,11 +158,50 @@ def test_distances_against_double_precision_reference(oracle, d):
         assert np.allclose(got, _double_reference(COS, a, b), rtol=0.01, atol=0.015)
 
 
-def test_unspecialised_type_pairs_are_reported(oracle):
-    with pytest.raises(ValueError):
-        oracle.distance_batch(L2, np.zeros((1, 4), np.int8), np.zeros((1, 4), np.float32))
-    with pytest.raises(ValueError):
-        oracle.distance_batch(L2, np.zeros((1, 4), np.float16), np.zeros((1, 4), np.uint8))
+def test_unspecialised_type_pairs_take_the_scalar_loops(oracle):
+    """The six (query, data) pairs of utils/search_index.cpp:147-162 without an AVX-512 specialisation are answered by generic_l2 / generic_ip /
+    generic_cosine_similarity (euclidean.h:206-215, inner_product.h:167-176, cosine.h:185-200): one float accumulator in element order, the
+    update contracted into ONE fma (the loops are instantiated in the -march=cascadelake kernel TU under GCC's default -ffp-contract=fast).
+    PARITY UNPINNED: the header cannot be compiled here.  This test holds the oracle to the stated reading operation by operation, to the
+    tolerance of the reference's own distance tests (tests/svs/core/distances/*.cpp: Approx epsilon 1e-4) against float64, and shows with a
+    fixture that the other reading (multiply and add rounded separately) gives other bits -- the choice is observable."""
+    rng = np.random.default_rng(11)
+    d = 223
+    gens = {np.int8: lambda n: rng.integers(-128, 128, (n, d)).astype(np.int8), np.uint8: lambda n: rng.integers(0, 256, (n, d)).astype(np.uint8),
+            np.float32: lambda n: rng.standard_normal((n, d)).astype(np.float32), np.float16: lambda n: rng.standard_normal((n, d)).astype(np.float16)}
+    pairs = [(np.int8, np.uint8), (np.int8, np.float32), (np.int8, np.float16), (np.uint8, np.int8), (np.uint8, np.float32), (np.uint8, np.float16)]
+
+    def fma(a, b, c):  # one rounding: exact in float64 (24-bit products of float32 values fit 53 bits, the sum is rounded once ... twice-safe here)
+        return np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+
+    differs = 0
+    for qa, qb in pairs:
+        a, b = gens[qa](3), gens[qb](5)
+        for m in (L2, IP, COS):
+            got = oracle.distance_batch(m, a, b)
+            for i in range(3):
+                an = oracle.norm(a[i]) if m == COS else 0.0
+                for j in range(5):
+                    r = np.float32(0.0); acc = np.float32(0.0); r2 = np.float32(0.0)
+                    for t in range(d):
+                        x, y = np.float32(a[i, t]), np.float32(b[j, t])
+                        if m == L2:
+                            c = np.float32(x - y)
+                            r = fma(c, c, r)
+                            r2 = np.float32(r2 + np.float32(c * c))
+                        else:
+                            if m == COS:
+                                acc = fma(y, y, acc)
+                            r = fma(x, y, r)
+                            r2 = np.float32(r2 + np.float32(x * y))
+                    want = r if m != COS else np.float32(r / np.float32(np.float32(an) * np.sqrt(acc, dtype=np.float32)))
+                    assert np.float32(got[i, j]).view(np.uint32) == np.float32(want).view(np.uint32), (qa, qb, m, i, j)
+                    differs += int(m != COS and np.float32(r2).view(np.uint32) != np.float32(r).view(np.uint32))
+            ref64 = {L2: ((a[:, None, :].astype(np.float64) - b[None].astype(np.float64)) ** 2).sum(-1),
+                     IP: a.astype(np.float64) @ b.astype(np.float64).T}.get(m)
+            if ref64 is not None:
+                assert np.allclose(got, ref64, rtol=1e-4, atol=1e-4)
+    assert differs > 0  # the un-contracted reading is a different function on these inputs
 
 
 def test_scalar_quantization_formulas(oracle):
