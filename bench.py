@@ -137,11 +137,14 @@ def stat3(ms_list, nq):
             "qps_at_median": nq / (float(np.median(a)) * 1e-3), "qps_best": nq / (float(a[0]) * 1e-3)}
 
 
-def designed_lines(stats_i64, gstride, row_bytes, bound_codes, d, k, record_bytes=32):
+def designed_lines(stats_i64, gstride, row_bytes, bound_codes, d, k, record_bytes=32, degree_aware=True):
     """128-byte lines one launch is DESIGNED to request (what `roofline.achieved` prices): per expansion the adjacency block
     (ids, + inline records in mode 2), one code line per evaluated candidate in mode 1, the full row of every candidate
     that reaches the exact path (entry point, survivors of the bound / all evaluated candidates without a bound), the
-    query and the result rows.  Counted from the kernel's own per-query statistics."""
+    query and the result rows.  Counted from the kernel's own per-query statistics.
+    degree_aware (round 5, inline records of indexes up to 2^26 nodes): an expansion requests only the 8-slot groups of its block that hold
+    neighbours -- one line per group and record plane, plus the id lines in front of them; the number of groups is taken from the mean
+    number of neighbour slots per expansion (ceil(degree / 8) averages (degree + 3.5) / 8 over a spread of degrees)."""
     exp = int(stats_i64[:, 0].sum())
     evals = int(stats_i64[:, 2].sum())
     early = int(stats_i64[:, 4].sum())
@@ -149,7 +152,14 @@ def designed_lines(stats_i64, gstride, row_bytes, bound_codes, d, k, record_byte
     nq = stats_i64.shape[0]
     row_lines = -(-row_bytes // LINE)
     if bound_codes == 2:
-        adj = exp * (-(-(gstride * (4 + record_bytes)) // LINE))
+        if degree_aware and exp > 0:
+            groups = min((int(stats_i64[:, 1].sum()) / exp + 3.5) / 8.0, gstride / 8.0)
+            full_chunks = int(groups // 8)
+            rem = groups - 8 * full_chunks
+            id_lines = 2 * full_chunks + (-(-int(round(rem * 32)) // LINE) if rem > 0 else 0)
+            adj = int(round(exp * (id_lines + (record_bytes // 16) * groups)))
+        else:
+            adj = exp * (-(-(gstride * (4 + record_bytes)) // LINE))
         code = 0
     else:
         adj = exp * (-(-(gstride * 4) // LINE))

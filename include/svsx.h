@@ -240,7 +240,7 @@ typedef struct {
     size_t window_size;
     size_t max_candidate_pool_size;
     size_t prune_to;                /* 0 = graph_max_degree - 4 */
-    int use_full_search_history;    /* only 1 (the reference's default) is built */
+    int use_full_search_history;    /* 1 (the reference's default): a vertex's candidates are the nodes its search expanded; 0: the search buffer's contents (vamana_build.h:407-421) */
 } svsx_build_params;
 
 /* Graph construction ("next" scope): the VamanaIndex build constructor (index/vamana/index.h:398-439 ->

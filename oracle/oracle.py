@@ -194,7 +194,7 @@ class Oracle:
             raise ValueError(f"svso_flat_search failed rc={rc}")
         return ids, dists
 
-    def build_vamana(self, metric, data, R, L, C_pool=750, prune_to=None, alpha=None):
+    def build_vamana(self, metric, data, R, L, C_pool=750, prune_to=None, alpha=None, use_full_search_history=True):
         data = np.ascontiguousarray(data)
         n, d = data.shape
         prune_to = R if prune_to is None else prune_to
@@ -202,7 +202,10 @@ class Oracle:
             alpha = 1.2 if metric == L2 else 0.95
         graph = np.zeros((n, R + 1), np.uint32)
         entry = C.c_uint32(0)
-        rc = self.lib.svso_build_vamana(metric, dtype_code(data), _ptr(data), n, d, R, L, C_pool, prune_to, alpha, _ptr(graph), C.byref(entry))
+        self.lib.svso_build_vamana_ex.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                                  C.c_int, C.c_void_p, C.POINTER(C.c_uint32)]
+        rc = self.lib.svso_build_vamana_ex(metric, dtype_code(data), _ptr(data), n, d, R, L, C_pool, prune_to, alpha, 1 if use_full_search_history else 0,
+                                           _ptr(graph), C.byref(entry))
         if rc:
             raise ValueError("svso_build_vamana failed")
         return graph, np.array([entry.value], np.uint32)

@@ -139,6 +139,8 @@ static int has_edge(const uint32_t* row, uint32_t id) {
     return 0;
 }
 
+static int g_full_history = 1; /* VamanaBuildParameters::use_full_search_history (build_params.h:28-75) */
+
 static void one_pass(svso_index* ix, uint32_t* graph, size_t R, size_t L, size_t C, size_t prune_to, float build_alpha, float pass_alpha, uint32_t entry) {
     size_t n = ix->n, stride = R + 1;
     size_t nb = (n + 4095) / 4096;
@@ -174,12 +176,23 @@ static void one_pass(svso_index* ix, uint32_t* graph, size_t R, size_t L, size_t
             hist[0] = entry;
             hist_d[0] = pair_distance(ix, (uint32_t)node, entry);
             if (hl > hist_cap - 1) hl = hist_cap - 1;
-            for (size_t i = 0; i <= hl; ++i) {
-                if (mark[hist[i]]) continue;
-                mark[hist[i]] = 1;
-                pool[np].id = hist[i];
-                pool[np].dist = hist_d[i];
-                np++;
+            if (g_full_history) {
+                for (size_t i = 0; i <= hl; ++i) {
+                    if (mark[hist[i]]) continue;
+                    mark[hist[i]] = 1;
+                    pool[np].id = hist[i];
+                    pool[np].dist = hist_d[i];
+                    np++;
+                }
+            } else { /* vamana_build.h:416-421: "pull results directly out of the search buffer" */
+                for (size_t i = 0; i < buf.size; ++i) {
+                    uint32_t id = buf.e[i].id & 0x7FFFFFFFu;
+                    if (mark[id]) continue;
+                    mark[id] = 1;
+                    pool[np].id = id;
+                    pool[np].dist = buf.e[i].dist;
+                    np++;
+                }
             }
             const uint32_t* row = graph + node * stride;
             for (uint32_t j = 0; j < row[0]; ++j) {
@@ -262,6 +275,22 @@ size_t svso_prune(int metric, int data_dtype, const void* data, size_t n, size_t
     size_t r = prune(&ix, node, pool, np, max_out, alpha, out);
     free(pool);
     return r;
+}
+
+int svso_build_vamana(
+    int metric, int data_dtype, const void* data, size_t n, size_t d, size_t R, size_t L, size_t C, size_t prune_to,
+    float alpha, uint32_t* graph, uint32_t* entry_out
+);
+
+/* the same with VamanaBuildParameters::use_full_search_history (0: candidates = the search buffer's contents, vamana_build.h:407-421) */
+int svso_build_vamana_ex(
+    int metric, int data_dtype, const void* data, size_t n, size_t d, size_t R, size_t L, size_t C, size_t prune_to,
+    float alpha, int use_full_search_history, uint32_t* graph, uint32_t* entry_out
+) {
+    g_full_history = use_full_search_history ? 1 : 0;
+    const int rc = svso_build_vamana(metric, data_dtype, data, n, d, R, L, C, prune_to, alpha, graph, entry_out);
+    g_full_history = 1;
+    return rc;
 }
 
 /* Builds an SVS-layout graph (n x (R+1) u32, slot 0 = degree) into `graph`; returns the entry point. */

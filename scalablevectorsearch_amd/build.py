@@ -200,7 +200,8 @@ def build_vamana_device(d_data, n: int, d: int, distance, params: VamanaBuildPar
     if entry_point is None:
         entry_point = index.find_medoid()
         d_entry.fill_(entry_point)  # the device view reads the entry point from this tensor at every search
-    index.vamana_build(params.alpha, R, params.window_size, params.max_candidate_pool_size, params.prune_to or max(R - 4, 1))
+    index.vamana_build(params.alpha, R, params.window_size, params.max_candidate_pool_size, params.prune_to or max(R - 4, 1),
+                       use_full_search_history=params.use_full_search_history)
     torch.cuda.synchronize(dev)
     return graph, entry_point
 

@@ -612,11 +612,15 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb) {
     // Record size by expected lines per hop: block lines (4 + RB bytes per slot) + the rows of the candidates the bound cannot
     // exclude.  How many it excludes follows the share f of the sample's second moment the coded directions carry -- the remainder
     // only enters the bound through a product of norms, which is loose: measured (profiles/r02_notes.md) the bound is useless
-    // below f ~ 0.6 and rejects ~88 % of the candidates at f ~ 1 -- modelled as rej = 0.88 clamp((f - 0.6) / 0.3, 0, 1).  A larger
-    // record must win by 10 % (the 32-byte form has static-dimension kernels and the fewest registers).
+    // below f ~ 0.6 and rejects ~88 % of the candidates at f ~ 0.9 -- modelled as rej = 0.88 clamp((f - 0.6) / 0.3, 0, 1) -- and a little more
+    // towards f = 1 (+ 0.05 clamp((f - 0.9) / 0.1, 0, 1): 0.86 -> 0.926 measured between 64- and 128-byte records on config 4's rows,
+    // profiles/r05_notes.md).  A row of scalar-quantized codes costs far more than its lines: every element is decompressed and multiplied
+    // (2.5 vector instructions, scalar.h:155-195) on a kernel the vector ALU bounds -- weighted 4x (round 5: 128-byte records beat 64-byte
+    // ones by 18 % on 768-byte rows although they double the block).  A larger record must win by 10 % (the 32-byte form has
+    // static-dimension kernels and the fewest registers).
     double trace = 0.0;
     for (uint32_t i = 0; i < d; ++i) trace += cov[static_cast<size_t>(i) * d + i];
-    const double row_lines = static_cast<double>((ix->row_bytes + 127) / 128);
+    const double row_lines = static_cast<double>((ix->row_bytes + 127) / 128) * (ix->sq_enabled ? 4.0 : 1.0);
     const double cand = 0.9 * static_cast<double>(ix->gstride);
     uint32_t rb = 32;
     double best_cost = 0.0;
@@ -624,7 +628,7 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb) {
         double got = 0.0;
         for (uint32_t c = 0; c < r - meta && c < m; ++c) got += std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0);
         const double f = trace > 0.0 ? got / trace : 1.0;
-        const double rej = 0.88 * std::min(std::max((f - 0.6) / 0.3, 0.0), 1.0);
+        const double rej = 0.88 * std::min(std::max((f - 0.6) / 0.3, 0.0), 1.0) + 0.05 * std::min(std::max((f - 0.9) / 0.1, 0.0), 1.0);
         const double cost = static_cast<double>(ix->gstride) * (4.0 + r) / 128.0 + cand * (1.0 - rej) * row_lines;
         if (r == 32 || cost < 0.9 * best_cost) {
             best_cost = cost;
@@ -1565,6 +1569,7 @@ struct BuildTarget {
 struct BuildParams {
     float alpha;
     uint32_t graph_max_degree, window_size, max_candidate_pool_size, prune_to;
+    int use_full_search_history;
 };
 int build_vamana(const BuildTarget& t, const BuildParams& p, hipStream_t stream, std::string& err);
 int find_medoid_device(const BuildTarget& t, uint32_t* medoid, hipStream_t stream, std::string& err);
@@ -1598,13 +1603,13 @@ int svsx_vamana_build_device(svsx_index* ix, const svsx_build_params* params, vo
         return fail(SVSX_INVALID_ARGUMENT, "graph_max_degree %zu does not fit the graph rows of %zu ids", params->graph_max_degree, ix->gstride);
     if (params->window_size == 0 || params->window_size > 8000) return fail(SVSX_INVALID_ARGUMENT, "build window_size out of range");
     if (!(params->alpha > 0.0f)) return fail(SVSX_INVALID_ARGUMENT, "alpha must be positive");
-    if (!params->use_full_search_history) return fail(SVSX_NOT_IMPLEMENTED, "only use_full_search_history = true is built");
     if (ix->d_fat || ix->d_codes) return fail(SVSX_INVALID_ARGUMENT, "bound codes describe a finished graph: build first");
     HIP_TRY(hipSetDevice(ix->device));
     svsx::BuildParams p;
     p.alpha = params->alpha;
     p.graph_max_degree = static_cast<uint32_t>(params->graph_max_degree);
     p.window_size = static_cast<uint32_t>(params->window_size);
+    p.use_full_search_history = params->use_full_search_history ? 1 : 0;
     p.max_candidate_pool_size = static_cast<uint32_t>(params->max_candidate_pool_size ? params->max_candidate_pool_size : 750);
     p.prune_to = static_cast<uint32_t>(params->prune_to);
     std::string err;

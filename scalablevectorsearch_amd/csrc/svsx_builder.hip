@@ -333,6 +333,16 @@ __global__ __launch_bounds__(256) void over_gather_kernel(const uint32_t* over, 
     sorted[3 * i + 2] = over[3 * s + 2];
 }
 
+// use_full_search_history = false: the search returned its buffer (ids + distances, rows of `stride`, padded with 0xFFFFFFFF when the buffer held
+// fewer): the number of real entries per vertex
+__global__ __launch_bounds__(256) void count_valid_kernel(const uint32_t* ids, uint32_t stride, uint32_t n, uint32_t* len) {
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= n) return;
+    uint32_t c = 0;
+    while (c < stride && ids[static_cast<size_t>(v) * stride + c] != 0xFFFFFFFFu) ++c;
+    len[v] = c;
+}
+
 __global__ __launch_bounds__(256) void iota_kernel(uint32_t* out, uint32_t first, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) out[i] = first + i;
@@ -418,6 +428,7 @@ struct BuildTarget {          // what svsx_api.hip knows about the index (the sv
 struct BuildParams {          // index/vamana/build_params.h:28-75
     float alpha;
     uint32_t graph_max_degree, window_size, max_candidate_pool_size, prune_to;
+    int use_full_search_history; // 0: the candidates of a vertex are the search buffer's contents (vamana_build.h:407-421), not the expanded nodes
 };
 
 namespace {
@@ -550,9 +561,21 @@ int build_vamana(const BuildTarget& t, const BuildParams& p, hipStream_t stream,
                 queries = static_cast<const unsigned char*>(t.d_data) + static_cast<size_t>(lo) * t.row_bytes;
                 aux.query_row_stride_bytes = t.row_bytes;
             }
-            if (int rc = svsx_search_device(t.index, queries, q_dtype, B, 1, &sp, nullptr, out_ids.as<uint32_t>(), nullptr, &aux, stream)) {
-                err = std::string("search of a build batch failed: ") + svsx_last_error();
-                return rc;
+            uint32_t a_cap = H;
+            if (p.use_full_search_history) {
+                if (int rc = svsx_search_device(t.index, queries, q_dtype, B, 1, &sp, nullptr, out_ids.as<uint32_t>(), nullptr, &aux, stream)) {
+                    err = std::string("search of a build batch failed: ") + svsx_last_error();
+                    return rc;
+                }
+            } else { // the buffer itself: the best L entries the search holds when it ends, in rows of L (H >= L: the history arrays hold them)
+                svsx_search_aux plain{};
+                plain.query_row_stride_bytes = aux.query_row_stride_bytes;
+                if (int rc = svsx_search_device(t.index, queries, q_dtype, B, L, &sp, nullptr, hist_ids.as<uint32_t>(), hist_d.as<float>(), &plain, stream)) {
+                    err = std::string("search of a build batch failed: ") + svsx_last_error();
+                    return rc;
+                }
+                hipLaunchKernelGGL(count_valid_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, hist_ids.as<uint32_t>(), L, B, hist_len.as<uint32_t>());
+                a_cap = L;
             }
             // ---- 2. candidate pools ------------------------------------------------------------------------------------------------
             BUILD_TRY(hipMemsetAsync(n_over.p, 0, sizeof(uint32_t), stream));
@@ -560,7 +583,7 @@ int build_vamana(const BuildTarget& t, const BuildParams& p, hipStream_t stream,
             PoolArgs pa{};
             pa.data = t.d_data; pa.row_bytes = t.row_bytes; pa.d = t.d; pa.sq_scale = t.sq_scale; pa.sq_bias = t.sq_bias;
             pa.node_ids = node_ids.as<uint32_t>(); pa.node_stride = 1; pa.n_nodes = B;
-            pa.a_ids = hist_ids.as<uint32_t>(); pa.a_dists = hist_d.as<float>(); pa.a_len = hist_len.as<uint32_t>(); pa.a_cap = H;
+            pa.a_ids = hist_ids.as<uint32_t>(); pa.a_dists = hist_d.as<float>(); pa.a_len = hist_len.as<uint32_t>(); pa.a_cap = a_cap;
             pa.graph = t.d_graph; pa.gstride = t.gstride; pa.max_degree = R;
             pa.sort_n = sort_n_fwd; pa.pool_size = pool_size;
             pa.pool_ids = pool_ids.as<int32_t>(); pa.pool_dists = pool_d.as<float>();

@@ -280,11 +280,12 @@ class VamanaIndex:
             recomputed.data_ptr() if recomputed is not None else None, C.c_void_p(s)))
         return d_ids64, d_dists
 
-    def vamana_build(self, alpha: float, graph_max_degree: int, window_size: int, max_candidate_pool_size: int = 750, prune_to: int = 0, stream=None) -> None:
+    def vamana_build(self, alpha: float, graph_max_degree: int, window_size: int, max_candidate_pool_size: int = 750, prune_to: int = 0, stream=None,
+                     use_full_search_history: bool = True) -> None:
         """VamanaIndex build constructor (index/vamana/index.h:398-439) on this device-view index: fills its (all 0xFFFFFFFF) graph in place."""
         import torch
 
-        bp = _lib.BuildParams(float(alpha), int(graph_max_degree), int(window_size), int(max_candidate_pool_size), int(prune_to), 1)
+        bp = _lib.BuildParams(float(alpha), int(graph_max_degree), int(window_size), int(max_candidate_pool_size), int(prune_to), 1 if use_full_search_history else 0)
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         _lib.check(_lib.lib().svsx_vamana_build_device(self._h, C.byref(bp), C.c_void_p(s)))
 

@@ -155,8 +155,9 @@ def test_cxx_facade_search_on_gpu(lib, tmp_path):
     lines = out.stdout.splitlines()
     assert lines[0].split() == ["5", "6", "4"]
     assert lines[1].split() == ["filtered:", "40", "42", "38", "44"]                        # IDFilter overload, inline-record index
-    assert lines[2].split()[0] == "calibrated:" and lines[2].split()[-1] == "1.00"          # VamanaIndex::calibrate reaches recall 1 on the ring
-    assert [ln.split()[2] for ln in lines[3:]] == ["5", "6", "4", "7", "3", "2", "1", "0"]  # BatchIterator, batches of 3
+    assert lines[2].split()[0] == "range:" and int(lines[2].split()[1]) >= 3                # runtime range_search + get_distance through the C ABI (exit codes 15-19 check the contents)
+    assert lines[3].split()[0] == "calibrated:" and lines[3].split()[-1] == "1.00"          # VamanaIndex::calibrate reaches recall 1 on the ring
+    assert [ln.split()[2] for ln in lines[4:]] == ["5", "6", "4", "7", "3", "2", "1", "0"]  # BatchIterator, batches of 3
 
 
 def test_cxx_io_recall_calibration_header(tmp_path):

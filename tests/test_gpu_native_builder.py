@@ -92,3 +92,30 @@ def test_native_builder_sq_and_small_batches(oracle):
     gi, _ = ix.flat_search_device(torch.from_numpy(qf).cuda(), 10)
     r = _recall(ix, qf, gi.cpu().numpy(), 10, 48)
     assert r > 0.9, r
+
+
+def test_builder_without_the_full_search_history(oracle):
+    """VamanaBuildParameters::use_full_search_history = false (build_params.h:28-75, vamana_build.h:407-421): a vertex's candidates are the search
+    buffer's contents instead of the nodes its search expanded.  Checked like the default: valid graph, and search quality within 1 % of the ORACLE
+    builder's graph built with the same flag -- and the flag must change the graph."""
+    from conftest import deep_like
+
+    n, d, R, k = 8000, 48, 32, 10
+    x = deep_like(n, d, 12, seed=3)
+    q = deep_like(300, d, 12, seed=4)
+    fn = svs.DistanceL2()
+    dx = torch.from_numpy(x).cuda()
+    g_full, _ = build_vamana_device(dx, n, d, fn, VamanaBuildParameters(alpha=1.2, graph_max_degree=R, window_size=2 * R, prune_to=R - 4))
+    g_buf, e_buf = build_vamana_device(dx, n, d, fn, VamanaBuildParameters(alpha=1.2, graph_max_degree=R, window_size=2 * R, prune_to=R - 4, use_full_search_history=False))
+    gn = g_buf.cpu().numpy()[:, :R]
+    valid = gn >= 0
+    assert (gn[valid] < n).all() and not (gn == np.arange(n)[:, None]).any() and valid.sum(1).min() >= 1
+    assert float((g_buf == g_full).all(1).float().mean()) < 1.0
+    g_o, e_o = oracle.build_vamana(L2, x, R=R, L=2 * R, prune_to=R - 4, alpha=1.2, use_full_search_history=False)
+    ix_ref = svs.VamanaIndex(g_o, x, fn, e_o)
+    ix_nat = svs.VamanaIndex.from_device(g_buf, dx, fn, torch.tensor([e_buf], dtype=torch.int32).cuda(), n, d, np.float32)
+    gi, _ = ix_nat.flat_search_device(torch.from_numpy(q).cuda(), k)
+    gt = gi.cpu().numpy()
+    for w in (20, 40):
+        r_ref, r_nat = _recall(ix_ref, q, gt, k, w), _recall(ix_nat, q, gt, k, w)
+        assert r_nat >= r_ref - 0.01, (w, r_ref, r_nat)

@@ -234,8 +234,9 @@ def test_argument_errors(svs, small_world):
     assert e.value.code == 2 and "k must be greater than 0" in e.value.message
     with pytest.raises(svs.SvsxError):
         svs.SearchBufferConfig(10, 9)
-    with pytest.raises(svs.SvsxError) as e:
-        idx.search(sw["q"].astype(np.int8), 5)
+    with pytest.raises(svs.SvsxError) as e:  # a scalar-quantized index takes float queries only (scalar.h:58-195); plain int8 queries are a scalar-loop pair (served)
+        codes = np.clip(np.round(sw["x"] * 400), -128, 127).astype(np.int8)
+        svs.VamanaIndex(sw["graph"], codes, svs.DistanceL2(), sw["entry"], sq=(0.0025, 0.0)).search(sw["q"].astype(np.int8), 5)
     assert e.value.code == 2
     # empty batch is a no-op (vamana_index_impl.h:125-127)
     r = idx.search(np.zeros((0, 96), np.float32), 5)
@@ -742,8 +743,9 @@ def test_flat_search_k_beyond_96(svs, oracle, k):
         assert (r.indices == oi.astype(np.uint64)).all(), (n, k)
         assert (r.distances.view(np.uint32) == od.view(np.uint32)).all(), (n, k)
         assert (np.diff(r.distances, axis=1) >= 0).all()
-    with pytest.raises(svs.SvsxError):
-        svs.FlatIndex(x, svs.DistanceL2()).search(q, 225)
+    r = svs.FlatIndex(x, svs.DistanceL2()).search(q[:3], 225)   # beyond the shortlist's 224: the exhaustive float32 pass alone (round 5)
+    oi, od = oracle.flat_search(L2, x, q[:3], 225)
+    assert (r.indices == oi.astype(np.uint64)).all() and (r.distances.view(np.uint32) == od.view(np.uint32)).all()
 
 
 def test_golden_flat_search_on_gpu(svs):
