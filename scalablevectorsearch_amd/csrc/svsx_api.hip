@@ -615,12 +615,13 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb) {
     // below f ~ 0.6 and rejects ~88 % of the candidates at f ~ 0.9 -- modelled as rej = 0.88 clamp((f - 0.6) / 0.3, 0, 1) -- and a little more
     // towards f = 1 (+ 0.05 clamp((f - 0.9) / 0.1, 0, 1): 0.86 -> 0.926 measured between 64- and 128-byte records on config 4's rows,
     // profiles/r05_notes.md).  A row of scalar-quantized codes costs far more than its lines: every element is decompressed and multiplied
-    // (2.5 vector instructions, scalar.h:155-195) on a kernel the vector ALU bounds -- weighted 4x (round 5: 128-byte records beat 64-byte
+    // (2.5 vector instructions, scalar.h:155-195) on a kernel whose few resident waves are bound by their instruction count, not by lines: a
+    // 768-byte row is ~34 wave instructions, doubling the records of a 128-slot row ~50 -- weighted 8x (round 5: 128-byte records beat 64-byte
     // ones by 18 % on 768-byte rows although they double the block).  A larger record must win by 10 % (the 32-byte form has
     // static-dimension kernels and the fewest registers).
     double trace = 0.0;
     for (uint32_t i = 0; i < d; ++i) trace += cov[static_cast<size_t>(i) * d + i];
-    const double row_lines = static_cast<double>((ix->row_bytes + 127) / 128) * (ix->sq_enabled ? 4.0 : 1.0);
+    const double row_lines = static_cast<double>((ix->row_bytes + 127) / 128) * (ix->sq_enabled ? 8.0 : 1.0);
     const double cand = 0.9 * static_cast<double>(ix->gstride);
     uint32_t rb = 32;
     double best_cost = 0.0;

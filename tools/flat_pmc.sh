@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 flat-search evidence: kernel trace + counters of svsx_flat_search_device, 10 000 queries x 1 M x 96 float32 (L2) and x 128 float16 (IP)
+# Flat-search evidence (tools/flat_pmc.sh <round prefix>): kernel trace + counters of svsx_flat_search_device, 10 000 queries x 1 M x 96 float32 (L2) and x 128 float16 (IP)
 set -u
-R=$PWD; O=$R/gpurun_out/r04flat; mkdir -p $O; rm -rf $O/*
+R=$PWD; O=$R/gpurun_out/${1:-r05}flat; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/tools/flat_check.py 1000000 96 10000 10 l2 > $O/traced.json 2>/dev/null
 i=0

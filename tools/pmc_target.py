@@ -16,11 +16,11 @@ ap.add_argument("--config", default="c2"); ap.add_argument("--n", type=int, defa
 ap.add_argument("--window", type=int, default=128); ap.add_argument("--codes", type=int, default=2); ap.add_argument("--visited", type=int, default=1)
 ap.add_argument("--degree", type=int, default=64); ap.add_argument("--launches", type=int, default=5); ap.add_argument("--graph-cache", default="")
 ap.add_argument("--matched", action="store_true", help="use the smallest window with recall@10 >= 0.9 instead of --window")
-ap.add_argument("--sid", type=int, default=0); ap.add_argument("--warmup", type=int, default=12, help="un-marked launches before the first marker: the traced launches then run in the warmed state the bench times")
+ap.add_argument("--build-window", type=int, default=0, help="build window L (0 = 2 R; the bench's config-4 graph uses 200)"); ap.add_argument("--sid", type=int, default=0); ap.add_argument("--warmup", type=int, default=12, help="un-marked launches before the first marker: the traced launches then run in the warmed state the bench times")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 k, R = 10, a.degree
-cache = f"{a.graph_cache}.{a.config}.s{a.sid}.n{a.n}" if a.graph_cache else ""
+cache = f"{a.graph_cache}.{a.config}.s{a.sid}.n{a.n}.R{a.degree}.L{a.build_window}" if a.graph_cache else ""
 if a.config == "c3":    # BASELINE config 3: sift-1M-like, float16 rows, float32 queries, inner product
     d, fn, ddt, sq = 128, svs.DistanceIP(), np.float16, None
     x = deep_like_device(a.n, d, 32, seed=31, device=dev, normalize=False).half()
@@ -28,12 +28,19 @@ if a.config == "c3":    # BASELINE config 3: sift-1M-like, float16 rows, float32
     graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache, distance=fn, alpha=0.95, data_dtype=ddt)
 elif a.config == "c4":  # BASELINE config 4's row type: scalar-quantized int8 codes, float32 queries, cosine
     d, fn, ddt = 768, svs.DistanceCosineSimilarity(), np.int8
-    xf = deep_like_device(a.n, d, 64, seed=1, device=dev, normalize=False)
     q = deep_like_device(a.nq, d, 64, seed=2, device=dev, normalize=False)
-    mn, mx = float(xf.min()), float(xf.max()); scale = (mx - mn) / 255.0; bias = mn + 128.0 * scale
-    x = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8); del xf
+    mn = mx = None  # two passes over the generator, 1 M rows at a time: the float32 rows of 10 M x 768 never exist at once (bench.config4_point)
+    for lo in range(0, a.n, 1 << 20):
+        xf = deep_like_device(min(1 << 20, a.n - lo), d, 64, seed=1, device=dev, normalize=False, row0=lo)
+        mn = float(xf.min()) if mn is None else min(mn, float(xf.min())); mx = float(xf.max()) if mx is None else max(mx, float(xf.max()))
+    scale = (mx - mn) / 255.0; bias = mn + 128.0 * scale
+    x = torch.empty((a.n, d), dtype=torch.int8, device=dev)
+    for lo in range(0, a.n, 1 << 20):
+        xf = deep_like_device(min(1 << 20, a.n - lo), d, 64, seed=1, device=dev, normalize=False, row0=lo)
+        x[lo:lo + xf.shape[0]] = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8)
+    del xf
     sq = (scale, bias)
-    graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache, distance=fn, alpha=0.95, data_dtype=ddt, sq=sq)
+    graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache, distance=fn, alpha=0.95, data_dtype=ddt, sq=sq, build_window=a.build_window)
 else:
     d, fn, ddt, sq = 96, svs.DistanceL2(), np.float32, None
     x = deep_like_device(a.n, d, 24, seed=1 + 1000 * a.sid, device=dev)
