@@ -46,24 +46,25 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_pmc_summaries_are_stamped_and_consistent():
-    """each committed round-4 PMC summary names its workload and the kernel sources it was measured on, its traffic agrees with the designed
-    bytes of the same launches (no wasted re-reads), and the kernel trace of the profiled process agrees with that process's own HIP-event time"""
+    """each committed round-5 PMC summary names its workload and the kernel sources it was measured on, its traffic agrees with the designed
+    bytes of the same launches (no wasted re-reads), and the kernel trace of the profiled process agrees with that process's own HIP-event time
+    (within 5 %: the tracer adds ~10-30 us per dispatch, 3 % of a 0.31 ms launch)"""
     shas = set()
-    for tag in ("r04_c2_w128", "r04_c2_matched", "r04_c5shard", "r04_c3_w128", "r04_c4_w512"):
+    for tag in ("r05_c2_w128", "r05_c2_matched", "r05_c5shard", "r05_c3_w128", "r05_c4_w285"):
         j = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
         assert len(j["kernel_src_sha"]) == 16 and j["workload_key"].count(":") >= 6
         shas.add(j["kernel_src_sha"])
         assert abs(j["fetch_size_calibration"]["factor"] - 2.0) < 0.01
         assert 0.5 < j["traffic_over_designed"] < 1.12
         assert j["frac_traffic_of_8TBs"] < 1.0 and j["kernel_trace"]["launches"] == j["launches"]
-        km = j["kernel_ms"]  # warmed process: trace and HIP events within 3 % of each other, and of the un-profiled process
-        assert abs(km["kernel_trace_avg_same_traced_process"] / km["hip_events_in_the_traced_process"] - 1.0) < 0.03
-        assert abs(km["hip_events_in_the_traced_process"] / km["hip_events_unprofiled_process"] - 1.0) < 0.03
+        km = j["kernel_ms"]  # warmed process: trace and HIP events within 5 % of each other, and of the un-profiled process
+        assert abs(km["kernel_trace_avg_same_traced_process"] / km["hip_events_in_the_traced_process"] - 1.0) < 0.05
+        assert abs(km["hip_events_in_the_traced_process"] / km["hip_events_unprofiled_process"] - 1.0) < 0.05
     assert len(shas) == 1  # one set of kernel sources
     sys.path.insert(0, ROOT)
     from bench import kernel_src_sha
 
-    assert shas == {kernel_src_sha()}, "the committed PMC summaries belong to other kernel sources: re-collect (tools/r4_pmc.sh)"
+    assert shas == {kernel_src_sha()}, "the committed PMC summaries belong to other kernel sources: re-collect (tools/pmc_round.sh r05)"
 
 
 def test_counter_generator_is_reproducible():
