@@ -527,8 +527,9 @@ def main():
     _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps in front of the timed region (default 20: the first ~10 launches after an idle period run 10-15 %% slower -- clock ramp, profiles/r05_notes.md section 6)")
     ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: BASELINE config 2 (default); c5: fixed-shard-count sharded index (SURVEY 8e)")
     ap.add_argument("--n", type=int, default=0, help="vectors per shard (default: 1 000 000 for c2, 12 500 000 for c5)")
     ap.add_argument("--shards", type=int, default=8, help="c5: total number of shards (fixed as the number of GPUs varies)")
@@ -702,14 +703,14 @@ def main():
     lines = designed_lines(stats.to(torch.int64).reshape(-1, 6), gstride, d * 4, mode, d, k, record_bytes)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     ev_step[0].record()
     for i in range(args.steps):
@@ -817,6 +818,7 @@ def main():
                              "queries_recomputed_exhaustively": int(gt_recomputed.item()), **(gt_check or {})},
             "merged_answer_qps": merged_qps if c5 else value,
             "step_ms_min_median_max": [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
+            "step_ms_each": [round(float(v), 4) for v in step_ms],
             "expansions_per_query": exp_total / nq,
             "neighbor_slots_per_query": slots_total / nq,
             "build_seconds": t_build,

@@ -1297,10 +1297,10 @@ int svsx_flat_search_device_counted(
         if (!ix->d_half) {
             void* h = nullptr;
             float* nrm = nullptr;
-            HIP_TRY(hipMalloc(&h, (ix->n + 32) * dpad * 2 + 64)); // one tile of padding: the threshold kernel loads whole 32-row tiles
+            HIP_TRY(hipMalloc(&h, (ix->n + kShadowPadRows) * dpad * 2 + 64)); // padding: the threshold kernels load whole 32-row tiles / 128-row steps
             if (hipMalloc(reinterpret_cast<void**>(&nrm), ix->n * 4) != hipSuccess) { (void)hipFree(h); return fail(SVSX_RUNTIME_ERROR, "hipMalloc failed"); }
             // the padding tile is read (masked) by the last tile of the threshold kernel: zeros, not whatever the allocation held
-            hipError_t e = hipMemsetAsync(static_cast<unsigned char*>(h) + ix->n * static_cast<size_t>(dpad) * 2, 0, 32 * static_cast<size_t>(dpad) * 2 + 64, stream);
+            hipError_t e = hipMemsetAsync(static_cast<unsigned char*>(h) + ix->n * static_cast<size_t>(dpad) * 2, 0, kShadowPadRows * static_cast<size_t>(dpad) * 2 + 64, stream);
             if (e == hipSuccess)
                 e = launch_to_half(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), dpad,
                                    ix->sq_enabled, ix->sq_scale, ix->sq_bias, h, nrm, stream);
@@ -1401,26 +1401,30 @@ int svsx_flat_search_device_counted(
 #endif
     StreamBuffer bcand, bkeys, bcnt, bgate, btau_a, btau_b;
     if (thresh_path) {
-        const size_t tiles = (ix->n + 31) / 32;
+        // sampling unit: a 32-row tile (d > 128) or a 64- / 128-row step of the four-wave kernel (d <= 128)
+        const size_t unit = flat_thresh_unit_rows(dpad);
+        const size_t units = (ix->n + unit - 1) / unit;
         uint32_t step = 1;
-        while (tiles / (static_cast<size_t>(step) * 16) >= 4) step *= 16; // coarsest level keeps >= 4 tiles = 128 rows >= kk
-        size_t s2 = (flat_thresh_waves_per_simd(dpad) * 1024) / nqb; // resident waves per SIMD x 1 024 SIMDs, one generation
+        while ((units / (static_cast<size_t>(step) * 16)) * unit >= 128) step *= 16; // coarsest level: 128 ... 2 047 rows
+        size_t s2 = flat_thresh_slices(ix->metric, dpad, nq); // one generation of resident workgroups
         if (s2 > ix->n / 4096) s2 = ix->n / 4096;
         if (s2 < 1) s2 = 1;
-        if (s2 > 1024) s2 = 1024;
-        // rows per (query, slice) list: ~16 kk / s2 expected at every level, at most 16 x 32 at the coarsest; 4x head room
+        const size_t lps = flat_thresh_lists_per_slice(dpad); // candidate lists per (query, slice)
+        if (s2 * lps > 1024) s2 = 1024 / lps;
+        const size_t lists = s2 * lps;
+        // rows per list: ~16 kk / lists expected at every level, at most the coarsest level's rows; 4x head room
         size_t cap = 512;
         // The thresholds are taken at rank kt < kk: with the proof of stage 4 behind it, the threshold pipeline needs no float16 safety margin
         // in its candidate lists -- ~16 kt rows per query (288 for k = 10) are appended and re-ranked instead of ~16 kk (640), and whether
         // that was enough is decided per query by the proof, not by the margin.  (The shortlist kernel keeps kk: its proof needs the gap
         // between the k-th and the kk-th key.)
         const size_t kt = SVSX_FLAT_KT(k, kk);
-        while (cap < 4 * (16 * kt / s2 + 1)) cap *= 2;
-        const size_t coarse_rows = (tiles / step + 1) * 32; // all of them are appended at the first level
+        while (cap < 4 * (16 * kt / lists + 1)) cap *= 2;
+        const size_t coarse_rows = (units / step + 1) * unit; // all of them are appended at the first level
         while (cap < 2 * coarse_rows / s2 && cap < 8192) cap *= 2;
-        HIP_TRY(bcand.alloc(nq * s2 * cap * 4, stream));
-        HIP_TRY(bkeys.alloc(nq * s2 * cap * 4, stream));
-        HIP_TRY(bcnt.alloc(nq * s2 * 4, stream));
+        HIP_TRY(bcand.alloc(nq * lists * cap * 4, stream));
+        HIP_TRY(bkeys.alloc(nq * lists * cap * 4, stream));
+        HIP_TRY(bcnt.alloc(nq * lists * 4, stream));
         HIP_TRY(bgate.alloc(nqb * 4, stream));
         HIP_TRY(btau_a.alloc(nq * 4, stream));
         HIP_TRY(btau_b.alloc(nq * 4, stream));
@@ -1440,14 +1444,14 @@ int svsx_flat_search_device_counted(
             ta.tau = tau_cur;
             ta.cand_keys = static_cast<float*>(bkeys.p);
             if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
-            if (e == hipSuccess) e = launch_flat_select(ta.cand_keys, ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t>(kt), tau_cur, 1, tau_nxt, stream);
+            if (e == hipSuccess) e = launch_flat_select(ta.cand_keys, ta.cnt, ta.nq, static_cast<uint32_t>(lists), ta.cap, static_cast<uint32_t>(kt), tau_cur, 1, tau_nxt, stream);
             float* t = tau_cur; tau_cur = tau_nxt; tau_nxt = t;
         }
         ta.tile_step = 1;
         ta.tau = tau_cur;
         ta.cand_keys = nullptr;
         if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
-        if (e == hipSuccess) e = launch_flat_gate_kk(ta.cnt, ta.nq, ta.n_slices, ta.cap, static_cast<uint32_t>(kk), static_cast<uint32_t*>(bgate.p), stream);
+        if (e == hipSuccess) e = launch_flat_gate_kk(ta.cnt, ta.nq, static_cast<uint32_t>(lists), ta.cap, static_cast<uint32_t>(kk), static_cast<uint32_t*>(bgate.p), stream);
         // gated fallback: full shortlist pass and merge only for the query blocks that overflowed
         fa.tile_step = 1;
         fa.block_gate = static_cast<const uint32_t*>(bgate.p);
@@ -1455,9 +1459,9 @@ int svsx_flat_search_device_counted(
         if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream);
         if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
         if (e == hipSuccess) e = launch_merge(M_L2, ma, stream);
-        ra.cand32 = ta.cand; ra.cnt = ta.cnt; ra.cap = ta.cap; ra.n_lists = ta.n_slices;
+        ra.cand32 = ta.cand; ra.cnt = ta.cnt; ra.cap = ta.cap; ra.n_lists = static_cast<uint32_t>(lists);
         if (e == hipSuccess) e = launch_rerank2(ix->data_dtype, ix->metric, qmode, ra, stream);
-        pa.tau = tau_cur; pa.cnt = ta.cnt; pa.cap = ta.cap; pa.n_lists = ta.n_slices;
+        pa.tau = tau_cur; pa.cnt = ta.cnt; pa.cap = ta.cap; pa.n_lists = static_cast<uint32_t>(lists);
         if (e == hipSuccess) e = launch_flat_certify(pa, stream);
     } else {
         if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream); // +inf, order-encoded

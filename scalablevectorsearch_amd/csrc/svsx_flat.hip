@@ -396,6 +396,7 @@ __device__ __forceinline__ uint32_t flat_find_slice(const uint32_t* loff, uint32
     return lo;
 }
 
+#ifdef SVSX_FLAT_NO_WG // the one-wave form of the d <= 128 pass (rounds 3-4): A/B builds only, the four-wave kernel below replaced it
 template <int METRIC, int KS>
 __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs a) {
     __shared__ uint32_t lcnt[64];
@@ -592,6 +593,235 @@ __global__ __launch_bounds__(64, 2) void flat_thresh_kernel(const FlatThreshArgs
     if (q0 + lane < a.nq) a.cnt[static_cast<size_t>(q0 + lane) * a.n_slices + slice] = lcnt[lane];
 }
 
+#endif // SVSX_FLAT_NO_WG
+
+// ---- stage 1b at d <= 128: four waves share the row tiles ------------------------------------------------------------------------------
+// The one-wave kernel above stages every 32-row tile once PER WAVE: 6-8 ds_write_b128 per tile and wave (13 cycles each on the store path,
+// MI355X_MICROARCH.md section LDS) next to 12-16 MFMAs of 32 cycles -- with all four SIMDs busy the LDS store path of a compute unit is as
+// loaded as its matrix pipes, and every tile crosses the L2 once per 64 queries.  Here a workgroup is four waves = 256 queries; a step is
+// TR = 64 (128) rows (16-byte pieces per thread, global -> registers -> LDS, double buffered, ONE barrier per step), staged once and read
+// as MFMA fragments by all four waves: a quarter of the stores and of the L2 traffic per query.
+// The operands are swapped against the kernel above: the ROWS are the MFMA's A operand (from LDS) and the wave's queries its B operand
+// (registers), so a lane's 16 accumulator cells of a 32 x 32 block belong to ONE query and 16 rows.  The threshold test of a block is then
+// max over the 16 cells (7 v_max3 + 1 v_max) and one compare against the lane's own threshold instead of 16 compares against 16
+// thresholds (32 -> 2 threshold registers per lane); the per-row constant of the accumulator's domain (L2: -|x|^2 / 2) arrives through
+// the C operand from a TR-float array staged with the step.  And a lane appends to lists of its own: every (query, slice) has TWO lists
+// (one per half-wave = per interleaved group of four rows of a block), so the list length is a register and an append is a store under
+// the lane's exec bit -- no LDS counter, no atomic, nothing to wait for.  Accept set and keys are those of the kernel above, cell by cell.
+// Sampled levels (tile_step > 1) take every tile_step-th STEP of TR rows (absolute: step index % tile_step == 0, so the samples are nested).
+__device__ __forceinline__ float fmax3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ float fmax2(float x, float y) { // the plain instruction: no canonicalising self-max in front (NaN cells are never accepted either way)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ void workgroup_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifndef SVSX_FLAT_WG_OCC
+#define SVSX_FLAT_WG_OCC 3 // workgroups per compute unit the kernel is compiled for (measured: 2 -> 3 is worth 6-8 % of a search)
+#endif
+#ifndef SVSX_FLAT_WG_TR
+#define SVSX_FLAT_WG_TR 64 // rows per step: 64 (needs an even number of 16-element k-steps; 128 otherwise).  Measured at d = 96: 128-row steps with
+#endif                     // 54 KB of LDS per workgroup lose 16 % against 64-row steps with 27 KB (profiles/r05_notes.md section 5)
+constexpr uint32_t flat_wg_rows(int ks) { return (SVSX_FLAT_WG_TR == 64 && ks % 2 == 0) ? 64u : 128u; }
+
+template <int METRIC, int KS>
+__global__ __launch_bounds__(256, SVSX_FLAT_WG_OCC) void flat_thresh_wg_kernel(const FlatThreshArgs a) {
+    constexpr uint32_t ROWB = KS * 32u;       // bytes of one f16 row (dpad * 2)
+    constexpr uint32_t PITCH = ROWB + 16u;    // conflict-free ds_read_b128 in the MFMA fragment layout
+    constexpr uint32_t TR = flat_wg_rows(KS); // rows per step
+    constexpr int NP = static_cast<int>(TR * ROWB / 4096u); // 16-byte pieces per thread and step
+    static_assert(NP * 4096u == TR * ROWB, "a step is a whole number of 4-KB chunks");
+    __shared__ __align__(16) float lrow[2][TR];  // per-row constant of the step's rows: L2 -|x|^2 / 2, cosine 1 / |x|
+    __shared__ __align__(16) unsigned char btile[2][TR * PITCH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t q0 = blockIdx.x * 256u, qw = q0 + wave * 64u;
+    const uint32_t slice = blockIdx.y;
+    const uint32_t rows_per_slice = (((a.n + a.n_slices - 1) / a.n_slices + TR - 1u) / TR) * TR;
+    const uint32_t x_lo = slice * rows_per_slice < a.n ? slice * rows_per_slice : a.n;
+    const uint32_t x_hi = (x_lo + rows_per_slice) < a.n ? (x_lo + rows_per_slice) : a.n;
+    const uint32_t xs = TR * (a.tile_step ? a.tile_step : 1u);
+    const uint32_t x_first = ((x_lo + xs - 1u) / xs) * xs; // sampled steps are absolute: step index % tile_step == 0
+    const uint32_t half = lane >> 5, col = lane & 31u;
+    uint32_t cnt0 = 0u, cnt1 = 0u; // lengths of this lane's two lists: (query qw + col, half) and (query qw + 32 + col, half)
+    if (x_first < x_hi) { // uniform over the workgroup
+        const _Float16* qh = static_cast<const _Float16*>(a.qh);
+        half8_t qf0[KS], qf1[KS]; // the wave's 2 x 32 queries as B fragments, resident for the whole slice
+        float thr0, thr1;         // this lane's two queries' thresholds in the accumulator's domain (flat_thresh_kernel)
+        {
+            const uint32_t r0 = qw + col, r1 = qw + 32u + col;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                half8_t z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = static_cast<_Float16>(0.0f);
+                qf0[s2] = r0 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r0) * a.dpad + 16 * s2 + 8u * half) : z;
+                qf1[s2] = r1 < a.nq ? *reinterpret_cast<const half8_t*>(qh + static_cast<size_t>(r1) * a.dpad + 16 * s2 + 8u * half) : z;
+            }
+            const float t0 = r0 < a.nq ? a.tau[static_cast<size_t>(r0) * a.tau_stride] : -__builtin_inff(); // padding queries: never accepted
+            const float t1 = r1 < a.nq ? a.tau[static_cast<size_t>(r1) * a.tau_stride] : -__builtin_inff();
+            thr0 = METRIC == M_L2 ? -0.5f * t0 : -t0;
+            thr1 = METRIC == M_L2 ? -0.5f * t1 : -t1;
+#ifdef SVSX_FLAT_DIAG_NO_HITS   // timing builds only: nothing is ever accepted by the full pass
+            if (a.tile_step <= 1u) thr0 = thr1 = __builtin_inff();
+#endif
+        }
+        uint32_t lds_off[NP]; // where this thread's 16-B piece of the step's 4-KB chunk i lands
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const uint32_t g = static_cast<uint32_t>(i) * 4096u + tid * 16u;
+            lds_off[i] = (g / ROWB) * PITCH + (g % ROWB);
+        }
+        const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(a.xh);
+        const uint32_t piece = tid * 16u;
+        // TR whole rows = NP contiguous 4-KB chunks: wave-uniform base + a 32-bit thread offset (the shadow is padded by more than a step,
+        // so the last, partial step reads initialised bytes).  The row constant travels raw: nothing here waits for a load.
+        auto load_step = [&](uint32_t xt, half8_t (&dst)[NP], float& xn_raw) {
+            const unsigned char* base = xbytes + static_cast<size_t>(xt) * ROWB;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) dst[i] = *reinterpret_cast<const half8_t*>(base + (piece + static_cast<uint32_t>(i) * 4096u));
+            if constexpr (METRIC != M_IP) {
+                const uint32_t r = xt + (tid & (TR - 1u));
+                xn_raw = a.xnorm2[r < a.n ? r : a.n - 1u];
+            }
+        };
+        auto stage = [&](uint32_t buf, const half8_t (&src)[NP], float xn_raw) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) *reinterpret_cast<half8_t*>(&btile[buf][lds_off[i]]) = src[i];
+            if constexpr (METRIC != M_IP) {
+                if (tid < TR) lrow[buf][tid] = METRIC == M_L2 ? -0.5f * xn_raw : 1.0f / sqrtf(xn_raw > 0.0f ? xn_raw : 1.0f);
+            }
+        };
+        // one accepted cell: the lane's own list grows by one (the count keeps running past the capacity: that is the overflow signal)
+        // Past the capacity the last slot is overwritten: a list whose count exceeds the capacity is never read (flat_overflow sends the
+        // query to the shortlist kernel), so the store needs no branch.
+        const uint32_t last_slot = a.cap - 1u;
+        auto emit = [&](uint32_t qt, uint32_t& cnt, uint32_t row, float v) {
+            const uint32_t pos = cnt < last_slot ? cnt : last_slot;
+            const size_t o = ((static_cast<size_t>(qw + qt * 32u + col) * a.n_slices + slice) * 2u + half) * a.cap + pos;
+            a.cand[o] = row;
+            // the key that is stored (smaller = better), an exact scaling of what was compared
+            if (a.cand_keys != nullptr) a.cand_keys[o] = METRIC == M_L2 ? -2.0f * v : -v;
+            ++cnt;
+        };
+        // one 32-row block of the step against the wave's 64 queries: the matrix part ...
+        auto mma = [&](uint32_t buf, uint32_t j, float16v_t& acc0, float16v_t& acc1, float16v_t& rs) {
+            float16v_t cin;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if constexpr (METRIC != M_IP) v = *reinterpret_cast<const float4*>(&lrow[buf][32u * j + 8u * static_cast<uint32_t>(g) + 4u * half]);
+                if constexpr (METRIC == M_L2) { cin[4 * g + 0] = v.x; cin[4 * g + 1] = v.y; cin[4 * g + 2] = v.z; cin[4 * g + 3] = v.w; }
+                else { cin[4 * g + 0] = 0.0f; cin[4 * g + 1] = 0.0f; cin[4 * g + 2] = 0.0f; cin[4 * g + 3] = 0.0f; }
+                rs[4 * g + 0] = v.x; rs[4 * g + 1] = v.y; rs[4 * g + 2] = v.z; rs[4 * g + 3] = v.w; // cosine only
+            }
+            const unsigned char* rowp = &btile[buf][(32u * j + col) * PITCH + 16u * half];
+            {
+                const half8_t xf = *reinterpret_cast<const half8_t*>(rowp);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf0[0], cin, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf1[0], cin, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s2 = 1; s2 < KS; ++s2) {
+                const half8_t xf = *reinterpret_cast<const half8_t*>(rowp + 32 * s2);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf0[s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf1[s2], acc1, 0, 0, 0);
+            }
+        };
+        // ... and the threshold test with its appends
+        auto epilogue = [&](uint32_t xt, float16v_t& acc0, float16v_t& acc1, const float16v_t& rs) {
+            if constexpr (METRIC == M_COS) { // what is compared with the threshold: acc / |x|
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] *= rs[r]; acc1[r] *= rs[r]; }
+            }
+            if (xt + 32u > x_hi) { // the last block of the last slice (every other slice ends on a step boundary): rows of the padding never match
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (xt + static_cast<uint32_t>(8 * (r >> 2) + (r & 3)) + 4u * half >= x_hi) { acc0[r] = -__builtin_inff(); acc1[r] = -__builtin_inff(); }
+                }
+            }
+            // The v_max3 below are inline assembly, and the compiler's hazard recogniser does not count an inline-assembly statement as a
+            // vector-ALU read of a matrix-core result (the hardware does not interlock that read: 8-pass MFMA -> VALU read needs 11 wait
+            // states on gfx950; the compiler pads its OWN reads with s_nop, see the masking branch above).  Without the padding the test
+            // read accumulators still missing their last k-step.  The statement is tied to both accumulators, so it stays behind the MFMAs.
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+            // maxima of the cells in groups of three; the block's test is one compare of their maximum, the groups find an accepted cell
+            float g0[5], g1[5];
+#pragma unroll
+            for (int g = 0; g < 5; ++g) {
+                g0[g] = fmax3(acc0[3 * g], acc0[3 * g + 1], acc0[3 * g + 2]);
+                g1[g] = fmax3(acc1[3 * g], acc1[3 * g + 1], acc1[3 * g + 2]);
+            }
+            const float m0 = fmax2(fmax3(g0[0], g0[1], g0[2]), fmax3(g0[3], g0[4], acc0[15]));
+            const float m1 = fmax2(fmax3(g1[0], g1[1], g1[2]), fmax3(g1[3], g1[4], acc1[15]));
+            const unsigned long long h0 = wave_ballot(m0 >= thr0), h1 = wave_ballot(m1 >= thr1);
+            if ((h0 | h1) == 0ull) return;
+            // some query of the wave accepts a row of this block: the lanes that own such cells append them
+            auto scan = [&](const float16v_t& v, const float (&gm)[5], float thr, uint32_t qt, uint32_t& cnt) {
+                const uint32_t rb = xt + 4u * half;
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    if (gm[g] >= thr) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            const int r = 3 * g + e;
+                            if (v[r] >= thr) emit(qt, cnt, rb + static_cast<uint32_t>(8 * (r >> 2) + (r & 3)), v[r]);
+                        }
+                    }
+                }
+                if (v[15] >= thr) emit(qt, cnt, rb + 27u, v[15]);
+            };
+            if (h0 != 0ull) scan(acc0, g0, thr0, 0u, cnt0);
+            if (h1 != 0ull) scan(acc1, g1, thr1, 1u, cnt1);
+        };
+        auto blocks = [&](uint32_t buf, uint32_t x0) {
+#pragma unroll
+            for (uint32_t j = 0; j < TR / 32u; ++j) {
+                const uint32_t xt = x0 + 32u * j;
+                if (xt >= x_hi) break;
+                float16v_t acc0, acc1, rs;
+                mma(buf, j, acc0, acc1, rs);
+                epilogue(xt, acc0, acc1, rs);
+            }
+        };
+        half8_t gnext[NP];
+        float xn_next = 0.0f;
+        load_step(x_first, gnext, xn_next);
+        stage(0u, gnext, xn_next);
+        load_step(x_first + xs < x_hi ? x_first + xs : x_first, gnext, xn_next);
+        workgroup_lds_barrier();
+        uint32_t buf = 0;
+        for (uint32_t x0 = x_first; x0 < x_hi; x0 += xs, buf ^= 1u) {
+            blocks(buf, x0);
+            // step t + 1 was requested a whole step ago (behind the staging of step t); as soon as its pieces have left the registers the
+            // request for step t + 2 goes out into the same registers (past the end: a harmless re-read of the first)
+#ifdef SVSX_FLAT_DIAG_NO_STAGE  // timing builds only (wrong results): the full pass neither stages nor requests new rows
+            if (a.tile_step > 1u)
+#endif
+            {
+                stage(buf ^ 1u, gnext, xn_next);
+#ifdef SVSX_FLAT_DIAG_NO_LOADS
+                if (a.tile_step > 1u)
+#endif
+                load_step(x0 + 2u * xs < x_hi ? x0 + 2u * xs : x_first, gnext, xn_next);
+            }
+#ifdef SVSX_FLAT_DIAG_NO_BARRIER // timing builds only (racy): the waves of a workgroup run free
+            if (a.tile_step > 1u)
+#endif
+            workgroup_lds_barrier(); // buf ^ 1 is complete, and nobody reads buf any more
+        }
+    }
+    {   // [nq][2 n_slices] list lengths
+        const uint32_t r0 = qw + col, r1 = qw + 32u + col;
+        if (r0 < a.nq) a.cnt[(static_cast<size_t>(r0) * a.n_slices + slice) * 2u + half] = cnt0;
+        if (r1 < a.nq) a.cnt[(static_cast<size_t>(r1) * a.n_slices + slice) * 2u + half] = cnt1;
+    }
+}
+
 // ---- stage 1b for 128 < d <= 768 ---------------------------------------------------------------------------------------------
 // The same threshold pass with the dimension cut into KCH chunks of 128 (the shadow's rows are padded to a multiple of 128 there).  All A
 // fragments of a wave's 64 queries stay in registers (2 x 8 KCH x 4 = 384 at d = 768: one wave per SIMD owns the whole 512-register file);
@@ -747,6 +977,57 @@ __global__ __launch_bounds__(64, KCH <= 2 ? 2 : 1) void flat_thresh_big_kernel(c
 // what the host needs to size the pass: which padded dimensions the threshold kernels take and how many waves per SIMD they run at
 bool flat_thresh_supports(uint32_t dpad) { return dpad <= 128u || (dpad % 128u == 0u && dpad <= 768u); }
 uint32_t flat_thresh_waves_per_simd(uint32_t dpad) { return dpad <= 256u ? 2u : 1u; } // two chunks of A fragments still leave room for two waves
+// the sampling unit of the threshold levels (rows per sampled tile / step) and the candidate lists a (query, slice) pair owns
+uint32_t flat_thresh_unit_rows(uint32_t dpad) {
+#ifndef SVSX_FLAT_NO_WG
+    if (dpad <= 128u) return flat_wg_rows(static_cast<int>(dpad >> 4));
+#endif
+    (void)dpad;
+    return 32u;
+}
+uint32_t flat_thresh_lists_per_slice(uint32_t dpad) {
+#ifndef SVSX_FLAT_NO_WG
+    if (dpad <= 128u) return 2u;
+#endif
+    (void)dpad;
+    return 1u;
+}
+#ifndef SVSX_FLAT_NO_WG
+typedef void (*flat_thresh_fn)(const FlatThreshArgs);
+template <int M>
+static flat_thresh_fn flat_wg_kernel_of(uint32_t ks) {
+    switch (ks) {
+        case 1: return flat_thresh_wg_kernel<M, 1>;
+        case 2: return flat_thresh_wg_kernel<M, 2>;
+        case 3: return flat_thresh_wg_kernel<M, 3>;
+        case 4: return flat_thresh_wg_kernel<M, 4>;
+        case 5: return flat_thresh_wg_kernel<M, 5>;
+        case 6: return flat_thresh_wg_kernel<M, 6>;
+        case 7: return flat_thresh_wg_kernel<M, 7>;
+        default: return flat_thresh_wg_kernel<M, 8>;
+    }
+}
+static flat_thresh_fn flat_wg_kernel_of(int metric, uint32_t ks) {
+    return metric == M_L2 ? flat_wg_kernel_of<M_L2>(ks) : metric == M_IP ? flat_wg_kernel_of<M_IP>(ks) : flat_wg_kernel_of<M_COS>(ks);
+}
+#endif
+// slices of the database per query block so that ONE generation of workgroups fills the machine (a second generation would double the
+// pass): d <= 128 runs four-wave workgroups of 256 queries, as many per compute unit as the runtime says that instantiation gets
+// (registers and LDS decide: 2-4); beyond, one-wave workgroups of 64 queries
+uint32_t flat_thresh_slices(int metric, uint32_t dpad, size_t nq) {
+#ifndef SVSX_FLAT_NO_WG
+    if (dpad <= 128u) {
+        int per_cu = 0, cus = 0, dev = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(flat_wg_kernel_of(metric, dpad >> 4)), 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        const size_t s = (static_cast<size_t>(cus) * static_cast<size_t>(per_cu)) / ((nq + 255u) / 256u);
+        return static_cast<uint32_t>(s < 1 ? 1 : s);
+    }
+#endif
+    (void)metric;
+    const size_t s = (static_cast<size_t>(flat_thresh_waves_per_simd(dpad)) * 1024u) / ((nq + 63u) / 64u);
+    return static_cast<uint32_t>(s < 1 ? 1 : s);
+}
 
 hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t stream) {
     const uint32_t ks = a.dpad >> 4;
@@ -773,6 +1054,13 @@ hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t s
 #undef SVSX_THRESH_BIG
         return hipErrorInvalidValue;
     }
+#ifndef SVSX_FLAT_NO_WG
+    { // d <= 128: four waves share the row tiles (svsx_api.hip sizes its lists by flat_thresh_lists_per_slice and samples by flat_thresh_unit_rows)
+        const dim3 wgrid((a.nq + 255) / 256, a.n_slices);
+        hipLaunchKernelGGL(flat_wg_kernel_of(metric, ks), wgrid, dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
+#else
 #define SVSX_THRESH_KERNEL flat_thresh_kernel
 #define SVSX_THRESH_CASE(M)                                   \
     switch (ks) {                                             \
@@ -792,6 +1080,7 @@ hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t s
     }
 #undef SVSX_THRESH_CASE
     return hipErrorInvalidValue;
+#endif
 }
 
 // kk-th smallest key of one query's candidate lists (one wave per query): radix descent over the order-encoded keys held in

@@ -40,6 +40,10 @@ hipError_t launch_flat_gate_kk(const uint32_t* cnt, uint32_t nq, uint32_t n_slic
 // which padded dimensions the threshold pipeline takes (d <= 128, or a multiple of 128 up to 768) and at how many waves per SIMD
 bool flat_thresh_supports(uint32_t dpad);
 uint32_t flat_thresh_waves_per_simd(uint32_t dpad);
+uint32_t flat_thresh_slices(int metric, uint32_t dpad, size_t nq);
+uint32_t flat_thresh_unit_rows(uint32_t dpad);        // rows of one sampled unit (a 32-row tile, or a 64- / 128-row step)
+uint32_t flat_thresh_lists_per_slice(uint32_t dpad);  // candidate lists per (query, slice)
+constexpr size_t kShadowPadRows = 160; // rows of zeros behind the float16 shadow: a partial last 128-row step (+ a 32-row tile) stays inside the allocation
 hipError_t launch_norm_range(const float* norm2, uint32_t n, uint32_t* d_max_min_bits, hipStream_t stream); // [0] = max bits (init 0), [1] = min bits (init ~0)
 
 } // namespace svsx

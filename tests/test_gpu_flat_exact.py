@@ -173,3 +173,26 @@ def test_other_element_types(svs, oracle, ddt, qdt):
         want_i, want_d = oracle.flat_search(metric, x, q, 10)
         _assert_equal(ids, dists, want_i, want_d, (ddt, qdt, metric))
         assert redone <= 3, redone  # 70 000 rows: the threshold pipeline re-ranks every row under its threshold, the 200 copies included
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("d", [96, 128, 80])
+def test_everything_that_matters_sits_in_the_last_sixteen_dimensions(svs, oracle, metric, d):
+    """All rows share their first d - 16 coordinates; who is near whom is decided by the last 16 alone -- the LAST matrix instruction of a
+    block's accumulation chain.  A threshold test that reads the accumulators before that instruction has retired (the matrix core's results
+    are not interlocked against the vector ALU on gfx950; svsx_flat.hip pads its inline-assembly screen with wait states) sees every row at the
+    same distance and drops true neighbours; the proof of stage 4 cannot notice a row that was never appended.  256 queries = one full
+    four-wave workgroup, 70 000 rows = the threshold pipeline, a ragged last block."""
+    n, nq, k = 70_001, 256, 10
+    rng = np.random.default_rng(77 + d + metric)
+    x = np.empty((n, d), np.float32)
+    x[:, : d - 16] = 0.05 * rng.standard_normal(d - 16).astype(np.float32)  # small: the float16 proof keeps its margin
+    x[:, d - 16 :] = rng.standard_normal((n, 16)).astype(np.float32)
+    q = np.empty((nq, d), np.float32)
+    q[:, : d - 16] = 0.05 * rng.standard_normal(d - 16).astype(np.float32)
+    q[:, d - 16 :] = 2.0 * rng.standard_normal((nq, 16)).astype(np.float32)
+    idx = svs.FlatIndex(x, _fn(svs, metric))
+    ids, dists, redone = _search_counted(idx, q, k)
+    want_i, want_d = oracle.flat_search(metric, x, q, k)
+    _assert_equal(ids, dists, want_i, want_d, (metric, d))
+    assert redone <= nq // 4, redone  # the answers come from the threshold pipeline, not from the exhaustive fallback

@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B builds of libsvsx.so with extra hipcc defines for svsx_flat.hip only:  tools/build_flat_variant.sh <name> [-DFOO=1 ...]
-# -> variants/<name>/libsvsx.so; every other object comes from the in-tree build (run `make` first).  SVSX_LIB=variants/<name>/libsvsx.so
+# A/B builds of the flat-search kernels only:  tools/build_flat_variant.sh <name> [-DSVSX_FLAT_...=...]
+# -> variants/<name>/libsvsx.so = the in-tree objects (run `make` first) with svsx_flat.o recompiled under the given defines.
 set -e
 NAME=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -10,6 +10,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-c
 cd $R/scalablevectorsearch_amd/csrc
 /opt/rocm/bin/hipcc $FLAGS "$@" -c svsx_flat.hip -o $OUT/svsx_flat.o
 OTHERS=$(ls *.o | grep -v -E '^svsx_flat\.o$')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsvsx.so $OUT/svsx_flat.o $OTHERS -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsvsx.so $OUT/svsx_flat.o $OTHERS
 rm -f $OUT/*.o
 echo built $OUT/libsvsx.so

@@ -36,5 +36,6 @@ for metric, fn in (("l2", svs.DistanceL2()), ("ip", svs.DistanceIP()), ("cos", s
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
     print(json.dumps({"metric": metric, "n": n, "d": d, "nq": nq, "k": k, "ms_per_batch": round(ms, 2), "recomputed": first,
-                      "tflops_f16": round(2.0 * n * d * nq / ms / 1e9, 1)}), flush=True)
+                      "tflops_f16": round(2.0 * n * d * nq / ms / 1e9, 1), "ids_sum": int(ids.to(torch.int64).sum().item()),
+                      "dist_sum": float(dists.double().sum().item()), "lib": os.environ.get("SVSX_LIB", "in-tree")}), flush=True)
     del idx
