@@ -622,15 +622,16 @@ __device__ __forceinline__ float fmax2(float x, float y) { // the plain instruct
 __device__ __forceinline__ void workgroup_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifndef SVSX_FLAT_WG_OCC
-#define SVSX_FLAT_WG_OCC 3 // workgroups per compute unit the kernel is compiled for (measured: 2 -> 3 is worth 6-8 % of a search)
-#endif
+#define SVSX_FLAT_WG_OCC 3 // workgroups per compute unit the kernel is compiled for.  Measured (profiles/r05_notes.md section 5): 2 -> 3 is worth
+#endif                     // 6-8 % of a search; forcing a fourth at d = 96 (128 registers, a few spills) loses 6-14 %; d <= 64 gets four or five anyway
+constexpr int flat_wg_occ(int) { return SVSX_FLAT_WG_OCC; }
 #ifndef SVSX_FLAT_WG_TR
 #define SVSX_FLAT_WG_TR 64 // rows per step: 64 (needs an even number of 16-element k-steps; 128 otherwise).  Measured at d = 96: 128-row steps with
 #endif                     // 54 KB of LDS per workgroup lose 16 % against 64-row steps with 27 KB (profiles/r05_notes.md section 5)
 constexpr uint32_t flat_wg_rows(int ks) { return (SVSX_FLAT_WG_TR == 64 && ks % 2 == 0) ? 64u : 128u; }
 
 template <int METRIC, int KS>
-__global__ __launch_bounds__(256, SVSX_FLAT_WG_OCC) void flat_thresh_wg_kernel(const FlatThreshArgs a) {
+__global__ __launch_bounds__(256, flat_wg_occ(KS)) void flat_thresh_wg_kernel(const FlatThreshArgs a) {
     constexpr uint32_t ROWB = KS * 32u;       // bytes of one f16 row (dpad * 2)
     constexpr uint32_t PITCH = ROWB + 16u;    // conflict-free ds_read_b128 in the MFMA fragment layout
     constexpr uint32_t TR = flat_wg_rows(KS); // rows per step
@@ -1083,8 +1084,11 @@ hipError_t launch_flat_thresh(int metric, const FlatThreshArgs& a, hipStream_t s
 #endif
 }
 
-// kk-th smallest key of one query's candidate lists (one wave per query): radix descent over the order-encoded keys held in
-// LDS.  Falls back to the coarser threshold when a list overflowed or holds fewer than kk rows.
+// kk-th smallest key of one query's candidate lists (one wave per query): radix descent over the order-encoded keys, most significant
+// differing bit first.  Lists of up to 512 keys (the usual case: ~16 kt rows per level) stay in registers, eight per lane -- one shift, one
+// compare and one scalar popcount per key and bit; longer ones (the coarsest level of a small shortlist) go through LDS as before.
+// Falls back to the coarser threshold when a list overflowed or holds fewer than kk rows.
+constexpr int kSelectRegs = 8;
 __global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict__ keys, const uint32_t* __restrict__ cnt, uint32_t nq,
                                                          uint32_t n_slices, uint32_t cap, uint32_t kk, const float* __restrict__ fb,
                                                          uint32_t fb_stride, float* __restrict__ out) {
@@ -1093,17 +1097,59 @@ __global__ __launch_bounds__(64) void flat_select_kernel(const float* __restrict
     uint32_t* buf = reinterpret_cast<uint32_t*>(select_smem);
     uint32_t* loff = buf + flat_select_cap(kk);
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
-    uint32_t total = 0;
-    const bool over = flat_overflow(cnt, q, n_slices, cap, total, flat_select_cap(kk));
-    if (over || total < kk) {
+    // list lengths: one parallel pass gives the offsets, the total and the overflow flag
+    bool lane_over = false;
+    for (uint32_t s0 = 0; s0 < n_slices; s0 += 64) {
+        const uint32_t s2 = s0 + lane;
+        lane_over = lane_over || (s2 < n_slices && cnt[static_cast<size_t>(q) * n_slices + s2] > cap);
+    }
+    flat_list_offsets(cnt, q, n_slices, loff, lane);
+    const uint32_t total = loff[n_slices];
+    if (wave_ballot(lane_over) != 0ull || total > flat_select_cap(kk) || total < kk) {
         if (lane == 0) out[q] = fb[static_cast<size_t>(q) * fb_stride];
         return;
     }
-    flat_list_offsets(cnt, q, n_slices, loff, lane);
-    for (uint32_t e = lane; e < total; e += 64) {
+    auto key_of = [&](uint32_t e) -> uint32_t {
         const uint32_t s2 = flat_find_slice(loff, n_slices, e);
-        buf[e] = enc_key(keys[(static_cast<size_t>(q) * n_slices + s2) * cap + (e - loff[s2])]);
+        return enc_key(keys[(static_cast<size_t>(q) * n_slices + s2) * cap + (e - loff[s2])]);
+    };
+    if (total <= 64u * kSelectRegs) {
+        uint32_t v[kSelectRegs];
+#pragma unroll
+        for (int r = 0; r < kSelectRegs; ++r) {
+            const uint32_t e = lane + 64u * static_cast<uint32_t>(r);
+            v[r] = e < total ? key_of(e) : 0xFFFFFFFFu; // padding: never has a zero bit under a matching prefix, so it is never counted
+        }
+        const uint32_t v0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v[0]))); // element 0 exists: total >= kk >= 1
+        uint32_t diff = 0;
+#pragma unroll
+        for (int r = 0; r < kSelectRegs; ++r) {
+            if (lane + 64u * static_cast<uint32_t>(r) < total) diff |= v[r] ^ v0;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) diff |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(diff), off));
+        diff = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(diff)));
+        if (diff == 0u) { // every key is the same
+            if (lane == 0) out[q] = dec_key(v0);
+            return;
+        }
+        const int top = 31 - __builtin_clz(diff);
+        uint32_t prefix = top == 31 ? 0u : (v0 & ~((2u << top) - 1u)); // the bits all keys share
+        uint32_t remaining = kk;
+        for (int bit = top; bit >= 0; --bit) {
+            const uint32_t want = prefix >> bit; // this bit still zero
+            uint32_t zeros = 0;
+#pragma unroll
+            for (int r = 0; r < kSelectRegs; ++r) zeros += static_cast<uint32_t>(__popcll(wave_ballot((v[r] >> bit) == want)));
+            if (remaining > zeros) {
+                remaining -= zeros;
+                prefix |= 1u << bit;
+            }
+        }
+        if (lane == 0) out[q] = dec_key(prefix);
+        return;
     }
+    for (uint32_t e = lane; e < total; e += 64) buf[e] = key_of(e);
     lds_order();
     uint32_t prefix = 0, remaining = kk;
     for (int bit = 31; bit >= 0; --bit) {

@@ -7,7 +7,7 @@ timeout 600 python -m pytest tests/test_gpu_flat_exact.py -q -x > $OUT/tests.log
 tail -2 $OUT/tests.log | tee -a $OUT/summary.txt
 for v in in-tree "$@"; do
   if [ "$v" = in-tree ]; then unset SVSX_LIB; else export SVSX_LIB=$PWD/variants/$v/libsvsx.so; fi
-  for cfg in "1000000 96 10000 10 l2" "1000000 128 10000 10 ip" "1000000 96 10000 10 cos"; do
+  for cfg in "1000000 96 10000 10 l2" "1000000 128 10000 10 ip" "1000000 96 10000 10 cos" "1000000 64 10000 10 l2"; do
     timeout 300 python tools/flat_check.py $cfg 2>>$OUT/err.log | sed "s/^/$v /" | tee -a $OUT/summary.txt
   done
 done
