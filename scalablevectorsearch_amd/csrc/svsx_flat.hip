@@ -721,20 +721,30 @@ __global__ __launch_bounds__(256, flat_wg_occ(KS)) void flat_thresh_wg_kernel(co
                 rs[4 * g + 0] = v.x; rs[4 * g + 1] = v.y; rs[4 * g + 2] = v.z; rs[4 * g + 3] = v.w; // cosine only
             }
             const unsigned char* rowp = &btile[buf][(32u * j + col) * PITCH + 16u * half];
-            {
-                const half8_t xf = *reinterpret_cast<const half8_t*>(rowp);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf0[0], cin, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf1[0], cin, 0, 0, 0);
-            }
+            // (Requesting ALL of the block's fragments before its first MFMA -- one LDS round trip per block instead of one per MFMA pair,
+            // -DSVSX_FLAT_WG_FRONTLOAD -- was measured: no gain, 16 more registers; the compiler's order stays.)
+            half8_t xf[KS];
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) xf[s2] = *reinterpret_cast<const half8_t*>(rowp + 32 * s2);
+#ifdef SVSX_FLAT_WG_FRONTLOAD
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[0], qf0[0], cin, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[0], qf1[0], cin, 0, 0, 0);
 #pragma unroll
             for (int s2 = 1; s2 < KS; ++s2) {
-                const half8_t xf = *reinterpret_cast<const half8_t*>(rowp + 32 * s2);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf0[s2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, qf1[s2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[s2], qf0[s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[s2], qf1[s2], acc1, 0, 0, 0);
             }
         };
         // ... and the threshold test with its appends
         auto epilogue = [&](uint32_t xt, float16v_t& acc0, float16v_t& acc1, const float16v_t& rs) {
+#ifdef SVSX_FLAT_DIAG_NO_EPILOGUE  // timing builds only: the MFMAs stay alive through one compare
+            if (a.tile_step <= 1u) {
+                if (acc0[0] + acc1[15] == 123.456f) ++cnt0;
+                return;
+            }
+#endif
             if constexpr (METRIC == M_COS) { // what is compared with the threshold: acc / |x|
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[r] *= rs[r]; acc1[r] *= rs[r]; }
