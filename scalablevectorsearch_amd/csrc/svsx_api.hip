@@ -1219,8 +1219,11 @@ int svsx_distance_batch(
     return SVSX_SUCCESS;
 }
 
+// rank at which the threshold levels take their next threshold: k + 4, at least 12, at most the shortlist length (round 4: k + 8, at least 16;
+// with the cheaper appends of round 5 the ~16 kt appended rows per query weigh more: k + 4 is worth 4-8 % of a search, k + 2 one more per cent,
+// and no query of the bench sets needs the exhaustive pass at either; profiles/r05_notes.md section 5)
 #ifndef SVSX_FLAT_KT
-#define SVSX_FLAT_KT(k, kk) ((k) + 8 > 16 ? ((k) + 8 < (kk) ? (k) + 8 : (kk)) : (16 < (kk) ? size_t(16) : (kk)))
+#define SVSX_FLAT_KT(k, kk) ((k) + 4 > 12 ? ((k) + 4 < (kk) ? (k) + 4 : (kk)) : (12 < (kk) ? size_t(12) : (kk)))
 #endif
 int svsx_flat_search_device(
     const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream
@@ -1415,7 +1418,7 @@ int svsx_flat_search_device_counted(
         // rows per list: ~16 kk / lists expected at every level, at most the coarsest level's rows; 4x head room
         size_t cap = 512;
         // The thresholds are taken at rank kt < kk: with the proof of stage 4 behind it, the threshold pipeline needs no float16 safety margin
-        // in its candidate lists -- ~16 kt rows per query (288 for k = 10) are appended and re-ranked instead of ~16 kk (640), and whether
+        // in its candidate lists -- ~16 kt rows per query (224 for k = 10) are appended and re-ranked instead of ~16 kk (640), and whether
         // that was enough is decided per query by the proof, not by the margin.  (The shortlist kernel keeps kk: its proof needs the gap
         // between the k-th and the kk-th key.)
         const size_t kt = SVSX_FLAT_KT(k, kk);
