@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r5_flat.sh <tag> [variants...]: flat-search A/B on one GPU lease -- parity tests on the in-tree library, then tools/flat_check.py per library
+# tools/flat_ab.sh <tag> [variants...]: flat-search A/B on one GPU lease -- parity tests on the in-tree library, then tools/flat_check.py per library
 TAG=${1:-r05flat}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r5_flat_diag.sh <tag> variants...: timing builds of the flat threshold kernel (results wrong by design), per-kernel times from a trace of each
+# tools/flat_diag.sh <tag> variants...: timing builds of the flat threshold kernel (results wrong by design), per-kernel times from a trace of each
 TAG=${1:-r05flatd}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null

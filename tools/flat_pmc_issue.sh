@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r5_flat_pmc_diag.sh <tag>: issue / wait counters of the flat threshold kernel's full pass (in-tree library), 10 000 x 1 M x 96 L2
+# tools/flat_pmc_issue.sh <tag>: issue / wait counters of the flat threshold kernel's full pass (in-tree library), 10 000 x 1 M x 96 L2
 TAG=${1:-r05flatp}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; R=$PWD
 cd /tmp && export TMPDIR=/tmp
 i=0
