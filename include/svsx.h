@@ -216,10 +216,10 @@ int svsx_sharded_search_device(
 );
 
 /* Exhaustive search: svs::index::flat::FlatIndex::search (index/flat/flat.h:322-460) -- every query
- * against every vector, k <= 224 best by (distance, then id), EXACT.  A float16 MFMA pass shortlists min(128, max(4k, k+32)) candidates per query
- * (k + 32 beyond k = 96; always >= k + 32; large sets up to d = 768: every row under a sampled threshold, about 16 (k + 8) per query), which are re-ranked with the exact reference-order distance kernels; then every query's answer is
+ * against every vector, k best by (distance, then id), EXACT, any k and d.  Up to k = 224 a float16 MFMA pass shortlists min(128, max(4k, k+32)) candidates per query
+ * (k + 32 beyond k = 96; always >= k + 32; large sets up to d = 768: every row under a sampled threshold, about 16 (k + 4) per query), which are re-ranked with the exact reference-order distance kernels; then every query's answer is
  * proven against the float16 rounding bounds (every row left out is strictly worse than the k-th answer), and a query that cannot be proven
- * (near-ties below float16 resolution, non-finite values, zero rows under cosine) is recomputed by an exhaustive float32 pass.
+ * (near-ties below float16 resolution, non-finite values, zero rows under cosine) is recomputed by an exhaustive float32 pass (which alone answers k > 224 and d beyond ~1 200).
  * _counted adds the number of such queries to *d_recomputed (a device word the caller zeroes; NULL = not wanted).
  * Works on any index, including one created with graph == NULL (a flat index).  Device pointers, enqueued on hip_stream; d_dists may be NULL. */
 int svsx_flat_search_device(
