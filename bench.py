@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured by a float4 copy)
+PREWARM_MIN, PREWARM_MAX = 24, 64  # untimed steps in front of --warmup (clock ramp after idle; see the timed region in main)
 LINE = 128             # bytes per fabric request: a 64-byte gather costs the same as a 128-byte one (tools/ubench/gather_bench)
 
 
@@ -476,7 +477,7 @@ def config4_point(args, svs, device, local_rank, k, t_run0):
             lo_w = mid + 1
     sp4 = svs.VamanaSearchParameters(svs.SearchBufferConfig(lo_w), 1)
     i4.search_device(q4, k, sp4, d_ids64=ids4, d_dists=dd4, d_stats=st4)
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 12)):  # informational points warm up on their own: at least 12 launches whatever --warmup says
         i4.search_device(q4, k, sp4, d_ids64=ids4, d_dists=dd4)
     torch.cuda.synchronize()
     ev4 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, args.steps // 2))]
@@ -705,6 +706,25 @@ def main():
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # Clock ramp: the first launches after an idle period run 10-15 % slow (profiles/r05_notes.md section 6), and the driver's command
+    # (--steps 20 --warmup 5) would end its warm-up inside that ramp.  So, IN ADDITION to --warmup and whatever its value: untimed steps until three
+    # consecutive ones agree within 1 % (at least PREWARM_MIN, at most PREWARM_MAX).  Reported as `prewarm_steps`; nothing of it is timed.
+    pre_adaptive = not (multi and use_dist and world > 1)  # a step with a collective in it must run the same number of times on every rank
+    pre_ev = [torch.cuda.Event(enable_timing=True) for _ in range(PREWARM_MAX + 1)]
+    pre_ms = []
+    pre_ev[0].record()
+    for i in range(PREWARM_MAX if pre_adaptive else PREWARM_MIN):
+        step()
+        pre_ev[i + 1].record()
+        if pre_adaptive and i + 1 >= PREWARM_MIN and (i + 1) % 4 == 0:  # look at the clock only every few steps: the check itself drains the queue
+            pre_ev[i + 1].synchronize()
+            pre_ms = [pre_ev[j].elapsed_time(pre_ev[j + 1]) for j in range(i + 1)]
+            last = pre_ms[-3:]
+            if max(last) <= 1.01 * min(last):
+                break
+    prewarm_steps = len(pre_ms) if pre_ms else (PREWARM_MAX if pre_adaptive else PREWARM_MIN)
+    if use_dist:  # every rank leaves the ramp before anybody's timed region starts (ranks may have stopped at different counts)
+        dist.barrier()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -796,6 +816,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "prewarm_steps": prewarm_steps,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": scaling,
@@ -927,7 +948,7 @@ def main():
         sp_m = svs.VamanaSearchParameters(svs.SearchBufferConfig(lo_w), args.visited)
         mstats = torch.zeros((nq, 6), dtype=torch.int32, device=device)
         index.search_device(q, k, sp_m, d_ids64=ids, d_dists=dists, d_stats=mstats)
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 12)):  # informational points warm up on their own: at least 12 launches whatever --warmup says
             index.search_device(q, k, sp_m, d_ids64=ids, d_dists=dists)
         torch.cuda.synchronize()
         mev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -956,7 +977,7 @@ def main():
             dists4 = torch.empty((nq4, k), dtype=torch.float32, device=device)
             st4 = torch.zeros((nq4, 6), dtype=torch.int32, device=device)
             index.search_device(q4, k, sp, d_ids64=ids4, d_dists=dists4, d_stats=st4)
-            for _ in range(args.warmup):
+            for _ in range(max(args.warmup, 12)):  # informational points warm up on their own: at least 12 launches whatever --warmup says
                 index.search_device(q4, k, sp, d_ids64=ids4, d_dists=dists4)
             torch.cuda.synchronize()
             e4 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, args.steps // 4))]
@@ -991,7 +1012,7 @@ def main():
                 dd3 = torch.empty((nq, k), dtype=torch.float32, device=device)
                 st3 = torch.zeros((nq, 6), dtype=torch.int32, device=device)
                 i3.search_device(q3, k, sp, d_ids64=ids3, d_dists=dd3, d_stats=st3)
-                for _ in range(args.warmup):
+                for _ in range(max(args.warmup, 12)):  # informational points warm up on their own: at least 12 launches whatever --warmup says
                     i3.search_device(q3, k, sp, d_ids64=ids3, d_dists=dd3)
                 torch.cuda.synchronize()
                 e3v = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -1042,7 +1063,7 @@ def main():
                 dd128 = torch.empty((nq, k), dtype=torch.float32, device=device)
                 st128 = torch.zeros((nq, 6), dtype=torch.int32, device=device)
                 i128.search_device(q, k, sp, d_ids64=ids128, d_dists=dd128, d_stats=st128)
-                for _ in range(args.warmup):
+                for _ in range(max(args.warmup, 12)):  # informational points warm up on their own: at least 12 launches whatever --warmup says
                     i128.search_device(q, k, sp, d_ids64=ids128, d_dists=dd128)
                 torch.cuda.synchronize()
                 ev128 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

@@ -69,7 +69,9 @@ typedef struct {
 
 /* Adopt arrays that already live in HBM in the device layout (no copy, not owned):
  *   data   n rows of data_row_stride_bytes (multiple of 16), element j of row i at i*stride + j*sizeof(T)
- *   graph  n rows of graph_row_stride_u32 ids (multiple of 16), unused slots = 0xFFFFFFFF, no degree slot
+ *   graph  n rows of graph_row_stride_u32 ids (multiple of 16), unused slots = 0xFFFFFFFF, no degree slot; the ids of a row are PACKED from
+ *          slot 0 (core/graph/graph.h:32-48: `[deg, n0 ... n_{deg-1}]` -- an SVS row has no holes): the kernels take the first empty slot of a
+ *          64-slot chunk as the end of the row, exactly as get_node's span(row + 1, deg) ends there
  * Used by the GPU graph builder, which rewrites the graph between search batches. */
 typedef struct {
     int metric;

@@ -373,10 +373,28 @@ class Ref:
         L.svsref_filter_contains.argtypes = [C.c_void_p, C.c_uint32]
         L.svsref_half_to_float_hw.restype = C.c_float
         L.svsref_half_to_float_hw.argtypes = [C.c_uint16]
+        L.svsref_scalar_loop.restype = C.c_float  # oracle/ref_scalar_loops.cpp: the reference's scalar loops under the reference's compile flags
+        L.svsref_scalar_loop.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.POINTER(C.c_int)]
 
     def norm(self, x):
         x = np.ascontiguousarray(x)
         return float(self.lib.svsref_norm(_ptr(x), dtype_code(x), x.size))
+
+    def scalar_loop_batch(self, metric, a, b, a_norms):
+        """generic_l2 / generic_ip / generic_cosine_similarity as the compiler builds them with the reference's flags (ref_scalar_loops.cpp);
+        a_norms: the query norms handed to the cosine loop (one per row of a)."""
+        a = np.ascontiguousarray(a)
+        b = np.ascontiguousarray(b)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        ok = C.c_int(0)
+        isz, jsz = a.shape[1] * a.itemsize, b.shape[1] * b.itemsize
+        for i in range(a.shape[0]):
+            for j in range(b.shape[0]):
+                out[i, j] = self.lib.svsref_scalar_loop(metric, a.ctypes.data + i * isz, dtype_code(a), b.ctypes.data + j * jsz, dtype_code(b), a.shape[1],
+                                                        float(a_norms[i]), C.byref(ok))
+                if not ok.value:
+                    raise ValueError("not one of the six scalar-loop pairs")
+        return out
 
     def distance_batch(self, metric, a, b):
         a = np.ascontiguousarray(a)

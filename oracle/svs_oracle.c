@@ -91,6 +91,25 @@ uint16_t svso_float_to_half(float f) {
     return (uint16_t)(sign | out);
 }
 
+/* Float16::operator float (lib/float16.h:45-52,103), the conversion every SCALAR piece of the reference uses -- norm() of a float16 query
+ * (distance_core.h:45-58: `accum += i * i` converts both operands) and the generic_* loops: a bit manipulation "without norm/denorm" that
+ * flushes float16 denormals to (signed) zero and gives the inf / NaN exponent finite values ((31 + 112) << 23 | mantissa << 13).  Pinned
+ * against the reference's own class by tests/test_oracle_vs_reference.py (scalar loops, query norms).  Round 6: the oracle used the exact
+ * conversion here before, which differs on exactly those inputs. */
+float svso_half_to_float_scalar(uint16_t x) {
+    const uint32_t e = ((uint32_t)x & 0x7C00u) >> 10;
+    const uint32_t m = ((uint32_t)x & 0x03FFu) << 13;
+    const uint32_t bits = (((uint32_t)x & 0x8000u) << 16) | (e != 0 ? (((e + 112u) << 23) | m) : 0u);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static inline float load_as_float_scalar(const void* p, int dtype, size_t i) {
+    if (dtype == SVSO_F16) return svso_half_to_float_scalar(((const uint16_t*)p)[i]);
+    return dtype == SVSO_F32 ? ((const float*)p)[i] : dtype == SVSO_I8 ? (float)((const int8_t*)p)[i] : (float)((const uint8_t*)p)[i];
+}
+
 static inline float load_as_float(const void* p, int dtype, size_t i) {
     switch (dtype) {
         case SVSO_F32: return ((const float*)p)[i];
@@ -114,7 +133,7 @@ float svso_norm(const void* x, int dtype, size_t d) {
             int v = ((const uint8_t*)x)[i];
             sq = (float)(v * v);
         } else {
-            float v = load_as_float(x, dtype, i);
+            float v = load_as_float_scalar(x, dtype, i);
             sq = v * v;
         }
         accum = accum + sq;
@@ -227,12 +246,16 @@ float svso_distance(int metric, const void* a, int adt, const void* b, int bdt, 
      * (euclidean.h:206-215), generic_ip (inner_product.h:167-176), generic_cosine_similarity (cosine.h:185-200): one float accumulator in
      * element order.  They are instantiated through L2Impl<..>::compute etc. (SVS_NOINLINE, euclidean.h:217-223) in the kernel translation unit,
      * which cmake/multi-arch.cmake builds with -march=cascadelake and GCC's default -ffp-contract=fast: `result += temp * temp` is ONE fma there.
-     * PARITY UNPINNED: these headers cannot be compiled here (euclidean.h -> lib/saveload.h -> toml++), so that reading is taken from the build
-     * files, not from a run; tests/test_contraction_choices.py holds inputs on which the other reading gives other bits. */
+     * These headers cannot be compiled here (euclidean.h -> lib/saveload.h -> toml++).  Round 6 pins the reading by a run all the same:
+     * oracle/ref_scalar_loops.cpp holds the three loop bodies, is compiled with that translation unit's flags (no -ffp-contract flag) over the
+     * reference's own Float16 class, and tests/test_oracle_vs_reference.py::test_scalar_loops_follow_the_compiler compares bit for bit --
+     * which is how the float16 conversion of these loops (scalar, denormals flushed: load_as_float_scalar) was found to differ from the SIMD
+     * kernels'.  What stays a restatement is the loop text itself.  tests/test_contraction_choices.py holds inputs on which the other
+     * reading of the contraction gives other bits. */
     {
         float result = 0.0f, accum = 0.0f;
         for (size_t i = 0; i < d; ++i) {
-            const float ai = load_as_float(a, adt, i), bi = load_as_float(b, bdt, i);
+            const float ai = load_as_float_scalar(a, adt, i), bi = load_as_float_scalar(b, bdt, i);
             if (metric == SVSO_L2) {
                 const float temp = ai - bi;
                 result = fmaf(temp, temp, result);
@@ -497,11 +520,13 @@ static int fix_query(const svso_index* ix, const void* query, int q_dtype, fixed
         if (ix->metric == SVSO_COS) fq->norm = svso_norm(query, q_dtype, ix->d); /* cosine.h:117-119 */
         return 0;
     }
-    /* SQ distances take float queries (scalar.h:58-195); f16 queries are widened by set_datum. */
+    /* SQ distances take float queries (scalar.h:58-195); f16 queries are widened element by element -- detail::compress<T>(v, ..) on a Float16
+     * value (scalar.h:75-82) and set_datum -> relaxed_narrow<float>(Float16) (scalar.h:123-125, core/data/simple.h:396-404) -- i.e. through
+     * Float16::operator float, the scalar conversion */
     if (q_dtype != SVSO_F32 && q_dtype != SVSO_F16) return -1;
     float* qf = (float*)malloc(ix->d * sizeof(float));
     if (!qf) return -2;
-    for (size_t i = 0; i < ix->d; ++i) qf[i] = load_as_float(query, q_dtype, i);
+    for (size_t i = 0; i < ix->d; ++i) qf[i] = load_as_float_scalar(query, q_dtype, i);
     if (ix->metric == SVSO_L2) { /* EuclideanCompressed::fix_argument :75-82 */
         void* qc = malloc(ix->d);
         if (!qc) { free(qf); return -2; }

@@ -33,6 +33,7 @@ size_t svso_dtype_size(int dtype);
 
 /* lib/float16.h -- hardware-exact half->float (vcvtph2ps semantics, denormals preserved). */
 float svso_half_to_float(uint16_t h);
+float svso_half_to_float_scalar(uint16_t h); /* Float16::operator float (lib/float16.h:45-52): denormals flushed, inf / NaN finite */
 /* round-to-nearest-even float->half (used by data generators only). */
 uint16_t svso_float_to_half(float f);
 

@@ -1295,6 +1295,20 @@ int svsx_flat_search_device_counted(
     // rows of the float16 shadow: padded to 16 elements, between 129 and 768 dimensions to 128 (the threshold kernel for those takes the
     // dimension in chunks of 128)
     const uint32_t dpad = static_cast<uint32_t>(ix->d > 128 && ix->d <= 768 ? (ix->d + 127) & ~size_t(127) : (ix->d + 15) & ~size_t(15));
+    // shortlist length: max(4k, k + 32) up to 128 entries; beyond k = 96 (the reference's own ground-truth files hold 100 neighbours per
+    // query, data/test_dataset/groundtruth_*.ivecs) k + 32, the general insert path of the shortlist kernel, up to 256 entries
+    size_t kk = 4 * k > k + 32 ? 4 * k : k + 32;
+    if (kk > 128) kk = k + 32 > 128 ? k + 32 : 128;
+    if (kk > ix->n) kk = ix->n < k ? k : ix->n;
+    {   // the shortlist kernel keeps 64 shortlists (and, beyond d = 128, the 64 queries) of a wave in LDS; where that does not fit the
+        // shortlist shrinks towards k + 8 -- the answer stays exact, a shorter shortlist only makes the proof of stage 4 fail more often
+        const size_t fixed = (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0) + 256;
+        while (fixed + 64 * kk * 8 > 160 * 1024 && kk > k + 8) kk -= 4;
+        if (kk < k) kk = k;
+        const size_t need = fixed + 64 * kk * 8;
+        // (decided BEFORE the float16 shadow is built: the exhaustive pass never reads it, and at 1 M x 1 536 it would be 3 GB of HBM kept for the index's life -- ADVICE r5)
+        if (need > 160 * 1024) return exhaustive_only(); // the 64 float16 queries of a wave + its shortlists do not fit (d >= ~1 200, or a long list at a large d)
+    }
     {   // float16 shadow of the database + squared norms, built once
         std::lock_guard<std::mutex> lock(ix->shadow_mutex);
         if (!ix->d_half) {
@@ -1321,19 +1335,6 @@ int svsx_flat_search_device_counted(
             ix->d_half = h;
             ix->d_norm2 = nrm;
         }
-    }
-    // shortlist length: max(4k, k + 32) up to 128 entries; beyond k = 96 (the reference's own ground-truth files hold 100 neighbours per
-    // query, data/test_dataset/groundtruth_*.ivecs) k + 32, the general insert path of the shortlist kernel, up to 256 entries
-    size_t kk = 4 * k > k + 32 ? 4 * k : k + 32;
-    if (kk > 128) kk = k + 32 > 128 ? k + 32 : 128;
-    if (kk > ix->n) kk = ix->n < k ? k : ix->n;
-    {   // the shortlist kernel keeps 64 shortlists (and, beyond d = 128, the 64 queries) of a wave in LDS; where that does not fit the
-        // shortlist shrinks towards k + 8 -- the answer stays exact, a shorter shortlist only makes the proof of stage 4 fail more often
-        const size_t fixed = (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0) + 256;
-        while (fixed + 64 * kk * 8 > 160 * 1024 && kk > k + 8) kk -= 4;
-        if (kk < k) kk = k;
-        const size_t need = fixed + 64 * kk * 8;
-        if (need > 160 * 1024) return exhaustive_only(); // the 64 float16 queries of a wave + its shortlists do not fit (d >= ~1 200, or a long list at a large d)
     }
     const size_t nqb = (nq + 63) / 64;
     // one round of resident waves: LDS (64 shortlists of kk entries) bounds the waves per CU; a second round would

@@ -209,14 +209,16 @@ template <int DT> __global__ __launch_bounds__(64) void pca_encode_kernel(const 
     }
 }
 
-// pass 3a (indexes of at most 2^26 nodes): ceil(degree / 8) of every node -- the number of 8-slot groups of its block that hold a neighbour
+// pass 3a (indexes of at most 2^26 nodes): ceil(used slots / 8) of every node -- the number of leading 8-slot groups of its block that hold a neighbour
 __global__ __launch_bounds__(256) void degree_class_kernel(const uint32_t* __restrict__ graph, uint32_t gstride, uint32_t n, uint8_t* __restrict__ cls) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const uint32_t* row = graph + static_cast<size_t>(v) * gstride;
-    uint32_t deg = 0;
-    for (uint32_t j = 0; j < gstride; ++j) deg += row[j] != kInvalidId ? 1u : 0u; // rows are packed from slot 0; counting all slots does not rely on it
-    cls[v] = static_cast<uint8_t>((deg + 7u) >> 3);
+    // the class bounds the SLOTS the search kernel reads (slot_limit = class * 8), so it follows the last slot that holds a neighbour, not the
+    // number of neighbours: a caller-supplied row (svsx_index_create_device_view) with a hole in it loses nothing behind the hole
+    uint32_t used = 0;
+    for (uint32_t j = 0; j < gstride; ++j) used = row[j] != kInvalidId ? j + 1u : used;
+    cls[v] = static_cast<uint8_t>((used + 7u) >> 3);
 }
 
 // pass 3: node v -> per chunk of <= 64 slots [ids | plane 0 | ... | plane RW-1]; plane p = bytes [16p, 16p + 16) of each

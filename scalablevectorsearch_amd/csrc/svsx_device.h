@@ -805,6 +805,14 @@ struct QueryFix {
 
 // Load query `qptr` into the wave's LDS slice and run fix_argument (greedy_search.h:140):
 //   float paths: widened exactly to f32 (zero padded to 16) in qf;  int paths: bytes (zero padded) in qw.
+// Float16::operator float (lib/float16.h:45-52,103): the reference's SCALAR float16 -> float32 conversion, "without norm/denorm": denormals
+// become (signed) zero and the inf / NaN exponent yields finite values.  Its SIMD kernels convert exactly (vcvtph2ps) -- see prepare_query.
+__device__ __forceinline__ float half_to_float_scalar(uint16_t x) {
+    const uint32_t e = (static_cast<uint32_t>(x) & 0x7C00u) >> 10;
+    const uint32_t m = (static_cast<uint32_t>(x) & 0x03FFu) << 13;
+    return __uint_as_float(((static_cast<uint32_t>(x) & 0x8000u) << 16) | (e != 0u ? (((e + 112u) << 23) | m) : 0u));
+}
+
 template <int DT, int METRIC, int QMODE>
 __device__ __forceinline__ QueryFix prepare_query(
     const unsigned char* __restrict__ qptr, int q_dtype, int d, int dpad, float* qf, uint32_t* qw, float sq_scale,
@@ -815,10 +823,18 @@ __device__ __forceinline__ QueryFix prepare_query(
     fx.norm = 0.0f;
     fx.offset = 0.0f;
     fx.qq = 0;
-    auto query_elem = [&](int i) -> float { // exact widening of query element i
+    // A float16 query element is widened in one of two ways by the reference.  Its SIMD kernels (QM_FLOAT) load it with vcvtph2ps: exact.
+    // Everything SCALAR goes through Float16::operator float (lib/float16.h:45-52; half_to_float_scalar above): norm() of the query
+    // (distance_core.h:45-58), the generic_* loops (QM_SCALAR), and the scalar-quantized distances, whose fix_argument compresses / copies the
+    // query element by element (scalar.h:75-82,123-125 -> detail::compress / set_datum -> relaxed_narrow).  Pinned against the reference's
+    // own class.
+    constexpr bool SCALAR_WIDEN = QMODE == QM_SCALAR || QMODE == QM_SQ_L2 || QMODE == QM_SQ_IP || QMODE == QM_SQ_COS;
+    auto query_elem = [&](int i) -> float { // widening of query element i
         switch (q_dtype) {
             case DT_F32: return reinterpret_cast<const float*>(qptr)[i];
-            case DT_F16: return static_cast<float>(reinterpret_cast<const _Float16*>(qptr)[i]);
+            case DT_F16:
+                if constexpr (SCALAR_WIDEN) return half_to_float_scalar(reinterpret_cast<const uint16_t*>(qptr)[i]);
+                else return static_cast<float>(reinterpret_cast<const _Float16*>(qptr)[i]);
             case DT_I8: return static_cast<float>(static_cast<int>(reinterpret_cast<const int8_t*>(qptr)[i]));
             default: return static_cast<float>(static_cast<unsigned>(qptr[i]));
         }
@@ -829,10 +845,18 @@ __device__ __forceinline__ QueryFix prepare_query(
         if constexpr (METRIC == M_COS) {
             // norm() (distance_core.h:45-66): accum += x*x sequentially in f32, multiply and add rounded separately
             float accum = 0.0f;
-            for (int i = 0; i < d; ++i) {
-                const float v = qf[i];
-                const float p = v * v;
-                accum = accum + p;
+            if (!SCALAR_WIDEN && q_dtype == DT_F16) { // the norm of a float16 query takes the scalar conversion even where the kernel's loads do not
+                for (int i = 0; i < d; ++i) {
+                    const float v = half_to_float_scalar(reinterpret_cast<const uint16_t*>(qptr)[i]);
+                    const float p = v * v;
+                    accum = accum + p;
+                }
+            } else {
+                for (int i = 0; i < d; ++i) {
+                    const float v = qf[i];
+                    const float p = v * v;
+                    accum = accum + p;
+                }
             }
             fx.norm = sqrtf(accum);
         }
@@ -883,8 +907,8 @@ __device__ __forceinline__ QueryFix prepare_query(
 
 // The reference's scalar fallback loops (QM_SCALAR): ONE lane owns one row -- a single float accumulator that takes the elements in order
 // cannot be split across lanes -- so a pass evaluates 64 rows.  `result += temp * temp` is one fma: the loops are instantiated in the kernel
-// translation unit, built -march=cascadelake with GCC's default -ffp-contract=fast (DESIGN.md section 2 has the argument; PARITY UNPINNED --
-// the reference header cannot be compiled here).  Rows and the LDS query are zero padded to 16 elements; the padding adds fma(0, 0, x) = x.
+// translation unit, built -march=cascadelake with GCC's default -ffp-contract=fast (DESIGN.md section 2 has the argument; round 6: pinned by a
+// run of the loop bodies compiled with that unit's flags over the reference's own Float16 class).  Rows and the LDS query are zero padded to 16 elements; the padding adds fma(0, 0, x) = x.
 template <int DT, int METRIC>
 __device__ __forceinline__ void scalar_row_distance(const unsigned char* __restrict__ row, const float* __restrict__ qf, int d, float& out_main, float& out_nrm) {
     float result = 0.0f, accum = 0.0f;
@@ -894,7 +918,19 @@ __device__ __forceinline__ void scalar_row_distance(const unsigned char* __restr
         BlockRaw<DT> raw;
 #pragma unroll
         for (int i = 0; i < (16 * Elem<DT>::BYTES) / 16; ++i) raw.v[i] = *reinterpret_cast<const uint4*>(row + 16 * Elem<DT>::BYTES * b + 16 * i); // inactive lanes read row 0
-        block_to_float<DT>(raw, x);
+        if constexpr (DT == DT_F16) { // static_cast<float>(b[i]) of the scalar loops = Float16::operator float, not the exact conversion
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t w[4] = {raw.v[i].x, raw.v[i].y, raw.v[i].z, raw.v[i].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    x[8 * i + 2 * t] = half_to_float_scalar(static_cast<uint16_t>(w[t] & 0xFFFFu));
+                    x[8 * i + 2 * t + 1] = half_to_float_scalar(static_cast<uint16_t>(w[t] >> 16));
+                }
+            }
+        } else {
+            block_to_float<DT>(raw, x);
+        }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 qv = *reinterpret_cast<const float4*>(qf + 16 * b + 4 * g4); // the same address in every lane: LDS broadcast

@@ -1005,7 +1005,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
         if (a.capacity > 512u && a.capacity <= 1024u) return launch_one<DT, METRIC, QMODE, DB, GENERAL, CODES, 2>(a, stream);
     }
     snprintf(last_search_instantiation_buffer(), 96, "search_kernel<dt=%d,metric=%d,qmode=%d,ds=%d,general=%d,codes=%d>%s", DT, METRIC, QMODE, DS, GENERAL ? 1 : 0, CODES,
-             QMODE == QM_SCALAR ? " scalar loop (parity unpinned)" : "");
+             QMODE == QM_SCALAR ? " scalar loop" : "");
     const int d = static_cast<int>(a.d);
     const int dpad = (d + 15) & ~15;
     const bool intpath = (QMODE == QM_INT || QMODE == QM_SQ_L2);

@@ -117,6 +117,7 @@ class VamanaIndex:
         self._keep = None
         _lib.check(_lib.lib().svsx_index_create(C.byref(desc), C.byref(self._h)))
         self.device = device
+        self.id_offset = int(id_offset)
         self.n, self.d = data.shape
         self.data_dtype = data.dtype
         self.entry_points = entry.copy()
@@ -139,6 +140,7 @@ class VamanaIndex:
         self._keep = (d_graph, d_data, d_entry_points)
         _lib.check(_lib.lib().svsx_index_create_device_view(C.byref(desc), C.byref(self._h)))
         self.device = device
+        self.id_offset = int(id_offset)
         self.n, self.d = n, d
         self.data_dtype = np.dtype(data_dtype)
         self.entry_points = None
@@ -346,6 +348,7 @@ class FlatIndex:
         self._h = C.c_void_p()
         _lib.check(_lib.lib().svsx_index_create(C.byref(desc), C.byref(self._h)))
         self.device = device
+        self.id_offset = int(id_offset)
         self.n, self.d = data.shape
 
     __del__ = VamanaIndex.__del__

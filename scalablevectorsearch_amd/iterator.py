@@ -204,6 +204,7 @@ def filtered_search(index, queries, k: int, is_member, search_parameters: Vamana
     sp = search_parameters or index.get_search_parameters()
     sws = sp.buffer_config.get_search_window_size()
     max_batch = index.size()
+    id_offset = int(getattr(index, "id_offset", 0))  # `is_member` is indexed by LOCAL id (label - id_offset), as svsx_search_filtered's bitmap is
     it = (make_iterator or BatchIterator)(index, queries, extra_search_buffer_capacity)
     ids = np.full((nq, k), np.iinfo(np.uint64).max, np.uint64)
     dists = np.full((nq, k), np.inf, np.float32)
@@ -228,7 +229,7 @@ def filtered_search(index, queries, k: int, is_member, search_parameters: Vamana
             c = int(counts[i])
             checked[i] += c
             for j in range(c):
-                if member[int(b_ids[i, j])]:
+                if member[int(b_ids[i, j]) - id_offset]:
                     ids[i, found[i]] = b_ids[i, j]
                     dists[i, found[i]] = b_dists[i, j]
                     found[i] += 1
@@ -253,6 +254,10 @@ def range_search(index, queries, radius: float, search_parameters: VamanaSearchP
     queries = np.ascontiguousarray(np.atleast_2d(queries))
     nq = queries.shape[0]
     sp = search_parameters or index.get_search_parameters()
+    if hasattr(index, "d") and queries.shape[1] != index.d:  # detail::checkdims (index/vamana/iterator.h): the C entry point only sees a pointer
+        raise _lib.SvsxError(_lib.INVALID_ARGUMENT, f"Incompatible dimensions. Query has {queries.shape[1]} while the index expects {index.d}.")
+    # `is_member` is indexed by LOCAL id (label - index.id_offset, position in the index's own arrays) on both paths below
+    id_offset = int(getattr(index, "id_offset", 0))
     if make_iterator is None and extra_search_buffer_capacity is None and hasattr(index, "_h"):
         # the library's own loop (svsx_range_search, include/svsx.h); the Python loop below is its mirror and runs over any iterator class
         import ctypes as C
@@ -277,6 +282,8 @@ def range_search(index, queries, radius: float, search_parameters: VamanaSearchP
         spc = sp._c()
         _lib.check(_lib.lib().svsx_range_search(index._h, queries.ctypes.data, dtype_code(queries), nq, float(radius), C.byref(spc),
                                                None if bitmap is None else bitmap.ctypes.data, _lib.RESULTS_ALLOCATOR(allocate), None))
+        if "lims" not in out:  # nq == 0: the library returns SUCCESS without calling the allocator, as the reference does
+            return np.zeros(nq + 1, np.int64), np.empty(0, np.uint64), np.empty(0, np.float32)
         return out["lims"], out["labels"], out["distances"]
     batch = max(sp.buffer_config.get_search_window_size(), 10)
     greater = int(index.distance.metric) != 0
@@ -295,7 +302,7 @@ def range_search(index, queries, radius: float, search_parameters: VamanaSearchP
                 in_range = bool(dd > radius) if greater else bool(dd < radius)
                 if not in_range:
                     break
-                if member is None or member[int(b_ids[i, j])]:
+                if member is None or member[int(b_ids[i, j]) - id_offset]:
                     res[i].append((int(b_ids[i, j]), dd))
             if not in_range or done[i]:
                 active[i] = False

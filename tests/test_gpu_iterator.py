@@ -233,6 +233,17 @@ def test_range_and_filtered_search_on_gpu(svs, oracle, small_world):
             assert a[0][-1] > 0
     with pytest.raises(svs.SvsxError):
         svs.range_search(idx, q, 0.0)
+    with pytest.raises(svs.SvsxError, match="Incompatible dimensions"):  # detail::checkdims before the library sees the pointer
+        svs.range_search(idx, q[:, :-3], 1.0)
+    e = svs.range_search(idx, q[:0], 1.0)  # no queries: the library never calls the allocator (as the reference)
+    assert e[0].tolist() == [0] and e[1].size == 0 and e[2].size == 0
+    # an index whose labels start at id_offset: the filter is indexed by local id on the library path and on its Python mirror alike
+    idx_off = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"], id_offset=1000)
+    idx_off.set_search_parameters(svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
+    a = svs.range_search(idx_off, q, 1.1, is_member=member)
+    a2 = svs.range_search(idx_off, q, 1.1, is_member=member, make_iterator=svs.BatchIterator)
+    b = svs.range_search(fake, q, 1.1, is_member=member, make_iterator=_OracleBatchIterator)
+    assert (a[0] == b[0]).all() and (a[1] == b[1] + 1000).all() and (a2[1] == a[1]).all() and (_bits(a2[2]) == _bits(a[2])).all()
     # VamanaIndex::get_distance (index.h:915-933): the value a search reports for that row, bit for bit
     res = idx.search(q, 5, svs.VamanaSearchParameters(svs.SearchBufferConfig(20)))
     for i in range(4):

@@ -49,7 +49,7 @@ def test_distance_bits_match_oracle(svs, oracle, d):
 
 # the (query, data) pairs utils/search_index.cpp:147-162 offers that have NO AVX-512 specialisation: the reference answers them with its scalar
 # loops (generic_l2 / generic_ip / generic_cosine_similarity); round 5 builds them (QM_SCALAR) against the oracle's restatement of those loops
-# (one fma per element: oracle/svs_oracle.c has the argument; parity unpinned -- the reference header does not compile here)
+# (one fma per element, float16 elements through the reference's scalar conversion: pinned by a run against oracle/ref_scalar_loops.cpp, tests/test_oracle_vs_reference.py)
 SCALAR_PAIRS = [(I8, U8), (I8, F32), (I8, F16), (U8, I8), (U8, F32), (U8, F16)]
 
 
@@ -65,6 +65,48 @@ def test_scalar_loop_pairs_distance_bits_match_oracle(svs, oracle, d):
             bad = got.view(np.uint32) != want.view(np.uint32)
             bad &= ~(np.isnan(got) & np.isnan(want))
             assert not bad.any(), (d, qa, qb, m, got[bad][:4], want[bad][:4])
+
+
+def _spice_f16(a):
+    """float16 array with denormals, the largest finite value, an infinity and a NaN pattern written into its first rows"""
+    b = a.view(np.uint16).copy()
+    d = b.shape[1]
+    b[0, 0] = 0x0001
+    b[0, d - 1] = 0x83FF
+    if b.shape[0] > 3 and d > 2:
+        b[1, 0] = 0x7BFF
+        b[2, 1] = 0x7C00
+        b[3, 2] = 0xFE01
+    return b.view(np.float16)
+
+
+@pytest.mark.parametrize("d", [16, 96, 100])
+def test_float16_scalar_conversion_cases(svs, oracle, small_world, d):
+    """Where the reference widens float16 through Float16::operator float (lib/float16.h:45-52: denormals flushed, inf / NaN patterns finite)
+    and where through vcvtph2ps (exact): scalar-loop pairs with float16 rows, the cosine norm of a float16 query, float16 queries of a
+    scalar-quantized index.  The oracle is pinned on exactly these inputs against the reference's own class (tests/test_oracle_vs_reference.py)."""
+    rng = np.random.default_rng(4200 + d)
+    x16 = _spice_f16((rng.standard_normal((70, d)) * 1e-3).astype(np.float16))
+    q16 = _spice_f16((rng.standard_normal((6, d)) * 1e-3).astype(np.float16))
+    fns = ((L2, svs.DistanceL2()), (IP, svs.DistanceIP()), (COS, svs.DistanceCosineSimilarity()))
+    for qa in (I8, U8):  # generic_* loops over float16 rows
+        a = _gen(rng, qa, 5, d)
+        for m, f in fns:
+            got, want = svs.compute(f, a, x16), oracle.distance_batch(m, a, x16)
+            assert (((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))).all(), (d, qa, m)
+    for xb in (x16, x16.astype(np.float32)):  # SIMD kernels, float16 queries: exact loads, scalar norm
+        for m, f in fns:
+            got, want = svs.compute(f, q16, xb), oracle.distance_batch(m, q16, xb)
+            assert (((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))).all(), (d, m)
+    if d == 96:  # scalar-quantized index searched with float16 queries (fix_argument widens them element by element)
+        sw = small_world
+        q = _spice_f16((sw["q"][:16] * 1e-3).astype(np.float16))
+        for code in (I8, U8):
+            codes, scale, bias = oracle.sq_compress(sw["x"], code)
+            for m, f in fns:
+                res, st, ids, dists, ost = _search_both(svs, oracle, m, f, codes, sw["graph"], sw["entry"], q, 10, 24, 24, sq=(scale, bias))
+                assert (res.indices == ids.astype(np.uint64)).all(), (code, m)
+                assert (((res.distances.view(np.uint32) == dists.view(np.uint32)) | (np.isnan(res.distances) & np.isnan(dists)))).all(), (code, m)
 
 
 @pytest.mark.parametrize("metric", [L2, IP, COS])
@@ -93,7 +135,7 @@ def test_search_scalar_loop_pairs(svs, oracle, small_world, metric, qdt, ddt):
         assert (res.indices == ids.astype(np.uint64)).all(), (metric, qdt, ddt, w)
         assert (res.distances.view(np.uint32) == dists.view(np.uint32)).all()
         assert (st[:, :2] == ost[:, :2]).all()
-        assert "qmode=5" in idx.last_kernel_info() and "parity unpinned" in idx.last_kernel_info()
+        assert "qmode=5" in idx.last_kernel_info() and "scalar loop" in idx.last_kernel_info()
     res = idx.search(q[:4], 3, svs.VamanaSearchParameters(svs.SearchBufferConfig(16)))
     for i in range(4):
         for j in range(3):

@@ -204,6 +204,15 @@ def test_range_and_filtered_search_host_logic(oracle, small_world):
     assert lims[-1] > 0
     with pytest.raises(svs.SvsxError):
         svs.range_search(ix, q, 0.0, make_iterator=_OracleBatchIterator)
+    # detail::checkdims: a query array of the wrong width is refused before anything reads it (the library path only gets a pointer)
+    ix.d = w["x"].shape[1]
+    with pytest.raises(svs.SvsxError, match="Incompatible dimensions"):
+        svs.range_search(ix, q[:, :-1], radius, make_iterator=_OracleBatchIterator)
+    # the filter is indexed by LOCAL id (label - id_offset) on the mirror path too
+    ix.id_offset = 0
+    mem = (np.arange(w["x"].shape[0]) % 2) == 0
+    l2, lab2, _ = svs.range_search(ix, q, radius, is_member=mem, make_iterator=_OracleBatchIterator)
+    assert (lab2 % 2 == 0).all() and 0 < l2[-1] < lims[-1]
     # filtered search: k members of the filter, best first, == the first k members in iterator order
     member = (np.arange(w["x"].shape[0]) % 3) == 0
     res = svs.filtered_search(ix, q, 10, member, make_iterator=_OracleBatchIterator)

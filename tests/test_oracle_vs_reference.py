@@ -237,3 +237,70 @@ def test_golden_flat_search(oracle):
         for i in range(len(od)):
             for ids in (oi[i].astype(np.int64), g[f"ids_tied_{k}"][i].astype(np.int64)):
                 assert len(set(ids.tolist())) == k and (full[i][ids].view(np.uint32) == od[i].view(np.uint32)).all()
+
+
+SCALAR_PAIRS = [(I8, U8), (I8, F32), (I8, F16), (U8, I8), (U8, F32), (U8, F16)]
+
+
+def _cast(v, dt, rng):
+    if dt == F32:
+        return v.astype(np.float32)
+    if dt == F16:
+        return v.astype(np.float16)
+    if dt == I8:
+        return rng.integers(-128, 128, v.shape).astype(np.int8)
+    return rng.integers(0, 256, v.shape).astype(np.uint8)
+
+
+@pytest.mark.parametrize("d", [1, 7, 96, 100, 223])
+def test_scalar_loops_follow_the_compiler(oracle, ref, d):
+    """The six pairs the reference answers with generic_l2 / generic_ip / generic_cosine_similarity: the C restatement hard-codes
+    one fmaf per element; oracle/ref_scalar_loops.cpp holds the three loop bodies and is compiled with the flags of the reference's kernel
+    translation unit (cmake/multi-arch.cmake:17-35: -O3 -march=cascadelake, the compiler's own -ffp-contract default) -- so whether GCC
+    contracts them is observed here, not assumed.  float16 elements go through the reference's own Float16 class (compiled from
+    lib/float16.h): its scalar conversion flushes denormals and gives inf / NaN finite values, unlike the SIMD kernels' vcvtph2ps."""
+    rng = np.random.default_rng(1000 + d)
+    for qa, qb in SCALAR_PAIRS:
+        a = _cast(rng.standard_normal((6, d)) * 3.0, qa, rng)
+        b = _cast(rng.standard_normal((9, d)) * 3.0, qb, rng)
+        if qb == F16:  # float16 rows with denormals, the largest finite value, an infinity and a NaN pattern in them
+            bb = b.view(np.uint16).copy()
+            bb[0, 0] = 0x0001
+            bb[1, d - 1] = 0x83FF
+            if d > 1:
+                bb[2, 0] = 0x7BFF
+                bb[3, 1] = 0x7C00
+                bb[4, 0] = 0xFE01
+            b = bb.view(np.float16)
+        norms = np.array([oracle.norm(a[i]) for i in range(a.shape[0])], np.float32)
+        for m in (L2, IP, COS):
+            got = oracle.distance_batch(m, a, b)
+            want = ref.scalar_loop_batch(m, a, b, norms)
+            assert _bits_equal(got, want), (d, qa, qb, m, got.ravel()[:4], want.ravel()[:4])
+
+
+def test_float16_query_norm_uses_the_scalar_conversion(oracle, ref):
+    """norm() of a float16 query (distance_core.h:45-58, called by DistanceCosineSimilarity::fix_argument, cosine.h:117-119) converts every
+    element through Float16::operator float -- denormals flushed, inf / NaN patterns finite -- while the SIMD kernels load the same elements
+    exactly (vcvtph2ps).  Both sides of that are pinned here: the norm against the reference's class, the cosine of a float16 query with
+    denormal, inf and NaN-pattern elements against the reference's kernels."""
+    rng = np.random.default_rng(77)
+    for d in (16, 96, 100):
+        q = (rng.standard_normal((5, d)) * 1e-4).astype(np.float16).view(np.uint16).copy()
+        q[0, :4] = (0x0001, 0x03FF, 0x8200, 0x0000)  # denormals
+        q[1, 0] = 0x7BFF
+        q[2, 1] = 0x7C00  # +inf: 65536 to the scalar conversion
+        q[3, 2] = 0xFC01  # a NaN pattern: a finite value to the scalar conversion
+        q = q.view(np.float16)
+        for i in range(q.shape[0]):
+            assert np.float32(oracle.norm(q[i])).view(np.uint32) == np.float32(ref.norm(q[i])).view(np.uint32), (d, i)
+        x = rng.standard_normal((7, d)).astype(np.float32)
+        for xb in (x, x.astype(np.float16)):
+            assert _bits_equal(oracle.distance_batch(COS, q, xb), ref.distance_batch(COS, q, xb)), d
+    # the conversion itself, all 65 536 patterns, against the reference's class (through the one-element L2 loop: (0 - x)^2 = x * x exactly
+    # representable or not, the comparison is of bits)
+    allh = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16).reshape(-1, 1)
+    zero = np.zeros((1, 1), np.int8)
+    got = oracle.distance_batch(IP, np.ones((1, 1), np.int8), allh)  # 1 * float(x) + 0 = float(x)
+    want = ref.scalar_loop_batch(IP, np.ones((1, 1), np.int8), allh, [0.0])
+    assert _bits_equal(got, want) and zero.size == 1
