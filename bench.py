@@ -499,7 +499,7 @@ def config4_point(args, svs, device, local_rank, k, t_run0):
     try:  # the same searches on the host by the CPU oracle for a query sample: ids identical?
         from oracle.oracle import COS, Oracle
 
-        ns = 8
+        ns = 256  # (round 5: 8 queries, ids only)
         host_need = 4 * (n4 * d4 + n4 * (R4 + 1) * 4)  # host copies of codes and graph, plus the temporaries of the layout conversion
         try:
             lim = open("/sys/fs/cgroup/memory.max").read().strip()
@@ -514,13 +514,97 @@ def config4_point(args, svs, device, local_rank, k, t_run0):
         o = Oracle()
         xh = x4.cpu().numpy()
         gh = device_graph_to_svs(g4, R4)
-        oi, _ = o.search(COS, xh, gh, np.array([e4], np.uint32), q4[:ns].cpu().numpy(), k, lo_w, sq=sq)
-        point["oracle_sample"] = {"queries": ns, "ids_identical": bool((oi.astype(np.int64) == ids4[:ns].cpu().numpy()).all())}
+        oi, od = o.search(COS, xh, gh, np.array([e4], np.uint32), q4[:ns].cpu().numpy(), k, lo_w, sq=sq)
+        point["oracle_sample"] = {"queries": ns, "window": lo_w, "ids_identical": bool((oi.astype(np.int64) == ids4[:ns].cpu().numpy()).all()),
+                                  "distance_bits_identical": bool((od.view(np.uint32) == dd4[:ns].cpu().numpy().view(np.uint32)).all())}
         del xh, gh
     except Exception as e:  # noqa: BLE001
         point["oracle_sample"] = {"error": f"{type(e).__name__}: {e}"}
-    del x4, g4, i4, gt4, ids4, dd4, st4
+    del i4, gt4
+    torch.cuda.empty_cache()
+    try:  # the SAME rows taken as raw int8 vectors, int8 queries, cosine (K6: cosine.h:261-326) -- the exact integer path
+        left = args.budget_s - (time.time() - t_run0)
+        if left < 150:
+            raise TimeoutError(f"{left:.0f} s of the run's budget left")
+        point["raw_int8"] = config4b_point(args, svs, device, local_rank, k, x4, g4, e4, q4, sq, n4)
+    except Exception as e:  # noqa: BLE001  (informational: never fail the line over it)
+        point["raw_int8"] = {"error": f"{type(e).__name__}: {e}"}
+    del x4, g4, ids4, dd4, st4
     return point
+
+
+def config4b_point(args, svs, device, local_rank, k, x4, g4, e4, q4f, sq, n4):
+    """raw int8 rows x int8 queries, cosine, batch 4 096 -- `CosineSimilarity` over the VNNI loops (cosine.h:261-326):
+    float(sum ab) / (||a|| sqrt(float(sum bb))), exact int32 sums.  Rows = config 4's codes read as plain int8 vectors, queries = the float
+    queries quantized with the same scale / bias; the graph is config 4's (built under the scalar-quantized cosine of the same codes: the two
+    metrics differ by the bias term only, |bias| / scale is reported).  Inline records over float(row element), round 6."""
+    import torch
+
+    d4, nq4, R4 = 768, q4f.shape[0], 128
+    scale, bias = sq
+    fn = svs.DistanceCosineSimilarity()
+    q8 = torch.clamp(torch.round((q4f - bias) / scale), -128, 127).to(torch.int8)
+    ib = svs.VamanaIndex.from_device(g4, x4, fn, torch.tensor([e4], dtype=torch.int32, device=device), n4, d4, np.int8, device=local_rank)
+    gtb, _ = ib.flat_search_device(q8, k)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ib.build_bound_codes(2)
+    torch.cuda.synchronize()
+    t_rec = time.time() - t0
+    mem = ib.memory()
+    ids = torch.empty((nq4, k), dtype=torch.int64, device=device)
+    dd = torch.empty((nq4, k), dtype=torch.float32, device=device)
+    st = torch.zeros((nq4, 6), dtype=torch.int32, device=device)
+    lo_w, hi_w = 32, 1024
+    while lo_w < hi_w:  # calibrate.h:286-300
+        mid = (lo_w + hi_w) // 2
+        ib.search_device(q8, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(mid), 1), d_ids64=ids, d_dists=dd)
+        torch.cuda.synchronize()
+        if recall_at(gtb, ids, k) >= 0.9:
+            hi_w = mid
+        else:
+            lo_w = mid + 1
+    spb = svs.VamanaSearchParameters(svs.SearchBufferConfig(lo_w), 1)
+    ib.search_device(q8, k, spb, d_ids64=ids, d_dists=dd, d_stats=st)
+    for _ in range(max(args.warmup, 12)):
+        ib.search_device(q8, k, spb, d_ids64=ids, d_dists=dd)
+    torch.cuda.synchronize()
+    evb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, args.steps // 2))]
+    for a_, b_ in evb:
+        a_.record()
+        ib.search_device(q8, k, spb, d_ids64=ids, d_dists=dd)
+        b_.record()
+    torch.cuda.synchronize()
+    msb = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evb]))
+    kb = ib.last_kernel_info()
+    rbb = int(mem["record_size"]) or 32
+    lb = designed_lines(st.to(torch.int64), 128, d4, 2, d4, k, rbb)
+    wkey = f"c4b:n={n4}:nq={nq4}:window={lo_w}:R=128:visited=1:codes=2"
+    tb, tb_src, _ = measured_traffic(wkey)
+    # the same launch on the plain kernel (no records: every neighbour's 768-byte row is read, the reference's own traffic)
+    ib.build_bound_codes(0)
+    for _ in range(3):
+        ib.search_device(q8, k, spb, d_ids64=ids, d_dists=dd)
+    torch.cuda.synchronize()
+    evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+    ids_p = torch.empty_like(ids)
+    for a_, b_ in evp:
+        a_.record()
+        ib.search_device(q8, k, spb, d_ids64=ids_p, d_dists=dd)
+        b_.record()
+    torch.cuda.synchronize()
+    msp = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evp]))
+    out = {"workload": f"synthetic {n4} x 768 raw int8 rows, int8 queries, cosine (VNNI pair, cosine.h:261-326), batch={nq4}, k=10, graph: config 4's (R=128), 1xMI355X",
+           "vectors": n4, "window_for_recall_0.9": lo_w, "recall_at_10": recall_at(gtb, ids, k), "qps": nq4 / (msb * 1e-3), "kernel_ms": msb, "kernel": "svsx::" + kb,
+           "record_bytes": rbb, "inline_record_GB": mem["inline_record_bytes"] / 1e9, "record_build_seconds": t_rec,
+           "expansions_per_query": int(st[:, 0].sum()) / nq4, "distance_evals_per_query": int(st[:, 2].sum()) / nq4,
+           "bound_code_rejects_per_query": int(st[:, 5].sum()) / nq4, "reject_share": float(st[:, 5].sum()) / max(float(st[:, 2].sum()), 1.0),
+           "designed_lines_per_query": lb["total"] / nq4, "frac_designed": lb["total"] * LINE / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "traffic": tb, "traffic_source": tb_src, "frac_traffic": (tb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None,
+           "plain_kernel_ms": msp, "speedup_over_plain_kernel": msp / msb, "ids_equal_plain_kernel": bool((ids_p == ids).all()),
+           "bias_over_scale": abs(bias) / scale}
+    del ib, gtb
+    return out
 
 
 def main():

@@ -30,7 +30,11 @@ typedef enum {
     SVSX_INVALID_ARGUMENT = 2,
     SVSX_NOT_IMPLEMENTED = 3,
     SVSX_NOT_INITIALIZED = 4,
-    SVSX_RUNTIME_ERROR = 5
+    SVSX_RUNTIME_ERROR = 5,
+    /* not in the reference's enum and NOT a failure: svsx_index_build_bound_codes completed, but with a smaller scheme than asked for because the
+     * one asked for does not fit the free HBM (searches stay result-identical; svsx_last_error() says what was built,
+     * svsx_index_memory()[8] / [3] which scheme and record size are in effect) */
+    SVSX_FELL_BACK = 64
 } svsx_status;
 
 /* svs::DistanceType (core/distance.h) / runtime MetricType (api_defs.h:95).  The distance functors these
@@ -217,6 +221,28 @@ int svsx_sharded_search_device(
     float* d_dists, void* hip_stream
 );
 
+/* The pipeline of svsx_sharded_search_device as data: every operation one call enqueues, in order, on its three streams (0 = the caller's,
+ * 1 / 2 = internal).  A pure host function (no GPU, no object): the library executes exactly this list, tests replay it through a
+ * happens-before model, a host can inspect what will overlap with what.  n_local local shards, exchange != 0 when an all-gather follows
+ * (world > 1 or a communicator attached), have_last != 0 when an earlier call's staging must be chained behind.  Writes up to `cap` operations
+ * and the total count (ops may be NULL to ask for the count only). */
+enum { SVSX_OP_WAIT = 0, SVSX_OP_RECORD = 1, SVSX_OP_SEARCH = 2, SVSX_OP_LOCAL_MERGE = 3, SVSX_OP_ALLGATHER = 4, SVSX_OP_WORLD_MERGE = 5, SVSX_OP_STAMP = 6 };
+enum { SVSX_EV_START = 0, SVSX_EV_JOIN0 = 1, SVSX_EV_JOIN1 = 2, SVSX_EV_READY0 = 3, SVSX_EV_READY1 = 4, SVSX_EV_DONE0 = 5, SVSX_EV_DONE1 = 6, SVSX_EV_LAST = 7 };
+typedef struct {
+    int32_t kind;    /* SVSX_OP_* */
+    int32_t stream;  /* 0 caller's stream, 1 / 2 internal streams */
+    int32_t chunk;   /* chunk of the batch (-1: the whole call) */
+    int32_t arg;     /* WAIT / RECORD: SVSX_EV_*; SEARCH: local shard; STAMP: phase boundary 0..4 (timing events, recorded only when timing is on) */
+} svsx_sharded_op;
+int svsx_sharded_plan(size_t n_local, int exchange, size_t nq, int have_last, svsx_sharded_op* ops, size_t cap, size_t* n_ops);
+
+/* Phase times of the LAST call on this object, for explaining a scaling curve: enable, search, read.  ms[0] shard searches, [1] local merge,
+ * [2] all-gather (includes waiting for the slowest rank), [3] world merge -- summed over the chunks of the call -- and [4] the span from the first
+ * search to the last merge (smaller than the sum when the second chunk's searches overlap the first chunk's exchange).  Synchronises with the
+ * call.  Timing adds five event records per chunk; leave it off in production. */
+int svsx_sharded_set_timing(svsx_sharded* sharded, int enabled);
+int svsx_sharded_phase_times(svsx_sharded* sharded, float ms[5]);
+
 /* Exhaustive search: svs::index::flat::FlatIndex::search (index/flat/flat.h:322-460) -- every query
  * against every vector, k best by (distance, then id), EXACT, any k and d.  Up to k = 224 a float16 MFMA pass shortlists min(128, max(4k, k+32)) candidates per query
  * (k + 32 beyond k = 96; always >= k + 32; large sets up to d = 768: every row under a sampled threshold, about 16 (k + 4) per query), which are re-ranked with the exact reference-order distance kernels; then every query's answer is
@@ -349,8 +375,13 @@ int svsx_get_distance(const svsx_index* index, uint64_t id, const void* query, i
  *   mode 2        graph-inline records (the default of bench.py): every adjacency row carries a 32- / 64- / 128-byte record per neighbour
  *                 (8-bit codes of the leading coordinates in a principal basis of the data, coding error, norm of the uncoded remainder),
  *                 so one hop reads ONE contiguous block of (4 + record) * max_degree bytes and bounds all its neighbours at once.  The record
- *                 size is chosen from the data's spectrum (expected lines per hop).  float32 / float16 rows under any metric, scalar-
- *                 quantized rows under inner product / cosine; dimension 32..4096; + record * max_degree bytes of HBM per vector.
+ *                 size is chosen from the data's spectrum (expected lines per hop).  float32 / float16 rows, scalar-quantized rows (the
+ *                 compressed L2 distance with records in code space, scalar.h:58-105) and raw int8 / uint8 rows searched with queries of
+ *                 their own type (the VNNI pairs), under any metric; dimension 32..4096.
+ *                 MEMORY: + (4 + record) * graph_row_stride bytes of HBM per vector -- 2.3 GB for 1 M vectors at R = 64 with 32-byte records
+ *                 (6x the 384 MB of d = 96 float32 rows), 29 GB per 12.5 M-vector shard, 169 GB for 10 M x R = 128 with 128-byte records.
+ *                 When that does not fit the free HBM the call does NOT fail: it builds smaller records (64, 32 bytes), then mode 1 where the
+ *                 row type has it, then nothing, and returns SVSX_FELL_BACK (svsx_last_error() names what was built).
  *   mode 32 / 64 / 128   the same with exactly this record size (refused when larger than a third of the rows it protects)
  *   mode 1        one 128-byte row per vector: 8-bit codes of its first min(d, 120) components + exact coding error (float32 / float16
  *                 rows, L2, d = 96 or 128; +128 B per vector, one extra line per candidate).  For indexes whose inline rows do not fit.
@@ -361,6 +392,12 @@ int svsx_index_build_bound_codes(svsx_index* index, int mode);
 /* Index facts: info[0]=n, [1]=d, [2]=data bytes in HBM, [3]=graph bytes in HBM, [4]=graph row stride (u32),
  * [5]=data row stride (bytes). */
 int svsx_index_info(const svsx_index* index, uint64_t info[6]);
+
+/* HBM the index holds and the bound scheme in effect (bytes): mem[0] vector rows, [1] graph, [2] graph-inline records, [3] their record size
+ * (32 / 64 / 128; 0 = none), [4] 128-byte code rows, [5] float16 shadow + squared norms of the flat search (built by the first flat search),
+ * [6] row norms of scalar-quantized cosine rows, [7] total ALLOCATED BY THE LIBRARY (a device view borrows [0] and [1]), [8] bound scheme in
+ * effect (0 none, 1 code rows, 2 inline records), [9] 1 when the index owns its rows and graph. */
+int svsx_index_memory(const svsx_index* index, uint64_t mem[10]);
 
 /* Status::message() (api_defs.h:119-184): text of the last failure on this thread. */
 const char* svsx_last_error(void);

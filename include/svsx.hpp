@@ -15,6 +15,7 @@
 #include "svsx.h"
 #include "svsx_io.hpp"
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -205,7 +206,15 @@ template <typename T, typename Dist> class VamanaIndex {
     }
     // optional, result-neutral (svsx.h): 2 = graph-inline bound records sized from the data's spectrum (the default and the fast path of
     // bench.py), 32 / 64 / 128 = records of that size, 1 = one 128-byte code row per vector (float rows, L2, d = 96 / 128), 0 = off
-    void build_bound_codes(int mode = 2) { check(svsx_index_build_bound_codes(h_, mode)); }
+    /// Returns false when the scheme asked for did not fit the free HBM and a smaller one was built instead (SVSX_FELL_BACK: not an error;
+    /// `memory()[8]` / `[3]` say which scheme and record size are in effect, svsx_last_error() why).
+    bool build_bound_codes(int mode = 2) {
+        const int rc = svsx_index_build_bound_codes(h_, mode);
+        if (rc == SVSX_FELL_BACK) return false;
+        check(rc);
+        return true;
+    }
+    std::array<uint64_t, 10> memory() const { std::array<uint64_t, 10> m{}; check(svsx_index_memory(h_, m.data())); return m; }
     // scalar-quantized rows under cosine similarity keep one norm per row (svsx.h): recompute them in the order of `hip_stream` after rewriting
     // rows of a device view, or release them (searches then take the norm per candidate, as the reference does; same results)
     void refresh_row_norms(void* hip_stream = nullptr) { check(svsx_index_refresh_row_norms(h_, hip_stream)); }

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVSX_LIB") or os.path.join(_HERE, "libsvsx.so")  # SVSX_LIB: A/B builds of the same ABI
 
 SUCCESS, UNKNOWN_ERROR, INVALID_ARGUMENT, NOT_IMPLEMENTED, NOT_INITIALIZED, RUNTIME_ERROR = range(6)
+FELL_BACK = 64  # svsx.h: not a failure -- svsx_index_build_bound_codes built a smaller scheme than asked for (HBM)
 
 
 class SvsxError(RuntimeError):
@@ -92,7 +93,8 @@ EXPORTS = [
     "svsx_last_kernel_info", "svsx_search_filtered", "svsx_search_filtered_ex", "svsx_vamana_build_device", "svsx_find_medoid_device",
     "svsx_sharded_unique_id", "svsx_sharded_create", "svsx_sharded_create_with_comm", "svsx_sharded_destroy", "svsx_sharded_info",
     "svsx_sharded_search_device", "svsx_abi_version", "svsx_flat_search_device_counted", "svsx_flat_search",
-    "svsx_index_refresh_row_norms", "svsx_index_drop_row_norms", "svsx_range_search", "svsx_get_distance",
+    "svsx_index_refresh_row_norms", "svsx_index_drop_row_norms", "svsx_range_search", "svsx_get_distance", "svsx_index_memory",
+    "svsx_sharded_plan", "svsx_sharded_set_timing", "svsx_sharded_phase_times",
 ]
 
 _lib = None
@@ -147,6 +149,7 @@ def lib() -> C.CDLL:
         L.svsx_flat_search_device_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.svsx_flat_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.svsx_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.svsx_index_memory.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.svsx_iterator_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
         L.svsx_iterator_destroy.argtypes = [C.c_void_p]
         L.svsx_iterator_destroy.restype = None

@@ -1,82 +1,16 @@
-// svsx_api.hip -- host side of the C ABI declared in include/svsx.h (libsvsx.so).
+// svsx_api.hip -- host side of the C ABI declared in include/svsx.h (libsvsx.so): index life cycle, the search entry points (device- and
+// host-pointer), distance plugin, iterator, filtered and range search.  Bound records: svsx_records.hip; flat search: svsx_flat_host.hip;
+// shared host-side types: svsx_host.h.
+//
 //
 // Owns the HBM-resident index (re-laid-out copies of the SVS data/graph arrays), validates arguments the way the
 // reference's runtime layer does (bindings/cpp/src/vamana_index.cpp:56-72, vamana_index_impl.h:109-138) and
 // launches the gfx950 kernels.  There is deliberately NO CPU fallback: without a HIP device every compute entry
 // point fails with SVSX_RUNTIME_ERROR.
-#include "../../include/svsx.h"
-#include "svsx_device.h"
-#include "svsx_kernels.h"
-#include "svsx_flat_proof.h"
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <thread>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <random>
-#include <string>
-#include <vector>
-
-using namespace svsx;
-
-struct svsx_index {
-    int metric = 0;
-    int data_dtype = 0;
-    size_t n = 0, d = 0;
-    void* d_data = nullptr;
-    size_t row_bytes = 0;
-    uint32_t* d_graph = nullptr;
-    size_t gstride = 0;
-    uint32_t* d_entry = nullptr;
-    size_t n_entry = 0;
-    int sq_enabled = 0;
-    float sq_scale = 1.0f, sq_bias = 0.0f;
-    float* d_sq_row_norm = nullptr; // scalar-quantized rows under cosine: sqrtf(||decompressed row||^2), reference order (launch_sq_row_norms)
-    int device = 0;
-    uint64_t id_offset = 0;
-    bool owns = true;
-    // lazily built float16 shadow for the MFMA flat-search filter (svsx_flat.hip)
-    mutable std::mutex shadow_mutex;
-    mutable void* d_half = nullptr;
-    mutable float* d_norm2 = nullptr;
-    mutable float shadow_max2 = 0.0f, shadow_min2 = 0.0f; // range of d_norm2 (flat search: exactness proof)
-    // bound codes (svsx_index_build_bound_codes): 128 B per vector
-    void* d_codes = nullptr;
-    float code_scale = 1.0f, code_bias = 0.0f, code_eq_abs = 0.0f;
-    // graph-inline records (svsx_index_build_bound_codes mode 2; svsx_codes.hip)
-    void* d_fat = nullptr;
-    size_t fat_stride = 0;
-    uint32_t fat_rb = 32;
-    uint32_t fat_degshift = 0; // 26 when the blocks' id words carry the neighbours' degree classes (n <= 2^26), else 0
-    float* d_pca = nullptr;      // [32][dpad] leading directions (float32, row-major, zero padded) | [dpad] mean | [32] bias
-    float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_delta = 0.0f, pca_eq_abs = 0.0f, pca_ref_extra = 0.0f;
-    // host-pointer calls (svsx_search): persistent staging contexts, one per concurrent caller (HostCallContext below)
-    mutable std::mutex ctx_mutex;
-    mutable std::vector<struct HostCallContext*> ctx_free;
-};
+#include "svsx_host.h"
 
 namespace {
-
 thread_local std::string g_error;
-constexpr uint32_t kDefaultFilterEntries = 2048;
-
-int fail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_error = buf;
-    return code;
-}
-
 } // namespace
 
 namespace svsx { // for the other translation units of the library (svsx_sharded.hip)
@@ -95,144 +29,6 @@ void index_facts(const svsx_index* ix, int* metric, int* device, size_t* d) {
     *d = ix->d;
 }
 } // namespace svsx
-
-namespace {
-
-#define HIP_TRY(expr)                                                                                      \
-    do {                                                                                                   \
-        hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : dt == DT_F16 ? 2 : (dt == DT_I8 || dt == DT_U8) ? 1 : 0; }
-
-// Which kernel family serves (query dtype, data dtype) -- the reference's AVX-512 specialisation table
-// (euclidean.h:318-358 and the VNNI pairs :291-313); everything else has only a scalar loop there (generic_l2 and its
-// siblings: utils/search_index.cpp:147-162 offers six such pairs) and takes the scalar-loop kernels here (QM_SCALAR, round 5).
-int select_qmode(int metric, int q_dtype, int data_dtype, int sq_enabled) {
-    if (sq_enabled) {
-        if (data_dtype != DT_I8 && data_dtype != DT_U8) return -1;
-        if (q_dtype != DT_F32 && q_dtype != DT_F16) return -1;
-        return metric == M_L2 ? QM_SQ_L2 : metric == M_IP ? QM_SQ_IP : QM_SQ_COS;
-    }
-    if ((q_dtype == DT_I8 && data_dtype == DT_I8) || (q_dtype == DT_U8 && data_dtype == DT_U8)) return QM_INT;
-    if (q_dtype == DT_F32) return QM_FLOAT;
-    if (q_dtype == DT_F16 && (data_dtype == DT_F32 || data_dtype == DT_F16)) return QM_FLOAT;
-    return QM_SCALAR;
-}
-
-size_t padded_row_bytes(size_t d, int dt) { return ((d + 15) & ~size_t(15)) * dtype_size(dt); }
-
-struct DeviceBuffer {
-    void* p = nullptr;
-    ~DeviceBuffer() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
-
-// Temporary buffer allocated and released in stream order (no device-wide synchronisation).
-struct StreamBuffer {
-    void* p = nullptr;
-    hipStream_t s = nullptr;
-    ~StreamBuffer() {
-        if (p) (void)hipFreeAsync(p, s);
-    }
-    hipError_t alloc(size_t bytes, hipStream_t stream) {
-        s = stream;
-        return hipMallocAsync(&p, bytes ? bytes : 1, stream);
-    }
-};
-
-// A private stream per host call: concurrent callers (index.h:541-545 contract) never serialise on the default stream.
-struct CallStream {
-    hipStream_t s = nullptr;
-    ~CallStream() {
-        if (s) (void)hipStreamDestroy(s);
-    }
-    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
-};
-
-} // namespace
-
-// Everything a host-pointer svsx_search needs between calls: streams and device staging, grown on demand and kept with the index -- the
-// per-call hipStreamCreate / hipMallocAsync of round 2 cost 0.65 ms per 10 000-query batch.
-// The batch is cut into chunks, each on its own stream: H2D of chunk i+1 and D2H of chunk i-1 overlap the kernel of chunk i (queries are
-// independent, index/vamana/index.h:571-574, so the results are those of one launch).
-struct HostCallContext {
-    static constexpr int kMaxChunks = 8;
-    hipStream_t streams[kMaxChunks] = {};
-    void* d_in = nullptr;   size_t d_in_cap = 0;    // queries
-    void* d_out = nullptr;  size_t d_out_cap = 0;   // ids64 | ids32 | dists | stats | history ids | history dists | history len
-    bool dirty = false;                             // an error return left work in flight on the streams: drained before the context is reused
-    static constexpr size_t kKeepBytes = size_t(64) << 20; // staging beyond this is given back when a call that needed it has returned
-    ~HostCallContext() {
-        for (auto st : streams) if (st) (void)hipStreamDestroy(st);
-        release();
-    }
-    void release() {
-        if (d_in) (void)hipFree(d_in);
-        if (d_out) (void)hipFree(d_out);
-        d_in = d_out = nullptr;
-        d_in_cap = d_out_cap = 0;
-    }
-    void drain() { // every stream idle: nothing reads or writes the staging any more
-        for (auto st : streams) if (st) (void)hipStreamSynchronize(st);
-        dirty = false;
-    }
-    void trim() {  // one huge batch must not keep gigabytes of staging for the life of the index
-        if (d_in_cap + d_out_cap > 2 * kKeepBytes) { drain(); release(); }
-    }
-    hipError_t reserve(size_t in_bytes, size_t out_bytes, int n_streams) {
-        for (int i = 0; i < n_streams; ++i)
-            if (!streams[i]) { hipError_t e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking); if (e != hipSuccess) return e; }
-        auto grow = [](void*& p, size_t& cap, size_t want) -> hipError_t {
-            if (want <= cap) return hipSuccess;
-            if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-            const size_t bytes = want + want / 4 + 4096;
-            hipError_t e = hipMalloc(&p, bytes);
-            if (e == hipSuccess) cap = bytes;
-            return e;
-        };
-        hipError_t e = grow(d_in, d_in_cap, in_bytes);
-        if (e == hipSuccess) e = grow(d_out, d_out_cap, out_bytes);
-        return e;
-    }
-    hipError_t stream0() { return streams[0] ? hipSuccess : hipStreamCreateWithFlags(&streams[0], hipStreamNonBlocking); }
-};
-
-namespace {
-
-// borrowed for the duration of one call; concurrent callers get one each (index/vamana/index.h:541-545)
-struct ContextLease {
-    const svsx_index* ix;
-    HostCallContext* c = nullptr;
-    explicit ContextLease(const svsx_index* index) : ix(index) {
-        {
-            std::lock_guard<std::mutex> lock(ix->ctx_mutex);
-            if (!ix->ctx_free.empty()) { c = ix->ctx_free.back(); ix->ctx_free.pop_back(); }
-        }
-        if (!c) c = new (std::nothrow) HostCallContext();
-        if (c && c->dirty) c->drain();
-    }
-    ~ContextLease() {
-        if (!c) return;
-        if (c->dirty) c->drain(); // an early return with copies / kernels still in flight: the next caller must not find an active DMA on the staging
-        c->trim();
-        std::lock_guard<std::mutex> lock(ix->ctx_mutex);
-        ix->ctx_free.push_back(c);
-    }
-};
-
-int validate_common(int metric, int dtype, size_t n, size_t d) {
-    if (metric < 0 || metric > 2) return fail(SVSX_INVALID_ARGUMENT, "unknown metric %d", metric);
-    if (dtype_size(dtype) == 0) return fail(SVSX_INVALID_ARGUMENT, "unknown data dtype %d", dtype);
-    if (n == 0 || d == 0) return fail(SVSX_INVALID_ARGUMENT, "empty dataset (n=%zu, d=%zu)", n, d);
-    if (n >= (size_t(1) << 31)) return fail(SVSX_INVALID_ARGUMENT, "n=%zu exceeds 2^31-1 ids per index (shard it)", n);
-    return SVSX_SUCCESS;
-}
-
-} // namespace
 
 extern "C" {
 
@@ -406,6 +202,24 @@ void svsx_index_destroy(svsx_index* ix) {
     delete ix;
 }
 
+int svsx_index_memory(const svsx_index* ix, uint64_t mem[10]) {
+    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
+    if (!mem) return fail(SVSX_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(ix->shadow_mutex);
+    const size_t dpad_h = ix->d > 128 && ix->d <= 768 ? (ix->d + 127) & ~size_t(127) : (ix->d + 15) & ~size_t(15);
+    mem[0] = ix->row_bytes * ix->n;
+    mem[1] = ix->d_graph ? ix->gstride * ix->n * sizeof(uint32_t) : 0;
+    mem[2] = ix->d_fat ? ix->n * ix->fat_stride + 128 : 0;
+    mem[3] = ix->d_fat ? ix->fat_rb : 0;
+    mem[4] = ix->d_codes ? ix->n * 128 + 128 : 0;
+    mem[5] = ix->d_half ? (ix->n + kShadowPadRows) * dpad_h * 2 + 64 + ix->n * 4 : 0;
+    mem[6] = ix->d_sq_row_norm ? ix->n * 4 : 0;
+    mem[7] = (ix->owns ? mem[0] + mem[1] : 0) + mem[2] + mem[4] + mem[5] + mem[6]; // what the library itself allocated (a device view borrows rows and graph)
+    mem[8] = ix->d_fat ? 2 : ix->d_codes ? 1 : 0;
+    mem[9] = ix->owns ? 1 : 0;
+    return SVSX_SUCCESS;
+}
+
 int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
     if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
     info[0] = ix->n;
@@ -418,395 +232,6 @@ int svsx_index_info(const svsx_index* ix, uint64_t info[6]) {
 }
 
 } // extern "C"
-
-namespace {
-
-// cyclic Jacobi eigen-decomposition of a symmetric d x d matrix (row-major, f64): A -> diagonal, V columns = eigenvectors
-void jacobi_eigh(std::vector<double>& A, int d, std::vector<double>& V) {
-    V.assign(static_cast<size_t>(d) * d, 0.0);
-    for (int i = 0; i < d; ++i) V[static_cast<size_t>(i) * d + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) (i == j ? diag : off) += A[static_cast<size_t>(i) * d + j] * A[static_cast<size_t>(i) * d + j];
-        if (off <= 1e-30 * diag || off == 0.0) break;
-        for (int p = 0; p < d - 1; ++p) {
-            for (int q = p + 1; q < d; ++q) {
-                const double apq = A[static_cast<size_t>(p) * d + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[static_cast<size_t>(q) * d + q] - A[static_cast<size_t>(p) * d + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < d; ++k) { // columns p, q
-                    const double akp = A[static_cast<size_t>(k) * d + p], akq = A[static_cast<size_t>(k) * d + q];
-                    A[static_cast<size_t>(k) * d + p] = c * akp - sn * akq;
-                    A[static_cast<size_t>(k) * d + q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < d; ++k) { // rows p, q
-                    const double apk = A[static_cast<size_t>(p) * d + k], aqk = A[static_cast<size_t>(q) * d + k];
-                    A[static_cast<size_t>(p) * d + k] = c * apk - sn * aqk;
-                    A[static_cast<size_t>(q) * d + k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < d; ++k) {
-                    const double vkp = V[static_cast<size_t>(k) * d + p], vkq = V[static_cast<size_t>(k) * d + q];
-                    V[static_cast<size_t>(k) * d + p] = c * vkp - sn * vkq;
-                    V[static_cast<size_t>(k) * d + q] = sn * vkp + c * vkq;
-                }
-            }
-        }
-    }
-}
-
-float half_bits_to_float(uint16_t h) {
-    const uint32_t sign = (h & 0x8000u) << 16, ex = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
-    uint32_t u;
-    if (ex == 0) {
-        if (man == 0) u = sign;
-        else {
-            int e = -1;
-            uint32_t m = man;
-            do { ++e; m <<= 1; } while (!(m & 0x400u));
-            u = sign | ((127 - 15 - e) << 23) | ((m & 0x3FFu) << 13);
-        }
-    } else if (ex == 31) u = sign | 0x7F800000u | (man << 13);
-    else u = sign | ((ex + 112) << 23) | (man << 13);
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-
-constexpr uint32_t kPcaRows = 128;  // rows of the float32 device copy of the directions (rows >= dc are zero)
-
-// modified Gram-Schmidt on the m columns of V (d x m, column j at V[i * m + j]); twice for orthogonality to rounding
-void orthonormalize_columns(std::vector<double>& V, uint32_t d, uint32_t m) {
-    for (int rep = 0; rep < 2; ++rep)
-        for (uint32_t j = 0; j < m; ++j) {
-            for (uint32_t k = 0; k < j; ++k) {
-                double dot = 0.0;
-                for (uint32_t i = 0; i < d; ++i) dot += V[static_cast<size_t>(i) * m + j] * V[static_cast<size_t>(i) * m + k];
-                for (uint32_t i = 0; i < d; ++i) V[static_cast<size_t>(i) * m + j] -= dot * V[static_cast<size_t>(i) * m + k];
-            }
-            double nrm = 0.0;
-            for (uint32_t i = 0; i < d; ++i) nrm += V[static_cast<size_t>(i) * m + j] * V[static_cast<size_t>(i) * m + j];
-            nrm = std::sqrt(nrm);
-            if (!(nrm > 1e-300)) { // degenerate direction: replace by a unit vector and let the next repetition clean it up
-                for (uint32_t i = 0; i < d; ++i) V[static_cast<size_t>(i) * m + j] = (i == j % d) ? 1.0 : 0.0;
-                nrm = 1.0;
-            }
-            for (uint32_t i = 0; i < d; ++i) V[static_cast<size_t>(i) * m + j] /= nrm;
-        }
-}
-
-// graph-inline records: sample -> leading principal directions (host, f64) -> per-vector records (device) -> node rows (device)
-int build_fat_rows(svsx_index* ix, uint32_t forced_rb) {
-    const uint32_t d = static_cast<uint32_t>(ix->d), n = static_cast<uint32_t>(ix->n);
-    const size_t es = dtype_size(ix->data_dtype);
-    const bool l2 = ix->metric == M_L2, cosine = ix->metric == M_COS;
-    const uint32_t meta = l2 ? 4u : 6u; // bytes of float16 fields at the end of a record
-    // 1. sample (evenly strided) -> host, the vector the metric sees (decompressed / normalised), f64
-    const size_t want = d <= 128 ? 65536 : (d <= 256 ? 32768 : 8192);
-    const size_t ns = n < want ? n : want;
-    const size_t step = n / ns;
-    std::vector<unsigned char> raw(ns * d * es);
-    HIP_TRY(hipMemcpy2D(raw.data(), d * es, ix->d_data, step * ix->row_bytes, d * es, ns, hipMemcpyDeviceToHost));
-    std::vector<double> xs(ns * d);
-    for (size_t i = 0; i < ns * d; ++i) {
-        float f;
-        switch (ix->data_dtype) {
-            case DT_F32: f = reinterpret_cast<const float*>(raw.data())[i]; break;
-            case DT_F16: f = half_bits_to_float(reinterpret_cast<const uint16_t*>(raw.data())[i]); break;
-            case DT_I8: f = static_cast<float>(reinterpret_cast<const int8_t*>(raw.data())[i]); break;
-            default: f = static_cast<float>(raw[i]); break;
-        }
-        if (ix->sq_enabled) {
-            const float t = ix->sq_scale * f;
-            f = t + ix->sq_bias;
-        }
-        xs[i] = f;
-        if (!(xs[i] - xs[i] == 0.0)) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
-    }
-    if (cosine)
-        for (size_t r = 0; r < ns; ++r) {
-            double nrm = 0.0;
-            for (uint32_t j = 0; j < d; ++j) nrm += xs[r * d + j] * xs[r * d + j];
-            nrm = nrm > 0.0 ? 1.0 / std::sqrt(nrm) : 0.0;
-            for (uint32_t j = 0; j < d; ++j) xs[r * d + j] *= nrm;
-        }
-    const uint32_t pd = (d + 15u) & ~15u;
-    std::vector<float> mean_f(pd, 0.0f);
-    if (l2) {
-        std::vector<double> mean(d, 0.0);
-        for (size_t r = 0; r < ns; ++r)
-            for (uint32_t j = 0; j < d; ++j) mean[j] += xs[r * d + j];
-        for (uint32_t j = 0; j < d; ++j) mean_f[j] = static_cast<float>(mean[j] / static_cast<double>(ns));
-        for (size_t r = 0; r < ns; ++r)
-            for (uint32_t j = 0; j < d; ++j) xs[r * d + j] -= static_cast<double>(mean_f[j]);
-    }
-    // 2. second-moment matrix (upper triangle, then mirrored)
-    std::vector<double> cov(static_cast<size_t>(d) * d, 0.0);
-    for (size_t r = 0; r < ns; ++r) {
-        const double* row = &xs[r * d];
-        for (uint32_t i = 0; i < d; ++i) {
-            const double ri = row[i];
-            double* c = &cov[static_cast<size_t>(i) * d];
-            for (uint32_t j = i; j < d; ++j) c[j] += ri * row[j];
-        }
-    }
-    for (uint32_t i = 0; i < d; ++i)
-        for (uint32_t j = i; j < d; ++j) {
-            const double v = cov[static_cast<size_t>(i) * d + j] / static_cast<double>(ns);
-            cov[static_cast<size_t>(i) * d + j] = v;
-            cov[static_cast<size_t>(j) * d + i] = v;
-        }
-    // 3. leading directions by subspace iteration + Rayleigh-Ritz (ANY orthonormal set is valid for the bound; a good one
-    //    makes it tight).  m >= dc columns for convergence margin.
-    // candidate record sizes: a record larger than a third of the row it protects cannot pay for itself
-    uint32_t rb_max = 32;
-    if (ix->row_bytes >= 3 * 64) rb_max = 64;
-    if (ix->row_bytes >= 3 * 128) rb_max = 128;
-    const uint32_t m = d < rb_max - meta + 12u ? d : rb_max - meta + 12u;
-    std::vector<double> V(static_cast<size_t>(d) * m), W(static_cast<size_t>(d) * m);
-    uint64_t lcg = 0x9E3779B97F4A7C15ull;
-    for (auto& v : V) {
-        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
-        v = static_cast<double>(static_cast<int64_t>(lcg >> 11) % 2000001 - 1000000) * 1e-6;
-    }
-    orthonormalize_columns(V, d, m);
-    for (int it = 0; it < 48; ++it) {
-        std::fill(W.begin(), W.end(), 0.0);
-        for (uint32_t i = 0; i < d; ++i) {
-            double* w = &W[static_cast<size_t>(i) * m];
-            const double* c = &cov[static_cast<size_t>(i) * d];
-            for (uint32_t k = 0; k < d; ++k) {
-                const double cik = c[k];
-                const double* v = &V[static_cast<size_t>(k) * m];
-                for (uint32_t j = 0; j < m; ++j) w[j] += cik * v[j];
-            }
-        }
-        V.swap(W);
-        orthonormalize_columns(V, d, m);
-    }
-    // Rayleigh-Ritz: T = V^T C V (m x m), eigenvectors Z, V <- V Z ordered by decreasing eigenvalue
-    std::fill(W.begin(), W.end(), 0.0);
-    for (uint32_t i = 0; i < d; ++i)
-        for (uint32_t k = 0; k < d; ++k) {
-            const double cik = cov[static_cast<size_t>(i) * d + k];
-            for (uint32_t j = 0; j < m; ++j) W[static_cast<size_t>(i) * m + j] += cik * V[static_cast<size_t>(k) * m + j];
-        }
-    std::vector<double> T(static_cast<size_t>(m) * m, 0.0), Z;
-    for (uint32_t a = 0; a < m; ++a)
-        for (uint32_t b = 0; b < m; ++b) {
-            double t = 0.0;
-            for (uint32_t i = 0; i < d; ++i) t += V[static_cast<size_t>(i) * m + a] * W[static_cast<size_t>(i) * m + b];
-            T[static_cast<size_t>(a) * m + b] = t;
-        }
-    for (uint32_t a = 0; a < m; ++a)
-        for (uint32_t b = a + 1; b < m; ++b) {
-            const double t = 0.5 * (T[static_cast<size_t>(a) * m + b] + T[static_cast<size_t>(b) * m + a]);
-            T[static_cast<size_t>(a) * m + b] = T[static_cast<size_t>(b) * m + a] = t;
-        }
-    jacobi_eigh(T, static_cast<int>(m), Z);
-    std::vector<uint32_t> order(m);
-    for (uint32_t i = 0; i < m; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return T[static_cast<size_t>(x) * m + x] > T[static_cast<size_t>(y) * m + y]; });
-    // Record size by expected lines per hop: block lines (4 + RB bytes per slot) + the rows of the candidates the bound cannot
-    // exclude.  How many it excludes follows the share f of the sample's second moment the coded directions carry -- the remainder
-    // only enters the bound through a product of norms, which is loose: measured (profiles/r02_notes.md) the bound is useless
-    // below f ~ 0.6 and rejects ~88 % of the candidates at f ~ 0.9 -- modelled as rej = 0.88 clamp((f - 0.6) / 0.3, 0, 1) -- and a little more
-    // towards f = 1 (+ 0.05 clamp((f - 0.9) / 0.1, 0, 1): 0.86 -> 0.926 measured between 64- and 128-byte records on config 4's rows,
-    // profiles/r05_notes.md).  A row of scalar-quantized codes costs far more than its lines: every element is decompressed and multiplied
-    // (2.5 vector instructions, scalar.h:155-195) on a kernel whose few resident waves are bound by their instruction count, not by lines: a
-    // 768-byte row is ~34 wave instructions, doubling the records of a 128-slot row ~50 -- weighted 8x (round 5: 128-byte records beat 64-byte
-    // ones by 18 % on 768-byte rows although they double the block).  A larger record must win by 10 % (the 32-byte form has
-    // static-dimension kernels and the fewest registers).
-    double trace = 0.0;
-    for (uint32_t i = 0; i < d; ++i) trace += cov[static_cast<size_t>(i) * d + i];
-    const double row_lines = static_cast<double>((ix->row_bytes + 127) / 128) * (ix->sq_enabled ? 8.0 : 1.0);
-    const double cand = 0.9 * static_cast<double>(ix->gstride);
-    uint32_t rb = 32;
-    double best_cost = 0.0;
-    for (uint32_t r = 32; r <= rb_max; r *= 2) {
-        double got = 0.0;
-        for (uint32_t c = 0; c < r - meta && c < m; ++c) got += std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0);
-        const double f = trace > 0.0 ? got / trace : 1.0;
-        const double rej = 0.88 * std::min(std::max((f - 0.6) / 0.3, 0.0), 1.0) + 0.05 * std::min(std::max((f - 0.9) / 0.1, 0.0), 1.0);
-        const double cost = static_cast<double>(ix->gstride) * (4.0 + r) / 128.0 + cand * (1.0 - rej) * row_lines;
-        if (r == 32 || cost < 0.9 * best_cost) {
-            best_cost = cost;
-            rb = r;
-        }
-    }
-    if (forced_rb != 0) { // the caller asked for this record size (svsx_index_build_bound_codes mode 32 / 64 / 128)
-        if (forced_rb > rb_max) return fail(SVSX_INVALID_ARGUMENT, "records of %u bytes exceed a third of the %zu-byte rows they protect", forced_rb, ix->row_bytes);
-        rb = forced_rb;
-    }
-    const uint32_t dc = rb - meta;
-    const uint32_t dcu = dc < m ? dc : m; // directions really used (d < dc cannot happen: d >= 32 and m >= dc unless d is smaller)
-    std::vector<double> Q(static_cast<size_t>(d) * dcu), sigma(dcu);
-    for (uint32_t c = 0; c < dcu; ++c) {
-        for (uint32_t i = 0; i < d; ++i) {
-            double v = 0.0;
-            for (uint32_t j = 0; j < m; ++j) v += V[static_cast<size_t>(i) * m + j] * Z[static_cast<size_t>(j) * m + order[c]];
-            Q[static_cast<size_t>(i) * dcu + c] = v;
-        }
-        sigma[c] = std::sqrt(std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0));
-    }
-    orthonormalize_columns(Q, d, dcu);
-    // device copies: float32 rows for the query side (+ delta = how far they are from the f64 directions), f64 rows for the data side
-    std::vector<float> host(static_cast<size_t>(kPcaRows) * pd + pd + 128, 0.0f); // P | mean | bias
-    std::vector<double> q64(static_cast<size_t>(dcu) * d);
-    double delta = 0.0;
-    for (uint32_t c = 0; c < dcu; ++c) {
-        double e2 = 0.0;
-        for (uint32_t j = 0; j < d; ++j) {
-            const double q = Q[static_cast<size_t>(j) * dcu + c];
-            const float f = static_cast<float>(q);
-            host[static_cast<size_t>(c) * pd + j] = f;
-            q64[static_cast<size_t>(c) * d + j] = q;
-            e2 += (static_cast<double>(f) - q) * (static_cast<double>(f) - q);
-        }
-        delta = std::max(delta, std::sqrt(e2));
-    }
-    for (uint32_t j = 0; j < d; ++j) host[static_cast<size_t>(kPcaRows) * pd + j] = mean_f[j];
-    if (ix->d_pca) { (void)hipFree(ix->d_pca); ix->d_pca = nullptr; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ix->d_pca), host.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(ix->d_pca, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
-    DeviceBuffer dq;
-    HIP_TRY(dq.alloc(q64.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(dq.p, q64.data(), q64.size() * sizeof(double), hipMemcpyHostToDevice));
-    // 4. per-coordinate range of y over ALL vectors (device), clipped to +-8 sigma; step, biases, tail unit
-    DeviceBuffer st;
-    HIP_TRY(st.alloc((2 * 128 + 2) * 4));
-    std::vector<uint32_t> init(2 * 128 + 2, 0u);
-    for (uint32_t i = 0; i < 128; ++i) init[i] = 0xFFFFFFFFu;
-    HIP_TRY(hipMemcpy(st.p, init.data(), init.size() * 4, hipMemcpyHostToDevice));
-    PcaArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    pa.data = ix->d_data; pa.row_bytes = ix->row_bytes; pa.dtype = ix->data_dtype; pa.n = n; pa.d = d; pa.dc = dcu; pa.rb = rb;
-    pa.decomp = ix->sq_enabled; pa.sq_scale = ix->sq_scale; pa.sq_bias = ix->sq_bias; pa.normalize = cosine ? 1 : 0; pa.signed_codes = l2 ? 0 : 1;
-    pa.q64 = static_cast<const double*>(dq.p);
-    pa.mean = ix->d_pca + static_cast<size_t>(kPcaRows) * pd; pa.bias = pa.mean + pd;
-    pa.stat_min = static_cast<uint32_t*>(st.p); pa.stat_max = pa.stat_min + 128; pa.stat_tail = pa.stat_max + 128; pa.stat_bad = pa.stat_tail + 1;
-    HIP_TRY(launch_pca_stats(pa, nullptr));
-    std::vector<uint32_t> stats(2 * 128 + 2);
-    HIP_TRY(hipMemcpy(stats.data(), st.p, stats.size() * 4, hipMemcpyDeviceToHost));
-    if (stats[2 * 128 + 1] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
-    double range = 0.0, bmax = 0.0;
-    std::vector<float> bias(128, 0.0f);
-    for (uint32_t i = 0; i < dcu; ++i) {
-        double lo = pca_key_to_float(stats[i]), hi = pca_key_to_float(stats[128 + i]);
-        if (sigma[i] > 0.0) { // outliers beyond 8 sigma clamp (their coding error is in their own ex)
-            lo = std::max(lo, -8.0 * sigma[i]);
-            hi = std::min(hi, 8.0 * sigma[i]);
-        }
-        if (!(hi > lo)) hi = lo;
-        if (l2) {
-            bias[i] = static_cast<float>(lo);
-            range = std::max(range, hi - lo);
-            bmax = std::max(bmax, std::fabs(static_cast<double>(bias[i])));
-        } else {
-            range = std::max(range, std::max(std::fabs(lo), std::fabs(hi)));
-        }
-    }
-    float stepf = static_cast<float>(range / (l2 ? 255.0 : 127.0));
-    if (!(stepf > 0.0f) || !(stepf < 3.0e38f)) stepf = 1.0f;
-    float tail_max = pca_key_to_float(stats[2 * 128]);
-    if (!(tail_max > 0.0f) || !(tail_max < 3.0e38f)) tail_max = 1.0f;
-    const float tail_unit = tail_max / 60000.0f;
-    HIP_TRY(hipMemcpy(ix->d_pca + static_cast<size_t>(kPcaRows) * pd + pd, bias.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
-    // 5. records, then node rows
-    DeviceBuffer rec;
-    HIP_TRY(rec.alloc(static_cast<size_t>(n) * rb + 128));
-    pa.step = stepf; pa.tail_unit = tail_unit; pa.records = static_cast<uint32_t*>(rec.p);
-    HIP_TRY(launch_pca_encode(pa, nullptr));
-    const size_t fat_stride = (ix->gstride * (4 + rb) + 127) & ~size_t(127);
-    void* fat = nullptr;
-    if (hipMalloc(&fat, static_cast<size_t>(n) * fat_stride + 128) != hipSuccess)
-        return fail(SVSX_RUNTIME_ERROR, "hipMalloc(%zu) for the graph-inline records failed", static_cast<size_t>(n) * fat_stride);
-    // degree-aware block loads (svsx_search_kernel.h): ids below 2^26 leave bits [26, 31) of a buffer word for ceil(degree / 8)
-    constexpr uint32_t kDegShift = 26;
-    const bool deg_aware = n <= (1u << kDegShift) && ix->gstride <= 248; // class = ceil(degree / 8) <= 31: five bits
-    DeviceBuffer cls;
-    if (deg_aware && cls.alloc(n) != hipSuccess) {
-        (void)hipFree(fat);
-        return fail(SVSX_RUNTIME_ERROR, "hipMalloc(%u) for the degree classes failed", n);
-    }
-    hipError_t e = launch_fat_build(ix->d_graph, static_cast<uint32_t>(ix->gstride), n, rec.p, rb, fat, fat_stride, deg_aware ? static_cast<uint8_t*>(cls.p) : nullptr,
-                                    kDegShift, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) {
-        (void)hipFree(fat);
-        return fail(SVSX_RUNTIME_ERROR, "graph-inline record kernels failed: %s", hipGetErrorString(e));
-    }
-    ix->d_fat = fat;
-    ix->fat_stride = fat_stride;
-    ix->fat_rb = rb;
-    ix->fat_degshift = deg_aware ? kDegShift : 0u;
-    ix->pca_step = stepf;
-    ix->pca_tail_unit = tail_unit;
-    ix->pca_delta = static_cast<float>(delta * 1.01 + 1e-9);
-    // rounding of fl(b + s c) (L2) / fl(s c) (signed codes) in the query's residual: <= 2^-23 (|b| + 255 s) per coordinate
-    ix->pca_eq_abs = static_cast<float>(std::sqrt(static_cast<double>(dcu)) * 1.2e-7 * (bmax + 255.0 * stepf) * 1.01);
-    ix->pca_ref_extra = ix->sq_enabled ? static_cast<float>(2.0 * std::fabs(static_cast<double>(ix->sq_bias)) * std::sqrt(static_cast<double>(d)) * 1.01) : 0.0f;
-    return SVSX_SUCCESS;
-}
-
-} // namespace
-
-extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
-    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
-    uint32_t forced_rb = 0;
-    if (mode == 32 || mode == 64 || mode == 128) { // graph-inline records of exactly this size
-        forced_rb = static_cast<uint32_t>(mode);
-        mode = 2;
-    }
-    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows), 2 (graph-inline records) or 32 / 64 / 128 (inline records of that size)");
-    HIP_TRY(hipSetDevice(ix->device));
-    std::lock_guard<std::mutex> lock(ix->shadow_mutex);
-    HIP_TRY(hipDeviceSynchronize());
-    // one scheme at a time: drop what the new mode does not use
-    if (mode != 1 && ix->d_codes) { (void)hipFree(ix->d_codes); ix->d_codes = nullptr; }
-    if (mode != 2 && ix->d_fat) { (void)hipFree(ix->d_fat); ix->d_fat = nullptr; }
-    if (mode == 0) return SVSX_SUCCESS;
-    if (mode == 2) {
-        // float32 / float16 rows (any metric) and scalar-quantized rows under inner product / cosine (the compressed L2 distance
-        // is taken between CODED query and data, scalar.h:58-105, and the raw int8 x int8 kernels are exact integer paths)
-        if (ix->d_fat && (forced_rb == 0 || forced_rb == ix->fat_rb)) return SVSX_SUCCESS;
-        if (ix->d_fat) { (void)hipFree(ix->d_fat); ix->d_fat = nullptr; }
-        const bool float_rows = (ix->data_dtype == DT_F32 || ix->data_dtype == DT_F16) && !ix->sq_enabled;
-        const bool sq_rows = ix->sq_enabled && ix->metric != M_L2;
-        if (!float_rows && !sq_rows) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover float32 / float16 rows and scalar-quantized rows under inner product or cosine");
-        if (ix->d < 32 || ix->d > 4096 || !ix->d_graph) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover graph indexes of dimension 32..4096");
-        return build_fat_rows(ix, forced_rb);
-    }
-    if (ix->metric != M_L2 || (ix->data_dtype != DT_F32 && ix->data_dtype != DT_F16) || ix->sq_enabled)
-        return fail(SVSX_NOT_IMPLEMENTED, "128-byte bound-code rows cover float32 / float16 L2 indexes");
-    if (ix->d_codes) return SVSX_SUCCESS;
-    if (ix->d != 96 && ix->d != 128) return fail(SVSX_NOT_IMPLEMENTED, "128-byte bound-code rows cover dimension 96 or 128");
-    const uint32_t dc = static_cast<uint32_t>(ix->d < 120 ? ix->d : 120);
-    DeviceBuffer mm;
-    HIP_TRY(mm.alloc(12));
-    HIP_TRY(launch_codes_minmax(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, static_cast<uint32_t*>(mm.p), nullptr));
-    uint32_t h[3];
-    HIP_TRY(hipMemcpy(h, mm.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[2] != 0) return fail(SVSX_INVALID_ARGUMENT, "bound codes need finite data");
-    const float lo = codes_key_to_float(h[0]), hi = codes_key_to_float(h[1]);
-    float scale = (hi - lo) / 255.0f;
-    if (!(scale > 0.0f) || !(scale < 3.0e38f)) scale = 1.0f;
-    void* codes = nullptr;
-    HIP_TRY(hipMalloc(&codes, ix->n * 128 + 128));
-    hipError_t e = launch_codes_build(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), dc, scale, lo, codes, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) {
-        (void)hipFree(codes);
-        return fail(SVSX_RUNTIME_ERROR, "bound code kernel failed: %s", hipGetErrorString(e));
-    }
-    ix->code_scale = scale;
-    ix->code_bias = lo;
-    ix->code_eq_abs = static_cast<float>(std::sqrt(static_cast<double>(dc)) * 2.4e-7 * (std::fabs(static_cast<double>(lo)) + 255.0 * scale) * 1.01);
-    ix->d_codes = codes;
-    return SVSX_SUCCESS;
-}
 
 extern "C" {
 
@@ -986,15 +411,6 @@ static int search_common(
     return SVSX_SUCCESS;
 }
 
-static int check_search_args(const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, bool need_graph = true) {
-    if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
-    if (need_graph && !ix->d_graph) return fail(SVSX_INVALID_ARGUMENT, "this index was created without a graph (flat search only)");
-    if (k == 0) return fail(SVSX_INVALID_ARGUMENT, "k must be greater than 0");
-    if (dtype_size(q_dtype) == 0) return fail(SVSX_INVALID_ARGUMENT, "unknown query dtype %d", q_dtype);
-    if (nq > 0 && !queries) return fail(SVSX_INVALID_ARGUMENT, "null queries");
-    if (nq >= (size_t(1) << 31)) return fail(SVSX_INVALID_ARGUMENT, "too many queries in one batch");
-    return SVSX_SUCCESS;
-}
 
 // the caller's aux through the size it was compiled with (svsx.h: struct_size)
 constexpr size_t kAuxSizeAbi3 = 64; // struct_size, four pointers, two sizes, the cancel word: the struct as ABI 3 introduced it
@@ -1216,269 +632,6 @@ int svsx_distance_batch(
     if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "distance kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, na * nb * 4, hipMemcpyDeviceToHost));
-    return SVSX_SUCCESS;
-}
-
-// rank at which the threshold levels take their next threshold: k + 4, at least 12, at most the shortlist length (round 4: k + 8, at least 16;
-// with the cheaper appends of round 5 the ~16 kt appended rows per query weigh more: k + 4 is worth 4-8 % of a search, k + 2 one more per cent,
-// and no query of the bench sets needs the exhaustive pass at either; profiles/r05_notes.md section 5)
-#ifndef SVSX_FLAT_KT
-#define SVSX_FLAT_KT(k, kk) ((k) + 4 > 12 ? ((k) + 4 < (kk) ? (k) + 4 : (kk)) : (12 < (kk) ? size_t(12) : (kk)))
-#endif
-int svsx_flat_search_device(
-    const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, void* hip_stream
-) {
-    return svsx_flat_search_device_counted(ix, d_queries, q_dtype, nq, k, d_ids64, d_dists, nullptr, hip_stream);
-}
-
-// host pointers in, host results out (svs::Flat::search through the C ABI): staging in stream order, one synchronisation at the end
-int svsx_flat_search(const svsx_index* ix, const void* queries, int q_dtype, size_t nq, size_t k, uint64_t* ids64, float* dists) {
-    if (int rc = check_search_args(ix, queries, q_dtype, nq, k, false)) return rc;
-    if (nq == 0) return SVSX_SUCCESS;
-    if (!ids64) return fail(SVSX_INVALID_ARGUMENT, "null argument");
-    HIP_TRY(hipSetDevice(ix->device));
-    CallStream cs;
-    HIP_TRY(cs.create());
-    StreamBuffer dq, di, dd;
-    const size_t q_bytes = nq * ix->d * dtype_size(q_dtype);
-    HIP_TRY(dq.alloc(q_bytes, cs.s));
-    HIP_TRY(di.alloc(nq * k * 8, cs.s));
-    HIP_TRY(dd.alloc(nq * k * 4, cs.s));
-    HIP_TRY(hipMemcpyAsync(dq.p, queries, q_bytes, hipMemcpyHostToDevice, cs.s));
-    if (int rc = svsx_flat_search_device_counted(ix, dq.p, q_dtype, nq, k, static_cast<uint64_t*>(di.p), static_cast<float*>(dd.p), nullptr, cs.s)) {
-        (void)hipStreamSynchronize(cs.s);
-        return rc;
-    }
-    HIP_TRY(hipMemcpyAsync(ids64, di.p, nq * k * 8, hipMemcpyDeviceToHost, cs.s));
-    if (dists) HIP_TRY(hipMemcpyAsync(dists, dd.p, nq * k * 4, hipMemcpyDeviceToHost, cs.s));
-    HIP_TRY(hipStreamSynchronize(cs.s));
-    return SVSX_SUCCESS;
-}
-
-int svsx_flat_search_device_counted(
-    const svsx_index* ix, const void* d_queries, int q_dtype, size_t nq, size_t k, uint64_t* d_ids64, float* d_dists, uint32_t* d_recomputed,
-    void* hip_stream
-) {
-    if (int rc = check_search_args(ix, d_queries, q_dtype, nq, k, false)) return rc;
-    if (nq == 0) return SVSX_SUCCESS;
-    if (!d_ids64) return fail(SVSX_INVALID_ARGUMENT, "null argument");
-    const int qmode = select_qmode(ix->metric, q_dtype, ix->data_dtype, ix->sq_enabled);
-    if (qmode < 0) return fail(SVSX_INVALID_ARGUMENT, "unsupported (query dtype %d, data dtype %d) pair", q_dtype, ix->data_dtype);
-    if (qmode == QM_SCALAR)
-        return fail(SVSX_NOT_IMPLEMENTED, "flat search serves the (query, data) type pairs with a SIMD kernel in the reference; (%d, %d) has the scalar loop only: graph search and svsx_distance_batch cover it", q_dtype, ix->data_dtype);
-    HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    // FlatIndex::search (index/flat/flat.h:322-460) bounds neither k nor the dimension.  The float16 pipeline below keeps k + 32 <= 256 shortlist
-    // entries per query (and, beyond d = 128, the 64 queries of a wave) in LDS; what does not fit it -- k > 224, or a dimension whose 64
-    // float16 queries plus k + 8 entries exceed 160 KB (d >= ~1 200) -- is answered by the exhaustive float32 pass alone: every query
-    // against every row with the reference-order routines and a k-entry list (stage 5 of the pipeline, exact by construction; one wave per
-    // query, so it is the slow path: 10 000 x 1 M x 96 takes ~1 s instead of 4 ms).
-    auto exhaustive_only = [&]() -> int {
-        const size_t lds = ((ix->d + 15) & ~size_t(15)) * 4 + k * 8;
-        if (lds > 160 * 1024) return fail(SVSX_INVALID_ARGUMENT, "flat search: k = %zu at d = %zu needs %zu bytes of LDS for one query's list (160 KB available)", k, ix->d, lds);
-        StreamBuffer redo;
-        HIP_TRY(redo.alloc(nq * 4, stream));
-        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(redo.p), 1, nq, stream));
-        FlatExactArgs xa;
-        memset(&xa, 0, sizeof(xa));
-        xa.r.data = ix->d_data; xa.r.row_bytes = ix->row_bytes; xa.r.d = static_cast<uint32_t>(ix->d); xa.r.sq_scale = ix->sq_scale; xa.r.sq_bias = ix->sq_bias;
-        xa.r.id_offset = ix->id_offset; xa.r.queries = d_queries; xa.r.q_row_bytes = ix->d * dtype_size(q_dtype); xa.r.q_dtype = q_dtype;
-        xa.r.nq = static_cast<uint32_t>(nq); xa.r.kk = static_cast<uint32_t>(k); xa.r.k = static_cast<uint32_t>(k);
-        xa.r.ids64 = d_ids64; xa.r.dists = d_dists;
-        xa.redo = static_cast<const uint32_t*>(redo.p); xa.n = static_cast<uint32_t>(ix->n);
-        hipError_t e = launch_flat_exact(ix->data_dtype, ix->metric, qmode, xa, stream);
-        if (e == hipSuccess && d_recomputed != nullptr) e = launch_add_word(d_recomputed, static_cast<uint32_t>(nq), stream);
-        if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "flat search launch failed: %s", hipGetErrorString(e));
-        return SVSX_SUCCESS;
-    };
-    if (k > 224) return exhaustive_only();
-    // rows of the float16 shadow: padded to 16 elements, between 129 and 768 dimensions to 128 (the threshold kernel for those takes the
-    // dimension in chunks of 128)
-    const uint32_t dpad = static_cast<uint32_t>(ix->d > 128 && ix->d <= 768 ? (ix->d + 127) & ~size_t(127) : (ix->d + 15) & ~size_t(15));
-    // shortlist length: max(4k, k + 32) up to 128 entries; beyond k = 96 (the reference's own ground-truth files hold 100 neighbours per
-    // query, data/test_dataset/groundtruth_*.ivecs) k + 32, the general insert path of the shortlist kernel, up to 256 entries
-    size_t kk = 4 * k > k + 32 ? 4 * k : k + 32;
-    if (kk > 128) kk = k + 32 > 128 ? k + 32 : 128;
-    if (kk > ix->n) kk = ix->n < k ? k : ix->n;
-    {   // the shortlist kernel keeps 64 shortlists (and, beyond d = 128, the 64 queries) of a wave in LDS; where that does not fit the
-        // shortlist shrinks towards k + 8 -- the answer stays exact, a shorter shortlist only makes the proof of stage 4 fail more often
-        const size_t fixed = (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0) + 256;
-        while (fixed + 64 * kk * 8 > 160 * 1024 && kk > k + 8) kk -= 4;
-        if (kk < k) kk = k;
-        const size_t need = fixed + 64 * kk * 8;
-        // (decided BEFORE the float16 shadow is built: the exhaustive pass never reads it, and at 1 M x 1 536 it would be 3 GB of HBM kept for the index's life -- ADVICE r5)
-        if (need > 160 * 1024) return exhaustive_only(); // the 64 float16 queries of a wave + its shortlists do not fit (d >= ~1 200, or a long list at a large d)
-    }
-    {   // float16 shadow of the database + squared norms, built once
-        std::lock_guard<std::mutex> lock(ix->shadow_mutex);
-        if (!ix->d_half) {
-            void* h = nullptr;
-            float* nrm = nullptr;
-            HIP_TRY(hipMalloc(&h, (ix->n + kShadowPadRows) * dpad * 2 + 64)); // padding: the threshold kernels load whole 32-row tiles / 128-row steps
-            if (hipMalloc(reinterpret_cast<void**>(&nrm), ix->n * 4) != hipSuccess) { (void)hipFree(h); return fail(SVSX_RUNTIME_ERROR, "hipMalloc failed"); }
-            // the padding tile is read (masked) by the last tile of the threshold kernel: zeros, not whatever the allocation held
-            hipError_t e = hipMemsetAsync(static_cast<unsigned char*>(h) + ix->n * static_cast<size_t>(dpad) * 2, 0, kShadowPadRows * static_cast<size_t>(dpad) * 2 + 64, stream);
-            if (e == hipSuccess)
-                e = launch_to_half(ix->data_dtype, ix->d_data, ix->row_bytes, static_cast<uint32_t>(ix->n), static_cast<uint32_t>(ix->d), dpad,
-                                   ix->sq_enabled, ix->sq_scale, ix->sq_bias, h, nrm, stream);
-            uint32_t* mm = nullptr; // {max, min} bits of the squared norms
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&mm), 8);
-            uint32_t range[2] = {0u, 0xFFFFFFFFu};
-            if (e == hipSuccess) e = hipMemcpyAsync(mm, range, 8, hipMemcpyHostToDevice, stream);
-            if (e == hipSuccess) e = launch_norm_range(nrm, static_cast<uint32_t>(ix->n), mm, stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(range, mm, 8, hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (mm) (void)hipFree(mm);
-            if (e != hipSuccess) { (void)hipFree(h); (void)hipFree(nrm); return fail(SVSX_RUNTIME_ERROR, "float16 shadow conversion failed: %s", hipGetErrorString(e)); }
-            memcpy(&ix->shadow_max2, &range[0], 4);
-            memcpy(&ix->shadow_min2, &range[1], 4);
-            ix->d_half = h;
-            ix->d_norm2 = nrm;
-        }
-    }
-    const size_t nqb = (nq + 63) / 64;
-    // one round of resident waves: LDS (64 shortlists of kk entries) bounds the waves per CU; a second round would
-    // double the time, more slices than needed only add shortlist inserts (measured: 14.1 ms at 80 % of the slots)
-    const size_t flat_lds = 64 * kk * 8 + 256 + (dpad > 128 ? 64 * (static_cast<size_t>(dpad) * 2 + 16) : 0); // shortlists + (beyond d = 128) the wave's 64 queries
-    size_t waves_per_cu = (160 * 1024) / flat_lds;
-    if (waves_per_cu > 8) waves_per_cu = 8;
-    if (waves_per_cu < 1) waves_per_cu = 1;
-    size_t target_waves = 256 * waves_per_cu * 4 / 5;
-    size_t slices = (target_waves + nqb - 1) / nqb; // thresholds are shared across the slices of a query block
-    if (slices > 64) slices = 64;
-    const size_t max_slices = (ix->n + 255) / 256;
-    if (slices > max_slices) slices = max_slices;
-    if (slices < 1) slices = 1;
-    const size_t q_stride = ix->d * dtype_size(q_dtype);
-    StreamBuffer bqh, bsk, bsi, bmk, bmi, bredo, bdist;
-    HIP_TRY(bredo.alloc(nq * 4, stream));
-    if (!d_dists) { // the proof needs the k-th exact distance
-        HIP_TRY(bdist.alloc(nq * k * 4, stream));
-        d_dists = static_cast<float*>(bdist.p);
-    }
-    HIP_TRY(bqh.alloc(nq * dpad * 2 + 64, stream));
-    HIP_TRY(bsk.alloc(slices * nq * kk * 4, stream));
-    HIP_TRY(bsi.alloc(slices * nq * kk * 8, stream));
-    HIP_TRY(bmk.alloc(nq * kk * 4, stream));
-    HIP_TRY(bmi.alloc(nq * kk * 8, stream));
-    void *qh = bqh.p, *sk = bsk.p, *si = bsi.p, *mk = bmk.p, *mi = bmi.p;
-    hipError_t e = launch_to_half(q_dtype, d_queries, q_stride, static_cast<uint32_t>(nq), static_cast<uint32_t>(ix->d), dpad, 0, 1.0f, 0.0f, qh, nullptr, stream);
-    FlatArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.xh = ix->d_half; fa.xnorm2 = ix->d_norm2; fa.n = static_cast<uint32_t>(ix->n); fa.dpad = dpad; fa.qh = qh;
-    fa.nq = static_cast<uint32_t>(nq); fa.kk = static_cast<uint32_t>(kk); fa.n_slices = static_cast<uint32_t>(slices);
-    fa.out_keys = static_cast<float*>(sk); fa.out_ids = static_cast<uint64_t*>(si);
-    fa.tile_step = 1;
-    StreamBuffer bgt;
-    HIP_TRY(bgt.alloc(nq * 4, stream));
-    fa.gtau = static_cast<uint32_t*>(bgt.p);
-    MergeArgs ma;
-    memset(&ma, 0, sizeof(ma));
-    ma.dists = static_cast<const float*>(sk); ma.ids = static_cast<const uint64_t*>(si);
-    ma.out_dists = static_cast<float*>(mk); ma.out_ids = static_cast<uint64_t*>(mi);
-    ma.n_shards = static_cast<uint32_t>(slices); ma.nq = static_cast<uint32_t>(nq); ma.k = static_cast<uint32_t>(kk);
-    RerankArgs ra;
-    memset(&ra, 0, sizeof(ra));
-    ra.data = ix->d_data; ra.row_bytes = ix->row_bytes; ra.d = static_cast<uint32_t>(ix->d); ra.sq_scale = ix->sq_scale; ra.sq_bias = ix->sq_bias;
-    ra.id_offset = ix->id_offset; ra.queries = d_queries; ra.q_row_bytes = q_stride; ra.q_dtype = q_dtype;
-    ra.nq = static_cast<uint32_t>(nq); ra.kk = static_cast<uint32_t>(kk); ra.k = static_cast<uint32_t>(k);
-    ra.cand_ids = static_cast<const uint64_t*>(mi); ra.ids64 = d_ids64; ra.dists = d_dists;
-    // Large sets with d <= 128 take the threshold pipeline (svsx_flat.hip stage 1b): nested strided samples of the 32-row
-    // tiles, every 16^j-th tile for j = L .. 1, each ~16x larger than the one before.  The smallest (>= 256 rows) is
-    // taken whole (threshold +inf); at every level the threshold kernel appends the rows at or below the current
-    // threshold (about 16 kk per query) and the select kernel takes the kk-th best key of that list as the next, tighter
-    // threshold -- which at least kk rows of the next level satisfy, because the samples are nested.  The last level is
-    // the full set; its lists (>= kk rows, ~16 kk expected) are re-ranked exactly.  Queries whose lists overflow
-    // (unrepresentative samples) are recomputed by the full shortlist kernel, gated per 64-query block.
-    FlatProofArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    pa.metric = ix->metric; pa.nq = ra.nq; pa.k = ra.k; pa.kk = ra.kk; pa.d = ra.d; pa.dpad = dpad;
-    pa.queries = d_queries; pa.q_row_bytes = q_stride; pa.q_dtype = q_dtype;
-    pa.sq_l2 = qmode == QM_SQ_L2 ? 1 : 0; pa.data_dtype = ix->data_dtype; pa.sq_scale = ix->sq_scale; pa.sq_bias = ix->sq_bias;
-    pa.out_ids = d_ids64; pa.out_dists = d_dists;
-    pa.short_keys = static_cast<const float*>(mk); pa.short_ids = static_cast<const uint64_t*>(mi);
-    pa.xmax2 = ix->shadow_max2; pa.xmin2 = ix->shadow_min2;
-    pa.redo = static_cast<uint32_t*>(bredo.p); pa.redo_count = d_recomputed;
-    bool thresh_path = flat_thresh_supports(dpad) && ix->n >= 65536 && nq <= 65536;
-#ifdef SVSX_DIAG
-    if (getenv("SVSX_FLAT_SHORTLIST_ONLY")) thresh_path = false; // A/B builds only
-#endif
-    StreamBuffer bcand, bkeys, bcnt, bgate, btau_a, btau_b;
-    if (thresh_path) {
-        // sampling unit: a 32-row tile (d > 128) or a 64- / 128-row step of the four-wave kernel (d <= 128)
-        const size_t unit = flat_thresh_unit_rows(dpad);
-        const size_t units = (ix->n + unit - 1) / unit;
-        uint32_t step = 1;
-        while ((units / (static_cast<size_t>(step) * 16)) * unit >= 128) step *= 16; // coarsest level: 128 ... 2 047 rows
-        size_t s2 = flat_thresh_slices(ix->metric, dpad, nq); // one generation of resident workgroups
-        if (s2 > ix->n / 4096) s2 = ix->n / 4096;
-        if (s2 < 1) s2 = 1;
-        const size_t lps = flat_thresh_lists_per_slice(dpad); // candidate lists per (query, slice)
-        if (s2 * lps > 1024) s2 = 1024 / lps;
-        const size_t lists = s2 * lps;
-        // rows per list: ~16 kk / lists expected at every level, at most the coarsest level's rows; 4x head room
-        size_t cap = 512;
-        // The thresholds are taken at rank kt < kk: with the proof of stage 4 behind it, the threshold pipeline needs no float16 safety margin
-        // in its candidate lists -- ~16 kt rows per query (224 for k = 10) are appended and re-ranked instead of ~16 kk (640), and whether
-        // that was enough is decided per query by the proof, not by the margin.  (The shortlist kernel keeps kk: its proof needs the gap
-        // between the k-th and the kk-th key.)
-        const size_t kt = SVSX_FLAT_KT(k, kk);
-        while (cap < 4 * (16 * kt / lists + 1)) cap *= 2;
-        const size_t coarse_rows = (units / step + 1) * unit; // all of them are appended at the first level
-        while (cap < 2 * coarse_rows / s2 && cap < 8192) cap *= 2;
-        HIP_TRY(bcand.alloc(nq * lists * cap * 4, stream));
-        HIP_TRY(bkeys.alloc(nq * lists * cap * 4, stream));
-        HIP_TRY(bcnt.alloc(nq * lists * 4, stream));
-        HIP_TRY(bgate.alloc(nqb * 4, stream));
-        HIP_TRY(btau_a.alloc(nq * 4, stream));
-        HIP_TRY(btau_b.alloc(nq * 4, stream));
-        float* tau_cur = static_cast<float*>(btau_a.p);
-        float* tau_nxt = static_cast<float*>(btau_b.p);
-        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tau_cur), 0x7F800000, nq, stream); // +inf
-        FlatThreshArgs ta;
-        memset(&ta, 0, sizeof(ta));
-        ta.xh = ix->d_half; ta.xnorm2 = ix->d_norm2; ta.n = static_cast<uint32_t>(ix->n); ta.dpad = dpad; ta.qh = qh;
-        ta.nq = static_cast<uint32_t>(nq);
-        ta.n_slices = static_cast<uint32_t>(s2);
-        ta.tau_stride = 1;
-        ta.cand = static_cast<uint32_t*>(bcand.p);
-        ta.cnt = static_cast<uint32_t*>(bcnt.p); ta.cap = static_cast<uint32_t>(cap);
-        for (; step > 1; step /= 16) {
-            ta.tile_step = step;
-            ta.tau = tau_cur;
-            ta.cand_keys = static_cast<float*>(bkeys.p);
-            if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
-            if (e == hipSuccess) e = launch_flat_select(ta.cand_keys, ta.cnt, ta.nq, static_cast<uint32_t>(lists), ta.cap, static_cast<uint32_t>(kt), tau_cur, 1, tau_nxt, stream);
-            float* t = tau_cur; tau_cur = tau_nxt; tau_nxt = t;
-        }
-        ta.tile_step = 1;
-        ta.tau = tau_cur;
-        ta.cand_keys = nullptr;
-        if (e == hipSuccess) e = launch_flat_thresh(ix->metric, ta, stream);
-        if (e == hipSuccess) e = launch_flat_gate_kk(ta.cnt, ta.nq, static_cast<uint32_t>(lists), ta.cap, static_cast<uint32_t>(kk), static_cast<uint32_t*>(bgate.p), stream);
-        // gated fallback: full shortlist pass and merge only for the query blocks that overflowed
-        fa.tile_step = 1;
-        fa.block_gate = static_cast<const uint32_t*>(bgate.p);
-        ma.gate64 = fa.block_gate;
-        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream);
-        if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
-        if (e == hipSuccess) e = launch_merge(M_L2, ma, stream);
-        ra.cand32 = ta.cand; ra.cnt = ta.cnt; ra.cap = ta.cap; ra.n_lists = static_cast<uint32_t>(lists);
-        if (e == hipSuccess) e = launch_rerank2(ix->data_dtype, ix->metric, qmode, ra, stream);
-        pa.tau = tau_cur; pa.cnt = ta.cnt; pa.cap = ta.cap; pa.n_lists = static_cast<uint32_t>(lists);
-        if (e == hipSuccess) e = launch_flat_certify(pa, stream);
-    } else {
-        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bgt.p), 0xFF800000, nq, stream); // +inf, order-encoded
-        if (e == hipSuccess) e = launch_flat_mfma(ix->metric, fa, stream);
-        if (e == hipSuccess) e = launch_merge(M_L2, ma, stream); // keys: smaller is better for every metric
-        if (e == hipSuccess) e = launch_rerank(ix->data_dtype, ix->metric, qmode, ra, stream);
-        if (e == hipSuccess) e = launch_flat_certify(pa, stream);
-    }
-    // the queries whose shortlist is not PROVEN to hold the exact answer are recomputed exhaustively in float32 (svsx_flat.hip stages 4, 5)
-    FlatExactArgs xa;
-    xa.r = ra; xa.redo = pa.redo; xa.n = static_cast<uint32_t>(ix->n);
-    if (e == hipSuccess) e = launch_flat_exact(ix->data_dtype, ix->metric, qmode, xa, stream);
-    if (e != hipSuccess) return fail(SVSX_RUNTIME_ERROR, "flat search launch failed: %s", hipGetErrorString(e));
     return SVSX_SUCCESS;
 }
 

@@ -248,12 +248,30 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     uint32_t fq[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
     [[maybe_unused]] int fat_qq = 0;
     [[maybe_unused]] float fat_eq = 0.0f, fat_tq_hi = 0.0f, fat_tq_lo = 0.0f, fat_s2m = 0.0f, fat_nuh = 0.0f, fat_nq = 0.0f;
+    [[maybe_unused]] const float fat_wunit = 1.0f / (a.sq_scale * a.sq_scale); // QM_SQ_L2: buffer distances -> code-space distances
     if constexpr (FAT) {
         constexpr int DC = FDC;
         const uint32_t ci = lane & 31u, half = lane >> 5; // lane -> coordinate ci (+ 32 per group), half of the element range
         const int hlen = dpad >> 1;                       // dpad is a multiple of 16 -> 8-float steps
         const float* qh = qf + half * hlen;
         const float* mh = a.pca_mean + half * hlen;
+        // eight consecutive query elements as float32.  The integer paths (int8 x int8 / uint8 x uint8 rows, and the scalar-quantized L2 distance,
+        // which is taken between CODED query and coded rows, scalar.h:58-105) keep the query as bytes: the records of such an index are built over
+        // float(row element) -- code space for scalar-quantized L2 -- so the query's image is float(query byte), exactly
+        auto q8 = [&](const int j0, float4& v0, float4& v1) {
+            if constexpr (INTPATH) {
+                const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(qw) + half * hlen + j0);
+                auto el = [](uint32_t word, int t) -> float {
+                    if constexpr (DT == DT_I8) return static_cast<float>(static_cast<int>(static_cast<int8_t>((word >> (8 * t)) & 0xFFu)));
+                    else return static_cast<float>((word >> (8 * t)) & 0xFFu);
+                };
+                v0 = make_float4(el(w.x, 0), el(w.x, 1), el(w.x, 2), el(w.x, 3));
+                v1 = make_float4(el(w.y, 0), el(w.y, 1), el(w.y, 2), el(w.y, 3));
+            } else {
+                v0 = *reinterpret_cast<const float4*>(qh + j0);
+                v1 = *reinterpret_cast<const float4*>(qh + j0 + 4);
+            }
+        };
         float r2 = 0.0f, un2 = 0.0f, vv = 0.0f;
         int qq = 0;
         if (lane < 32u) qcodes[lane] = 0u;
@@ -265,7 +283,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
 #pragma unroll 1
             for (int j0 = 0; j0 < hlen; j0 += 8) { // rolled: the projection must not raise the kernel's register peak
                 const float4 p0 = prow[j0 >> 2], p1 = prow[(j0 >> 2) + 1];
-                float4 v0 = *reinterpret_cast<const float4*>(qh + j0), v1 = *reinterpret_cast<const float4*>(qh + j0 + 4);
+                float4 v0, v1;
+                q8(j0, v0, v1);
                 if constexpr (METRIC == M_L2) {
                     const float4 m0 = *reinterpret_cast<const float4*>(mh + j0), m1 = *reinterpret_cast<const float4*>(mh + j0 + 4);
                     v0.x -= m0.x; v0.y -= m0.y; v0.z -= m0.z; v0.w -= m0.w;
@@ -594,7 +613,9 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     if constexpr (METRIC == M_L2) {
                         // A = max(0, s sqrt(I) - e), e = eq + ex;  B = max(0, |tq - tx| - slack):  dist >= A^2 + B^2.  Reject iff
                         // A^2 + B^2 > W' := worst * 1.0001, implied by  s^2 I > W' - B^2 + e (2 sqrt(W') + e)  (one square root per hop)
-                        const float wp = worst * 1.0001f;
+                        // (scalar-quantized L2: the buffer holds scale^2 * I, scalar.h:88-94, the records live in code space: worst / fl(scale^2), two
+                        // more roundings under the 1e-4 margin; a scale whose square under- or overflows gives inf or NaN and the bound never fires)
+                        const float wp = (QMODE == QM_SQ_L2 ? worst * fat_wunit : worst) * 1.0001f;
                         const float r2 = 2.0f * __builtin_amdgcn_sqrtf(wp) * 1.00001f;
                         uint32_t dqx = 0u, dxx = 0u;
 #pragma unroll
@@ -1052,6 +1073,16 @@ template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const Sear
         if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
     }
     if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && (DT == DT_I8 || DT == DT_U8)) {
+        if (a.fat != nullptr && a.fat_rb == 32 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 32) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 64 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 3>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 64) return launch_one<DT, METRIC, QMODE, 0, false, 3>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 128 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 4>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
+    }
+    if constexpr ((QMODE == QM_INT || QMODE == QM_SQ_L2) && (DT == DT_I8 || DT == DT_U8)) {
+        // round 6: the exact integer paths (VNNI pairs euclidean.h:265-313, inner_product.h:222-267, cosine.h:261-326; EuclideanCompressed
+        // scalar.h:58-105) behind inline records built over float(row element)
         if (a.fat != nullptr && a.fat_rb == 32 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 2>(a, stream);
         if (a.fat != nullptr && a.fat_rb == 32) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
         if (a.fat != nullptr && a.fat_rb == 64 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 3>(a, stream);

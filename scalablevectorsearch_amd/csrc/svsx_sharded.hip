@@ -91,6 +91,11 @@ struct svsx_sharded {
     hipEvent_t ev_start = nullptr, ev_join[2] = {nullptr, nullptr}, ev_ready[kMaxChunks] = {nullptr, nullptr}, ev_done[kMaxChunks] = {nullptr, nullptr};
     hipEvent_t ev_last = nullptr;              // end of the previous call (staging reuse across streams)
     bool have_last = false;
+    // optional phase timing of the last call (svsx_sharded_set_timing / _phase_times): per chunk, events at search start, searches done,
+    // local merge done, all-gather done, world merge done -- recorded only while enabled
+    bool timing = false, timed_exchange = false;
+    int timed_chunks = 0;
+    hipEvent_t tev[kMaxChunks][5] = {};
 };
 
 namespace {
@@ -196,6 +201,7 @@ void svsx_sharded_destroy(svsx_sharded* s) {
     if (s->d_recv) (void)hipFree(s->d_recv);
     for (hipStream_t st : s->side) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : {s->ev_start, s->ev_join[0], s->ev_join[1], s->ev_ready[0], s->ev_ready[1], s->ev_done[0], s->ev_done[1], s->ev_last}) if (e) (void)hipEventDestroy(e);
+    for (auto& row : s->tev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -205,6 +211,96 @@ int svsx_sharded_info(const svsx_sharded* s, uint64_t info[4]) {
     info[1] = static_cast<uint64_t>(s->world);
     info[2] = static_cast<uint64_t>(s->rank);
     info[3] = s->comm ? 1u : 0u;
+    return SVSX_SUCCESS;
+}
+
+// ---- the pipeline as DATA: svsx_sharded_plan lists, in enqueue order, every operation a call puts on its three streams (0 = the caller's,
+// 1 / 2 = the internal ones) -- searches, merges, the all-gather, event records and waits -- and svsx_sharded_search_device executes exactly that
+// list.  A pure host function: tests/test_sharded_plan.py replays the list through a happens-before model (every read after its write, the
+// second chunk's searches NOT ordered behind the first chunk's exchange, the caller's stream joined at the end, calls chained through
+// ev_last) without a GPU -- the part of the N > 1 path that a one-GPU box cannot time is at least checked for order.
+int svsx_sharded_plan(size_t n_local, int exchange, size_t nq, int have_last, svsx_sharded_op* ops, size_t cap, size_t* n_ops) {
+    if (!n_ops || n_local == 0 || nq == 0) return svsx::set_error(SVSX_INVALID_ARGUMENT, "null / empty argument");
+    size_t n = 0;
+    auto put = [&](int kind, int stream, int chunk, int arg) {
+        if (ops && n < cap) ops[n] = svsx_sharded_op{kind, stream, chunk, arg};
+        ++n;
+    };
+    const bool fan_out = n_local > 1;
+    const int nchunk = (exchange && nq >= 8192) ? 2 : 1; // the exchange + world merge of chunk c runs under the searches of chunk c + 1
+    // the staging may still be in use by the previous call (made on another stream): chain behind it
+    if (have_last) put(SVSX_OP_WAIT, 0, -1, SVSX_EV_LAST);
+    if (fan_out || nchunk > 1) {
+        put(SVSX_OP_RECORD, 0, -1, SVSX_EV_START);
+        put(SVSX_OP_WAIT, 1, -1, SVSX_EV_START);
+        put(SVSX_OP_WAIT, 2, -1, SVSX_EV_START);
+    }
+    for (int c = 0; c < nchunk; ++c) {
+        if (!fan_out) {
+            put(SVSX_OP_STAMP, 0, c, 0);
+            put(SVSX_OP_SEARCH, 0, c, 0);
+            put(SVSX_OP_STAMP, 0, c, 1);
+            put(SVSX_OP_STAMP, 0, c, 2); // no local merge: an empty phase
+        } else {
+            put(SVSX_OP_STAMP, 1, c, 0);
+            for (size_t i = 0; i < n_local; ++i) put(SVSX_OP_SEARCH, 1 + static_cast<int>(i & 1), c, static_cast<int>(i));
+            for (int j = 0; j < 2; ++j) {
+                put(SVSX_OP_RECORD, 1 + j, c, SVSX_EV_JOIN0 + j);
+                put(SVSX_OP_WAIT, 0, c, SVSX_EV_JOIN0 + j);
+            }
+            put(SVSX_OP_STAMP, 0, c, 1);
+            put(SVSX_OP_LOCAL_MERGE, 0, c, 0);
+            put(SVSX_OP_STAMP, 0, c, 2);
+        }
+        if (!exchange) continue;
+        // exchange + world-way merge.  One local shard, two chunks: on an internal stream, so that the caller's stream goes straight on to the
+        // search of the next chunk.  With local fan-out the searches already run on the internal streams (the next chunk's are not held up
+        // by anything queued here), so the exchange stays on the caller's stream.
+        int xs = 0;
+        if (nchunk > 1 && !fan_out) {
+            xs = 1;
+            put(SVSX_OP_RECORD, 0, c, SVSX_EV_READY0 + c);
+            put(SVSX_OP_WAIT, xs, c, SVSX_EV_READY0 + c);
+        }
+        put(SVSX_OP_ALLGATHER, xs, c, 0);
+        put(SVSX_OP_STAMP, xs, c, 3);
+        put(SVSX_OP_WORLD_MERGE, xs, c, 0);
+        put(SVSX_OP_STAMP, xs, c, 4);
+        if (xs != 0) put(SVSX_OP_RECORD, xs, c, SVSX_EV_DONE0 + c);
+    }
+    if (exchange && nchunk > 1 && !fan_out) // the caller's stream joins the exchanges only now: every search is already queued in front
+        for (int c = 0; c < nchunk; ++c) put(SVSX_OP_WAIT, 0, c, SVSX_EV_DONE0 + c);
+    put(SVSX_OP_RECORD, 0, -1, SVSX_EV_LAST);
+    *n_ops = n;
+    if (ops && n > cap) return svsx::set_error(SVSX_INVALID_ARGUMENT, "the plan has %zu operations, room for %zu", n, cap);
+    return SVSX_SUCCESS;
+}
+
+int svsx_sharded_set_timing(svsx_sharded* s, int enabled) {
+    if (!s) return svsx::set_error(SVSX_NOT_INITIALIZED, "Index not initialized");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->timing = enabled != 0;
+    s->timed_chunks = 0;
+    return SVSX_SUCCESS;
+}
+
+int svsx_sharded_phase_times(svsx_sharded* s, float ms[5]) {
+    if (!s || !ms) return svsx::set_error(SVSX_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->timing || s->timed_chunks == 0 || !s->have_last) return svsx::set_error(SVSX_INVALID_ARGUMENT, "no timed call to report: svsx_sharded_set_timing(s, 1), then search");
+    if (hipSetDevice(s->device) != hipSuccess || hipEventSynchronize(s->ev_last) != hipSuccess) return svsx::set_error(SVSX_RUNTIME_ERROR, "the timed call did not complete");
+    for (int i = 0; i < 5; ++i) ms[i] = 0.0f;
+    for (int c = 0; c < s->timed_chunks; ++c) {
+        for (int ph = 0; ph < 4; ++ph) {
+            if (ph >= 2 && !s->timed_exchange) break;
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, s->tev[c][ph], s->tev[c][ph + 1]) != hipSuccess) return svsx::set_error(SVSX_RUNTIME_ERROR, "hipEventElapsedTime failed");
+            ms[ph] += t;
+        }
+    }
+    float span = 0.0f;
+    if (hipEventElapsedTime(&span, s->tev[0][0], s->tev[s->timed_chunks - 1][s->timed_exchange ? 4 : 2]) != hipSuccess) return svsx::set_error(SVSX_RUNTIME_ERROR, "hipEventElapsedTime failed");
+    ms[4] = span;
     return SVSX_SUCCESS;
 }
 
@@ -225,8 +321,7 @@ int svsx_sharded_search_device(
     const size_t n_local = s->shards.size();
     const bool exchange = s->world > 1 || s->comm != nullptr;
     const size_t q_row = s->d * esize[q_dtype];
-    // chunks of the batch: the exchange + world merge of chunk c runs under the searches of chunk c + 1
-    const int nchunk = (exchange && nq >= 8192) ? 2 : 1;
+    const int nchunk = (exchange && nq >= 8192) ? 2 : 1; // (the same rule as svsx_sharded_plan)
     size_t lo[kMaxChunks + 1], slot[kMaxChunks], off[kMaxChunks + 1];
     off[0] = 0;
     for (int c = 0; c < nchunk; ++c) {
@@ -242,6 +337,9 @@ int svsx_sharded_search_device(
     }
     if (n_local > 1)
         if (int rc = grow(s, s->d_local, s->local_cap, all * n_local)) return rc;
+    std::vector<svsx_sharded_op> plan(64 + 4 * n_local);
+    size_t n_ops = 0;
+    if (int rc = svsx_sharded_plan(n_local, exchange ? 1 : 0, nq, s->have_last ? 1 : 0, plan.data(), plan.size(), &n_ops)) return rc;
 #define SH_TRY(expr)                                                                                                         \
     do {                                                                                                                     \
         hipError_t e_ = (expr);                                                                                              \
@@ -261,15 +359,18 @@ int svsx_sharded_search_device(
             s->have_last = false;
         }
     } drain{s, stream};
-    // the staging may still be in use by the previous call (made on another stream): chain behind it
-    if (s->have_last) SH_TRY(hipStreamWaitEvent(stream, s->ev_last, 0));
-    const bool fan_out = n_local > 1;
-    if (fan_out || nchunk > 1) {
-        SH_TRY(hipEventRecord(s->ev_start, stream));
-        for (hipStream_t st : s->side) SH_TRY(hipStreamWaitEvent(st, s->ev_start, 0));
+    if (s->timing) {
+        for (int c = 0; c < nchunk; ++c)
+            for (hipEvent_t& e : s->tev[c])
+                if (!e) SH_TRY(hipEventCreate(&e));
     }
+    hipStream_t streams[3] = {stream, s->side[0], s->side[1]};
+    hipEvent_t events[8] = {s->ev_start, s->ev_join[0], s->ev_join[1], s->ev_ready[0], s->ev_ready[1], s->ev_done[0], s->ev_done[1], s->ev_last};
     Rccl& r = rccl();
-    for (int c = 0; c < nchunk; ++c) {
+    for (size_t oi = 0; oi < n_ops; ++oi) {
+        const svsx_sharded_op& op = plan[oi];
+        hipStream_t st = streams[op.stream];
+        const int c = op.chunk < 0 ? 0 : op.chunk;
         const size_t rows = lo[c + 1] - lo[c], m = rows * k;
         const unsigned char* q = static_cast<const unsigned char*>(d_queries) + lo[c] * q_row;
         auto ids_of = [&](void* base, size_t region_slots, size_t i) {  // slot i of chunk c in a staging buffer holding `region_slots` slots per chunk
@@ -279,38 +380,38 @@ int svsx_sharded_search_device(
         // where this rank's merged list of the chunk goes: the send slot when an exchange follows, else straight to the caller's rows
         uint64_t* own_i = exchange ? ids_of(s->d_send, 1, 0) : d_ids64 + lo[c] * k;
         float* own_d = exchange ? dist_of(s->d_send, 1, 0) : d_dists + lo[c] * k;
-        if (!fan_out) {
-            if (int rc = svsx_search_device(s->shards[0], q, q_dtype, rows, k, params, own_i, nullptr, own_d, nullptr, stream)) return rc;
-        } else {
-            for (size_t i = 0; i < n_local; ++i)
-                if (int rc = svsx_search_device(s->shards[i], q, q_dtype, rows, k, params, ids_of(s->d_local, n_local, i), nullptr, dist_of(s->d_local, n_local, i), nullptr, s->side[i & 1])) return rc;
-            for (int j = 0; j < 2; ++j) {
-                SH_TRY(hipEventRecord(s->ev_join[j], s->side[j]));
-                SH_TRY(hipStreamWaitEvent(stream, s->ev_join[j], 0));
+        switch (op.kind) {
+            case SVSX_OP_WAIT: SH_TRY(hipStreamWaitEvent(st, events[op.arg], 0)); break;
+            case SVSX_OP_RECORD: SH_TRY(hipEventRecord(events[op.arg], st)); break;
+            case SVSX_OP_STAMP:
+                if (s->timing) SH_TRY(hipEventRecord(s->tev[c][op.arg], st));
+                break;
+            case SVSX_OP_SEARCH: {
+                const size_t i = static_cast<size_t>(op.arg);
+                uint64_t* oi_ = n_local > 1 ? ids_of(s->d_local, n_local, i) : own_i;
+                float* od_ = n_local > 1 ? dist_of(s->d_local, n_local, i) : own_d;
+                if (int rc = svsx_search_device(s->shards[i], q, q_dtype, rows, k, params, oi_, nullptr, od_, nullptr, st)) return rc;
+                break;
             }
-            if (int rc = svsx_merge_topk_strided_device(s->metric, n_local, rows, k, dist_of(s->d_local, n_local, 0), slot[c] / 4, ids_of(s->d_local, n_local, 0), slot[c] / 8, own_d, own_i, stream)) return rc;
+            case SVSX_OP_LOCAL_MERGE:
+                if (int rc = svsx_merge_topk_strided_device(s->metric, n_local, rows, k, dist_of(s->d_local, n_local, 0), slot[c] / 4, ids_of(s->d_local, n_local, 0), slot[c] / 8, own_d, own_i, st)) return rc;
+                break;
+            case SVSX_OP_ALLGATHER: {
+                const int rc = r.AllGather(ids_of(s->d_send, 1, 0), ids_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c], kNcclChar, s->comm, st);
+                if (rc != 0) return svsx::set_error(SVSX_RUNTIME_ERROR, "ncclAllGather failed: %s", r.GetErrorString(rc));
+                break;
+            }
+            case SVSX_OP_WORLD_MERGE:
+                if (int rc2 = svsx_merge_topk_strided_device(s->metric, static_cast<size_t>(s->world), rows, k, dist_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c] / 4,
+                                                             ids_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c] / 8, d_dists + lo[c] * k, d_ids64 + lo[c] * k, st))
+                    return rc2;
+                break;
+            default: return svsx::set_error(SVSX_RUNTIME_ERROR, "unknown operation %d in the sharded plan", op.kind);
         }
-        if (!exchange) continue;
-        // exchange + world-way merge.  One local shard, two chunks: on an internal stream, so that the caller's stream goes straight on to the
-        // search of the next chunk.  With local fan-out the searches already run on the internal streams (the next chunk's are not held up
-        // by anything queued here), so the exchange stays on the caller's stream.
-        hipStream_t xs = stream;
-        if (nchunk > 1 && !fan_out) {
-            xs = s->side[0];
-            SH_TRY(hipEventRecord(s->ev_ready[c], stream));
-            SH_TRY(hipStreamWaitEvent(xs, s->ev_ready[c], 0));
-        }
-        const int rc = r.AllGather(ids_of(s->d_send, 1, 0), ids_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c], kNcclChar, s->comm, xs);
-        if (rc != 0) return svsx::set_error(SVSX_RUNTIME_ERROR, "ncclAllGather failed: %s", r.GetErrorString(rc));
-        if (int rc2 = svsx_merge_topk_strided_device(s->metric, static_cast<size_t>(s->world), rows, k, dist_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c] / 4,
-                                                     ids_of(s->d_recv, static_cast<size_t>(s->world), 0), slot[c] / 8, d_dists + lo[c] * k, d_ids64 + lo[c] * k, xs))
-            return rc2;
-        if (xs != stream) SH_TRY(hipEventRecord(s->ev_done[c], xs));
     }
-    if (exchange && nchunk > 1 && !fan_out) // the caller's stream joins the exchanges only now: every search is already queued in front
-        for (int c = 0; c < nchunk; ++c) SH_TRY(hipStreamWaitEvent(stream, s->ev_done[c], 0));
-    SH_TRY(hipEventRecord(s->ev_last, stream));
     s->have_last = true;
+    s->timed_chunks = s->timing ? nchunk : 0;
+    s->timed_exchange = exchange;
     drain.ok = true;
 #undef SH_TRY
     return SVSX_SUCCESS;

@@ -207,6 +207,13 @@ class VamanaIndex:
         _lib.check(_lib.lib().svsx_index_info(self._h, arr))
         return dict(n=arr[0], d=arr[1], data_bytes=arr[2], graph_bytes=arr[3], graph_row_stride=arr[4], data_row_bytes=arr[5])
 
+    def memory(self) -> dict:
+        """svsx_index_memory: the HBM the index holds (bytes) and the bound scheme in effect"""
+        m = (C.c_uint64 * 10)()
+        _lib.check(_lib.lib().svsx_index_memory(self._h, m))
+        return dict(data_bytes=m[0], graph_bytes=m[1], inline_record_bytes=m[2], record_size=m[3], code_row_bytes=m[4], flat_shadow_bytes=m[5],
+                    sq_row_norm_bytes=m[6], allocated_by_library=m[7], bound_mode=m[8], owns_rows_and_graph=bool(m[9]))
+
     # -- search ---------------------------------------------------------------------------------------------------
     def search(self, queries, num_neighbors: int, search_parameters: VamanaSearchParameters | None = None, stats: bool = False):
         """Batch search with host arrays (svs.Vamana.search(queries, k) -> (ids, distances))."""
@@ -247,11 +254,19 @@ class VamanaIndex:
                                                       bitmap.ctypes.data, float(filter_stop), int(bool(filter_estimate_batch)), ids.ctypes.data, dists.ctypes.data))
         return QueryResult(ids, dists)
 
-    def build_bound_codes(self, mode: int | bool = 1) -> None:
+    def build_bound_codes(self, mode: int | bool = 1) -> int:
         """svsx_index_build_bound_codes: result-neutral bound rejection.  mode 2: graph-inline records per neighbour, size chosen from the
-        data's spectrum (float32 / float16 rows, any metric; SQ rows under IP / cosine; 32 <= d <= 4096); 32 / 64 / 128: the same with that
-        record size; mode 1 (True): 128-byte code row per vector (float rows, L2, d = 96 / 128); 0 (False): off."""
-        _lib.check(_lib.lib().svsx_index_build_bound_codes(self._h, int(mode)))
+        data's spectrum (float32 / float16 rows, scalar-quantized rows, raw int8 / uint8 rows; any metric; 32 <= d <= 4096); 32 / 64 / 128: the
+        same with that record size; mode 1 (True): 128-byte code row per vector (float rows, L2, d = 96 / 128); 0 (False): off.
+        Returns the scheme in effect (0 / 1 / 2): records that do not fit the free HBM shrink or fall back with a RuntimeWarning, not an error."""
+        rc = _lib.lib().svsx_index_build_bound_codes(self._h, int(mode))
+        if rc == _lib.FELL_BACK:  # not a failure: a smaller scheme than asked for was built (the one asked for does not fit the free HBM)
+            import warnings
+
+            warnings.warn(_lib.lib().svsx_last_error().decode(), RuntimeWarning, stacklevel=2)
+        else:
+            _lib.check(rc)
+        return self.memory()["bound_mode"]
 
     def last_kernel_info(self) -> str:
         """svsx_last_kernel_info: which search-kernel instantiation the last search on this thread launched."""
@@ -348,7 +363,7 @@ class FlatIndex:
         self._h = C.c_void_p()
         _lib.check(_lib.lib().svsx_index_create(C.byref(desc), C.byref(self._h)))
         self.device = device
-        self.id_offset = int(id_offset)
+        self.id_offset = 0
         self.n, self.d = data.shape
 
     __del__ = VamanaIndex.__del__

@@ -201,12 +201,16 @@ class Query:
         self.rec = rec
 
 
-def rejected(qs: Query, worst):
-    """the lane-parallel bound of the main loop (svsx_search_kernel.h, `if (full)` block) for every record against ONE threshold per record"""
+def rejected(qs: Query, worst, wunit=None):
+    """the lane-parallel bound of the main loop (svsx_search_kernel.h, `if (full)` block) for every record against ONE threshold per record.
+    wunit: scalar-quantized L2 only -- fl(1 / fl(scale * scale)), the factor that takes a buffer distance (scale^2 * I, scalar.h:88-94) to the
+    code space the records of such an index live in"""
     rec = qs.rec
     worst = np.asarray(worst, f32)
     with np.errstate(all="ignore"):
         if rec.metric == L2:
+            if wunit is not None:
+                worst = (worst * f32(wunit)).astype(f32)
             wp = (worst * f32(1.0001)).astype(f32)
             # v_sqrt_f32 is accurate to 1 ulp: take the correctly rounded root and the two neighbours, the bound must hold for each
             out = np.zeros(worst.shape, bool)
@@ -336,3 +340,91 @@ def test_record_bound_scalar_quantized_rows(oracle, metric, rb):
         exact[qi, ids[qi].astype(np.int64)] = dists[qi]
     fired, total = _check(oracle, metric, exact, q, rb, "sq", sq=(codes, sc, bias))
     assert fired > 0
+
+
+# ---- round 6: records over integer rows (raw int8 / uint8 rows searched with queries of the same type; the scalar-quantized L2 distance) -----
+def _int_sets(d, dt):
+    rng = np.random.default_rng(d + (7 if dt == np.int8 else 0))
+    lo, hi = (-128, 127) if dt == np.int8 else (0, 255)
+    off = 0 if dt == np.int8 else 128
+
+    def quant(a, gain):
+        return np.clip(np.round(a * gain + off), lo, hi).astype(dt)
+
+    xf = deep_like(300, d, min(24, d // 2), seed=31, normalize=False)
+    g = 100.0 / float(np.abs(xf).max())
+    yield "deep-like", quant(xf, g), quant(deep_like(16, d, min(24, d // 2), seed=32, normalize=False), g)
+    yield "small values", quant(xf, g * 0.03), quant(deep_like(8, d, min(24, d // 2), seed=33, normalize=False), g * 0.03)
+    xs = quant(xf, g * 4.0)  # most elements saturate
+    yield "saturated", xs, np.concatenate([xs[:6], np.full((1, d), hi, dt), np.full((1, d), lo, dt)])
+    xc = quant(xf, g)
+    xc[::9] = 7      # constant rows
+    xc[::13] = 0     # zero rows: NaN under cosine (never bounded)
+    xc[5] = xc[4]    # duplicates
+    yield "constant, zero and duplicated rows", xc, np.concatenate([np.zeros((1, d), dt), np.full((1, d), 3, dt), xc[:6]])
+    yield "uniform noise", rng.integers(lo, hi + 1, (300, d)).astype(dt), rng.integers(lo, hi + 1, (8, d)).astype(dt)
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("dt", [np.int8, np.uint8])
+@pytest.mark.parametrize("d,rb", [(96, 32), (768, 64), (768, 128)])
+def test_record_bound_integer_rows(oracle, metric, dt, d, rb):
+    """int8 x int8 / uint8 x uint8: the reference's values are exact int32 sums narrowed to float32 (euclidean.h:265-313, inner_product.h:222-267)
+    and, under cosine, float(sum ab) / (||a|| sqrt(float(sum bb))) (cosine.h:261-326); the records are built over float(row element) and the
+    query's image is float(query element) -- both exact"""
+    fired_deep = 0
+    for name, x, q in _int_sets(d, dt):
+        exact = oracle.distance_batch(metric, q, x)
+        rec = Records(x.astype(f32), metric, rb)
+        fired = 0
+        for qi in range(q.shape[0]):
+            qs = Query(rec, q[qi].astype(f32))
+            own = rejected(qs, exact[qi])
+            assert not own.any(), (name, metric, rb, qi, np.nonzero(own)[0][:5])
+            with np.errstate(all="ignore"):
+                if metric == L2:
+                    far = rejected(qs, (exact[qi] * f32(0.25)).astype(f32))
+                else:
+                    far = rejected(qs, (exact[qi] + np.abs(exact[qi]) + f32(0.5) * np.abs(exact[qi]).max()).astype(f32))
+            fired += int(far.sum())
+        if name == "deep-like":
+            fired_deep = fired
+            assert fired > 0.5 * q.shape[0] * x.shape[0], (fired, q.shape[0] * x.shape[0])
+    assert fired_deep > 0
+
+
+def _sq_compress_query(q, scale, bias, dt):
+    """detail::compress (scalar.h:37-42): clamp(std::round((v - bias) / scale)) in float32, half away from zero"""
+    t = ((np.asarray(q, f32) - f32(bias)).astype(f32) / f32(scale)).astype(f32).astype(f64)
+    r = np.trunc(t + np.copysign(0.5, t))
+    lo, hi = (-128, 127) if dt == np.int8 else (0, 255)
+    return np.clip(r, lo, hi).astype(dt)
+
+
+@pytest.mark.parametrize("rb", [32, 64, 128])
+@pytest.mark.parametrize("code", [2, 3])
+def test_record_bound_scalar_quantized_l2(oracle, rb, code):
+    """EuclideanCompressed (scalar.h:58-105): distance = fl(scale * scale) * float(sum (cq - cx)^2) between the CODED query and the coded row; the
+    records live in code space and the kernel takes the buffer's worst distance there with one multiplication (fat_wunit)"""
+    d = 768
+    dt = np.int8 if code == 2 else np.uint8
+    for seed, gain, shift in ((41, 1.0, 0.0), (43, 1e-3, 5.0), (45, 300.0, -1e4)):
+        xf = (deep_like(200, d, 32, seed=seed, normalize=False) * f32(gain) + f32(shift)).astype(f32)
+        q = (deep_like(6, d, 32, seed=seed + 1, normalize=False) * f32(gain) + f32(shift)).astype(f32)
+        q[0] = xf[3]
+        q[1] = q[1] * f32(50.0)  # far outside the coded range: clamped query codes
+        codes, sc, bias = oracle.sq_compress(xf, code)
+        assert codes.dtype == dt
+        ids, dists = oracle.flat_search(L2, codes, q, xf.shape[0], sq=(sc, bias))
+        exact = np.empty((q.shape[0], xf.shape[0]), f32)
+        for qi in range(q.shape[0]):
+            exact[qi, ids[qi].astype(np.int64)] = dists[qi]
+        rec = Records(codes.astype(f32), L2, rb)
+        wunit = f32(1.0) / f32(f32(sc) * f32(sc))
+        fired = 0
+        for qi in range(q.shape[0]):
+            qs = Query(rec, _sq_compress_query(q[qi], sc, bias, dt).astype(f32))
+            own = rejected(qs, exact[qi], wunit)
+            assert not own.any(), (seed, rb, qi, np.nonzero(own)[0][:5])
+            fired += int(rejected(qs, (exact[qi] * f32(0.25)).astype(f32), wunit).sum())
+        assert fired > 0

@@ -156,16 +156,12 @@ def test_bound_codes_scope(svs, oracle, small_world, mode):
         idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceIP(), sw["entry"])
         with pytest.raises(svs.SvsxError):
             idx.build_bound_codes(mode)
-    else:          # inline records: not for raw int8 rows, nor for the compressed L2 distance
-        raw = np.clip(np.round(sw["x"] * 400), -128, 127).astype(np.int8)
-        idx = svs.VamanaIndex(sw["graph"], raw, svs.DistanceIP(), sw["entry"])
+    else:          # inline records: since round 6 also over raw int8 rows and under the compressed L2 distance (tests below); an index without
+        # a graph, or of fewer than 32 dimensions, is still refused
+        idx = svs.VamanaIndex(sw["graph"], sw["x"][:, :24].copy(), svs.DistanceL2(), sw["entry"])
         with pytest.raises(svs.SvsxError) as e:
             idx.build_bound_codes(mode)
         assert e.value.code == 3
-        codes, sc, bias = oracle.sq_compress(sw["x"], 2)
-        idx = svs.VamanaIndex(sw["graph"], codes, svs.DistanceL2(), sw["entry"], sq=(sc, bias))
-        with pytest.raises(svs.SvsxError):
-            idx.build_bound_codes(mode)
     bad = sw["x"].copy()
     bad[3, 5] = np.inf
     idx = svs.VamanaIndex(sw["graph"], bad, svs.DistanceL2(), sw["entry"])
@@ -197,10 +193,10 @@ def _u64(ids):
 def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24, inline=False):
     codes, sc, bias = oracle.sq_compress(x, code_dtype)
     g, e = oracle.build_vamana(metric, x, R=R, L=40)
-    fn = svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
+    fn = svs.DistanceL2() if metric == L2 else svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
     idx = svs.VamanaIndex(g, codes, fn, e, sq=(sc, bias))
     with pytest.raises(svs.SvsxError):
-        idx.build_bound_codes(1)  # 128-byte rows are an L2 / float-row scheme
+        idx.build_bound_codes(1)  # 128-byte rows are a float-row scheme
     if inline:
         idx.build_bound_codes(2)  # graph-inline records: upper bound of the similarity from 26 signed codes
     rej = 0
@@ -217,7 +213,7 @@ def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24, inline=False
 
 
 @pytest.mark.parametrize("inline", [False, True])
-@pytest.mark.parametrize("metric", [IP, COS])
+@pytest.mark.parametrize("metric", [L2, IP, COS])
 @pytest.mark.parametrize("code_dtype", [I8, U8])
 def test_sq_parity_d768_and_ragged(svs, oracle, metric, code_dtype, inline):
     x = deep_like(1500, 768, 32, seed=61, normalize=False)
@@ -303,3 +299,135 @@ def test_sq_parity_fuzz(svs, oracle, seed, inline):
     metric = IP if seed % 2 == 0 else COS
     code_dtype = I8 if seed % 3 else U8
     _check_sq(svs, oracle, metric, x, q, code_dtype, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], inline=inline)
+    if inline:  # EuclideanCompressed (scalar.h:58-105) behind records in code space (round 6), same adversarial sets
+        _check_sq(svs, oracle, L2, x, q, code_dtype, [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0)], inline=True)
+
+
+# ---- raw int8 / uint8 rows with queries of the same type: the exact integer paths (VNNI pairs: euclidean.h:265-313, inner_product.h:222-267,
+# cosine.h:261-326) behind inline records built over float(row element) (round 6) -----------------------------------------------------------
+def _to_int(a, dt, gain):
+    if dt == I8:
+        return np.clip(np.round(a * gain), -128, 127).astype(np.int8)
+    return np.clip(np.round(a * gain + 128), 0, 255).astype(np.uint8)
+
+
+def _check_int(svs, oracle, metric, x, q, graph, entry, configs, nan_rows=False, record_bytes=2):
+    fn = svs.DistanceL2() if metric == L2 else svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
+    idx = svs.VamanaIndex(graph, x, fn, entry)
+    idx.build_bound_codes(record_bytes)
+    rej = 0
+    for w, c, k, vis in configs:
+        res, st = idx.search(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
+        ids, dists, ost = oracle.search(metric, x, graph, entry, q, k, w, c, visited_set=bool(vis) and not nan_rows, stats=True)
+        assert (res.indices == _u64(ids)).all(), (metric, x.dtype, w, c, k, vis)
+        assert (_bits(res.distances) == _bits(dists)).all(), (metric, x.dtype, w, c, k, vis)
+        assert (st[:, :2] == ost[:, :2]).all()
+        info = idx.last_kernel_info()
+        assert "qmode=1" in info and re.search(r"codes=[234]>", info), info
+        rej += int(st[:, 5].sum())
+    return rej
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("dt", [I8, U8])
+@pytest.mark.parametrize("d", [96, 768, 100, 40])
+def test_inline_records_integer_rows(svs, oracle, metric, dt, d):
+    """int8 x int8 and uint8 x uint8 (QM_INT): static (768) and runtime dimensions, ragged tail (100, 40), every record size the rows allow"""
+    xf = deep_like(1500, d, 16, seed=d + metric + 11, normalize=False)
+    gain = 100.0 / float(np.abs(xf).max())
+    x = _to_int(xf, dt, gain)
+    q = _to_int(deep_like(32, d, 16, seed=d + 5, normalize=False), dt, gain)
+    g, e = oracle.build_vamana(metric, x.astype(np.float32), R=24, L=40)
+    for rb in ((2, 64, 128) if d == 768 else (2,)):
+        rej = _check_int(svs, oracle, metric, x, q, g, e, CONFIGS, record_bytes=rb)
+        # (uint8 rows under the similarity metrics: every vector is dominated by the +128 offset direction, the similarities differ in the third
+        # digit -- less than the 8-bit code step of that one coordinate -- and the bound has little to say: sound, weak; 327 rejects at d = 96,
+        # 41 at d = 768.  The L2 records subtract the mean and are as strong as for int8 rows.)
+        if not (dt == U8 and metric != L2):
+            assert rej > 500, (rb, rej)
+    if d == 768:  # float32 queries on the same index: pairs (float, int8) / (float, uint8), euclidean.h:318-358 -- whichever kernel serves them
+        idx = svs.VamanaIndex(g, x, svs.DistanceL2() if metric == L2 else svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity(), e)
+        idx.build_bound_codes(2)
+        qf = q.astype(np.float32) + np.float32(0.25)
+        res = idx.search(qf, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(40), 1))
+        ids, dists = oracle.search(metric, x, g, e, qf, 10, 40)
+        assert (res.indices == _u64(ids)).all() and (_bits(res.distances) == _bits(dists)).all()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_inline_records_integer_fuzz(svs, oracle, seed):
+    """saturated rows (every element at the type's extremes), constant rows and a constant query (no variance along any direction), zero rows and
+    a zero query (NaN cosines), duplicated rows (ties), a query equal to a row, wide graphs (two adjacency chunks), big buffers"""
+    rng = np.random.default_rng(500 + seed)
+    d = int(rng.choice([32, 64, 96, 200, 768]))
+    n = int(rng.integers(400, 1300))
+    dt = I8 if seed & 1 else U8
+    xf = deep_like(n, d, int(rng.integers(3, 40)), seed=seed + 130, normalize=False)
+    x = _to_int(xf, dt, float(10.0 ** rng.uniform(0.5, 2.5)) / float(np.abs(xf).max()))
+    lo, hi = (-128, 127) if dt == I8 else (0, 255)
+    x[rng.integers(0, n, 5)] = hi
+    x[rng.integers(0, n, 5)] = lo
+    x[rng.integers(0, n, 4)] = 7
+    if seed % 3 == 0:
+        x[rng.integers(0, n, 6)] = 0
+    x[rng.integers(0, n, 10)] = x[rng.integers(0, n, 10)]
+    q = x[rng.integers(0, n, 24)].astype(np.int32) + rng.integers(-9, 10, (24, d))
+    q = np.clip(q, lo, hi).astype(x.dtype)
+    q[0] = 0
+    q[1] = hi
+    q[2] = lo
+    q[3] = 3
+    q[4] = x[17]
+    metric = (L2, IP, COS)[seed % 3]
+    R = int(rng.choice([12, 40, 70, 128]))
+    g, e = oracle.build_vamana(metric, x.astype(np.float32), R=R, L=max(48, R))
+    nan_rows = metric == COS  # zero rows / the zero query give NaN cosines
+    cfgs = [(16, 16, 10, 0), (40, 60, 20, 1), (100, 100, 30, 0), (200, 260, 10, 1)]
+    _check_int(svs, oracle, metric, x, q, g, e, cfgs, nan_rows=nan_rows, record_bytes=(2, 32, 64)[seed % 3] if d >= 200 else 2)
+
+
+def test_records_that_do_not_fit_the_free_hbm_fall_back(svs):
+    """svsx_index_build_bound_codes never fails for want of memory: records shrink (128 -> 64 -> 32 bytes), then 128-byte code
+    rows where the row type has them, then nothing -- SVSX_FELL_BACK (a RuntimeWarning here), results unchanged, svsx_index_memory says what
+    is in effect and how much HBM it takes"""
+    import warnings
+
+    import torch
+
+    n, d, R = 200_000, 96, 64
+    x = deep_like(n, d, 24, seed=9)
+    ids = (np.arange(n, dtype=np.int64)[:, None] * 3 + np.arange(1, R + 1, dtype=np.int64)[None, :] * 7919) % n  # distinct neighbours per row
+    graph = np.concatenate([np.full((n, 1), R, np.uint32), ids.astype(np.uint32)], axis=1)
+    q = deep_like(64, d, 24, seed=10)
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(48), 1)
+    idx = svs.VamanaIndex(graph, x, svs.DistanceL2(), np.array([0], np.uint32))
+    want = idx.search(q, 10, sp)
+    m0 = idx.memory()
+    assert m0["bound_mode"] == 0 and m0["inline_record_bytes"] == 0 and m0["data_bytes"] == n * d * 4 and m0["owns_rows_and_graph"]
+    torch.cuda.synchronize()
+
+    def leave_free(nbytes):
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        return torch.empty(max(free - int(nbytes), 1 << 20), dtype=torch.uint8, device="cuda")
+
+    for free_bytes, asked, expect_mode, expect_rb in ((1.3e9, 64, 2, 64), (1.3e9, 2, 2, None), (0.75e9, 64, 2, 32), (0.25e9, 2, 1, 0)):
+        idx.build_bound_codes(0)
+        filler = leave_free(free_bytes)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            mode = idx.build_bound_codes(asked)
+        m = idx.memory()
+        assert mode == expect_mode == m["bound_mode"], (free_bytes, asked, mode, m)
+        if expect_rb is not None:
+            assert m["record_size"] == expect_rb, m
+        fell = (asked == 64 and m["record_size"] != 64) or expect_mode == 1
+        assert bool(w) == fell, (free_bytes, asked, [str(i.message) for i in w])
+        if expect_mode == 2:
+            assert m["inline_record_bytes"] >= n * R * (4 + m["record_size"])
+        else:
+            assert m["code_row_bytes"] >= n * 128 and m["inline_record_bytes"] == 0
+        del filler
+        got = idx.search(q, 10, sp)
+        assert (got.indices == want.indices).all() and (_bits(got.distances) == _bits(want.distances)).all()
+    torch.cuda.empty_cache()

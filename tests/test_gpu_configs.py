@@ -393,18 +393,22 @@ def test_config3_full_size_ids_identical_to_reference(svs, ref):
 
 
 # ---- config 4 at a size where the record-size rule decides as it does at 10 M ----------------------------------------------------
-def test_config4_large_sq_cosine_matches_oracle(svs, oracle):
+@pytest.mark.parametrize("R", [64, 128])
+def test_config4_large_sq_cosine_matches_oracle(svs, oracle, R):
     """BASELINE config 4's row type at 1 000 000 x 768: scalar-quantized int8 codes (one global scale / bias, scalar.h:454-462),
     float32 queries, cosine (CosineSimilarityCompressed, scalar.h:155-195), batch 4 096, windows 128 and 1 024 (the big-buffer
     instantiation) -- with the record size the spectrum rule picks here AND with the 128-byte records of the 10 M-vector run (codes=4):
-    ids and distance bits must equal the C oracle on a sample of the batch."""
+    ids and distance bits must equal the C oracle on a sample of the batch.
+    R = 128 is what bench.py times: the reference's regression graph (R = 128, L = 200, prune_to 124), window 285 -- two
+    adjacency chunks per row, the 129..512-entry buffer level with its 5-entries-per-lane merge, eight lanes per row (float_row_distance_bc8),
+    128-byte records -- on 256 queries, ids AND distance bits, the kernel named by svsx_last_kernel_info equal to the string the bench reports."""
     import torch
 
     from bench import deep_like_device
     from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
 
     dev = torch.device("cuda", 0)
-    n, d, nq, k, R = 1_000_000, 768, 4096, 10, 64
+    n, d, nq, k, R = 1_000_000, 768, 4096, 10, R
     xf = deep_like_device(n, d, 64, 1, dev, normalize=False)
     q = deep_like_device(nq, d, 64, 2, dev, normalize=False)
     mn, mx = float(xf.min()), float(xf.max())
@@ -413,7 +417,7 @@ def test_config4_large_sq_cosine_matches_oracle(svs, oracle):
     x = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8)
     del xf
     fn = svs.DistanceCosineSimilarity()
-    graph, entry = build_vamana_device(x, n, d, fn, VamanaBuildParameters(alpha=0.95, graph_max_degree=R, window_size=2 * R, prune_to=R - 4),
+    graph, entry = build_vamana_device(x, n, d, fn, VamanaBuildParameters(alpha=0.95, graph_max_degree=R, window_size=200 if R == 128 else 2 * R, prune_to=R - 4),
                                        data_dtype=np.int8, sq=(scale, bias))
     torch.cuda.empty_cache()
     idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), n, d, np.int8, sq=(scale, bias))
@@ -422,22 +426,86 @@ def test_config4_large_sq_cosine_matches_oracle(svs, oracle):
     ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
     dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
     want = {}
-    for window, sample in ((128, 256), (1024, 48)):
+    cases = ((128, 256), (1024, 48)) if R == 64 else ((285, 256), (128, 64), (1024, 32))
+    for window, sample in cases:
         want[window] = oracle.search(COS, xh, gh, eh, q[:sample].cpu().numpy(), k, window, visited_set=True, sq=(scale, bias))
     # mode 2 = whatever the spectrum rule picks at this size (64- or 128-byte records: the two cost within 10 % of each other on this set,
     # and the rule flips between 1 M and 10 M vectors), then 128-byte records explicitly = the instantiation of the 10 M-vector run
     for mode, kernels in ((2, ("codes=3>", "codes=4>")), (128, ("codes=4>",))):
         idx.build_bound_codes(mode)
-        for window, sample in ((128, 256), (1024, 48)):
+        for window, sample in cases:
             st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
             idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(window), 1), d_ids64=ids, d_dists=dist, d_stats=st)
             torch.cuda.synchronize()
             info = idx.last_kernel_info()
             assert info.startswith("search_kernel<dt=2,metric=2,qmode=3,ds=768,general=0,") and info.endswith(kernels), info
+            if mode == 128:  # the string bench.py's config-4 point reports (other_configs.c4.kernel, minus its "svsx::" prefix)
+                assert info == "search_kernel<dt=2,metric=2,qmode=3,ds=768,general=0,codes=4>", info
             oi, od = want[window]
             assert (ids[:sample].cpu().numpy() == oi.astype(np.int64)).all(), (mode, window)
             assert (_bits(dist[:sample].cpu().numpy()) == _bits(od)).all(), (mode, window)
             assert int(st[:, 5].sum()) > 0.5 * int(st[:, 2].sum())
+
+
+# ---- raw int8 rows x int8 queries, cosine, against the reference's own VNNI kernels --------------------------------------
+@pytest.mark.parametrize("metric", [COS, L2])
+def test_config4b_raw_int8_matches_reference(svs, ref, metric):
+    """1 000 000 x 768 raw int8 rows, int8 queries, batch 4 096, GPU-built Vamana R = 64: ids AND distance bits of the HIP path -- plain kernel and
+    inline records over float(row element) (round 6), windows 128 and 285 (the 129..512-entry buffer level) -- identical to oracle/_ref, whose
+    int8 x int8 paths ARE the reference's compiled code (ConvertForVNNI<int16_t,32> simd_utils.h:418-456 through generic_simd_op; cosine.h:261-326,
+    euclidean.h:265-313).  The records must reject more than half of the candidates; the exhaustive search of the same
+    pair (flat search) is checked against the reference on a sample."""
+    import os
+
+    import torch
+
+    from bench import deep_like_device
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device, device_graph_to_svs
+
+    dev = torch.device("cuda", 0)
+    n, d, nq, k, R = 1_000_000, 768, 4096, 10, 64
+    xf = deep_like_device(n, d, 64, 1, dev, normalize=False)
+    qf = deep_like_device(nq, d, 64, 2, dev, normalize=False)
+    mn, mx = float(xf.min()), float(xf.max())
+    scale = (mx - mn) / 255.0
+    bias = mn + 128.0 * scale
+    x = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8)
+    q = torch.clamp(torch.round((qf - bias) / scale), -128, 127).to(torch.int8)
+    del xf, qf
+    fn = svs.DistanceCosineSimilarity() if metric == COS else svs.DistanceL2()
+    graph, entry = build_vamana_device(x, n, d, fn, VamanaBuildParameters(alpha=0.95 if metric == COS else 1.2, graph_max_degree=R, window_size=2 * R, prune_to=R - 4),
+                                       data_dtype=np.int8)
+    torch.cuda.empty_cache()
+    idx = svs.VamanaIndex.from_device(graph, x, fn, torch.tensor([entry], dtype=torch.int32, device=dev), n, d, np.int8)
+    xh, qh, gh = x.cpu().numpy(), q.cpu().numpy(), device_graph_to_svs(graph, R)
+    eh = np.array([entry], np.uint32)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    threads = max(1, len(os.sched_getaffinity(0)))
+    # exhaustive search of the same pair: ids equal the reference's flat search wherever its top k is free of distance ties
+    fi, fd = idx.flat_search_device(q[:64], k)
+    full = ref.distance_batch(metric, qh[:8], xh)
+    order = np.argsort(-full if metric == COS else full, axis=1, kind="stable")[:, : k + 1]
+    for i in range(8):
+        top = full[i, order[i]]
+        if len(np.unique(top)) == k + 1:
+            assert (fi[i].cpu().numpy() == order[i, :k]).all(), i
+            assert (_bits(fd[i].cpu().numpy()) == _bits(top[:k])).all(), i
+    for window in (128, 285):
+        rid, rd = ref.search(metric, xh, gh, eh, qh, k, window, nthreads=min(threads, 32))
+        for mode, vis in ((0, 0), (2, 1), (128, 1)):
+            idx.build_bound_codes(mode)
+            st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
+            idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(window), vis), d_ids64=ids, d_dists=dist, d_stats=st)
+            torch.cuda.synchronize()
+            info = idx.last_kernel_info()
+            assert info.startswith(f"search_kernel<dt=2,metric={metric},qmode=1,ds=768,general=0,") if mode else "codes=0>" in info, info
+            if mode == 128:
+                assert info.endswith("codes=4>"), info
+            assert (ids.cpu().numpy() == rid.astype(np.int64)).all(), (window, mode)
+            assert (_bits(dist.cpu().numpy()) == _bits(rd)).all(), (window, mode)
+            if mode:
+                assert int(st[:, 5].sum()) > 0.5 * int(st[:, 2].sum()), (window, mode, int(st[:, 5].sum()), int(st[:, 2].sum()))
 
 
 # ---- cancellation (index/vamana/index.h:541-545,564-570; greedy_search.h:155; extensions.h:575-578) ---------------------------------
