@@ -66,13 +66,13 @@ def deep_like_device(n, d, latent, seed, device, sigma=0.1, normalize=True, row0
     the stream (a pure function of the row index: chunked generation equals one-shot generation)."""
     import torch
 
-    a = counter_normal(latent, d, 7, 0, device)
+    a = counter_normal(max(latent, 1), d, 7, 0, device)
     out = torch.empty((n, d), device=device)
     for lo in range(0, n, 1 << 18):
         m = min(1 << 18, n - lo)
-        z = counter_normal(m, latent, seed, 1, device, row0=row0 + lo)
+        z = counter_normal(m, max(latent, 1), seed, 1, device, row0=row0 + lo)
         e = counter_normal(m, d, seed, 2, device, row0=row0 + lo)
-        x = z @ a + sigma * e
+        x = (z @ a + sigma * e) if latent > 0 else e   # latent = 0: no low-rank part at all -- isotropic rows (a flat spectrum)
         out[lo : lo + m] = x / x.norm(dim=1, keepdim=True) if normalize else x
     return out
 
@@ -371,7 +371,7 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
     sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window), search_buffer_visited_set=args.visited)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=device)
     out_d = torch.empty((nq, k), dtype=torch.float32, device=device)
-    for _ in range(max(1, warmup)):
+    for _ in range(max(5, warmup)):
         ns.search(q, k, sp, d_ids64=out_i, d_dists=out_d)
     torch.cuda.synchronize()
     if world > 1:
@@ -389,6 +389,24 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # where a batch's time goes, from the library's own phase events (a few extra, untimed calls): what explains the scaling curve at N > 1
+    phases = None
+    try:
+        ns.set_timing(True)
+        acc = []
+        for _ in range(3):
+            ns.search(q, k, sp, d_ids64=out_i, d_dists=out_d)
+            acc.append(ns.phase_times())
+        ns.set_timing(False)
+        phases = {kk_: float(np.median([a_[kk_] for a_ in acc])) for kk_ in acc[0]}
+        if world > 1:  # every rank's view: the all-gather phase of a fast rank contains its wait for the slowest one
+            t = torch.tensor([phases[kk_] for kk_ in sorted(phases)], device=device, dtype=torch.float64)
+            allt = torch.empty((world, t.numel()), device=device, dtype=torch.float64)
+            dist.all_gather_into_tensor(allt.view(-1), t)
+            phases = {"rank0": phases, "max_over_ranks": {kk_: float(allt[:, i].max()) for i, kk_ in enumerate(sorted(phases))},
+                      "min_over_ranks": {kk_: float(allt[:, i].min()) for i, kk_ in enumerate(sorted(phases))}}
+    except Exception as e:  # noqa: BLE001 (informational)
+        phases = {"error": f"{type(e).__name__}: {e}"}
     # recall against the exact global top-k: exact per-shard lists (MFMA flat search + exact re-rank), gathered, best k overall
     gd, gi = [], []
     for sh in keep:
@@ -410,12 +428,92 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
     res = {"shards_total": total, "shards_per_gpu": per, "vectors_per_shard": n5, "n_gpus": world, "batch": nq, "window_per_shard": args.window,
            "merged_answers_per_s": nq * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "steps": steps, "recall_at_10": recall_at(gt, out_i, k),
            "rccl_communicator": info["communicator"], "rccl_ranks": info["world"], "build_seconds_this_rank": t_build, "bound_codes": mode5,
+           "phases_ms": phases,
+           "phases_note": "svsx_sharded_phase_times (events inside the library, median of 3 extra calls): search = the per-shard searches of this GPU, all_gather "
+                          "includes waiting for the slowest rank; span < sum of phases when the second chunk's searches overlap the first chunk's exchange",
+           "expected_at_8_gpus": "DESIGN.md section 6: one 12.5 M-vector shard per GPU ~1.17 ms per 10 000 queries + an exposed half-batch exchange and two merges "
+                                 "~0.25 ms => ~7 M merged answers/s; falsified or confirmed by the first 8-GPU run of this line",
            "path": "svsx_sharded_search_device (libsvsx: per-shard search -> local merge -> ONE ncclAllGather -> world-way merge, one stream)",
            "scaling": "strong (the set of 8 shards is fixed as N grows)",
            "shard_size_note": ("BASELINE config 5's shard size at every N (inline records where the GPU's shards fit with them, 128-byte code rows where not: bound_codes)"
                                if n5 == 12_500_000 else f"{n5} vectors per shard (--c5-n, or 12.5 M-vector shards do not fit this GPU)")}
     ns.close()
     return res
+
+
+def spectrum_points(args, svs, device, local_rank, q_seed, k, R, headline):
+    """how the headline moves with the data's spectrum.  The inline records bound a distance from the coordinates along the
+    leading principal directions; G(24, 0.1) puts nearly all variance into 24 of them.  Two more sets of the same shape (1 M x 96 float32 unit
+    rows, L2, batch, window, graph parameters of the headline): G(48, 0.2) and isotropic rows (no low-rank part: the flattest spectrum there
+    is, where a 32-byte record says almost nothing and the size rule has to pay for 128-byte ones).  Each: QPS, recall, record size chosen,
+    rejects and lines per query, the plain kernel on the same graph, ids against the reference on a query sample."""
+    import torch
+
+    from scalablevectorsearch_amd.build import device_graph_to_svs
+
+    n, d, nq = 1_000_000, 96, args.nq
+    out = [headline]
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window), search_buffer_visited_set=args.visited)
+    for name, latent, sigma in (("G(48, 0.2)", 48, 0.2), ("isotropic", 0, 0.0)):
+        t0 = time.time()
+        x = deep_like_device(n, d, latent, seed=1, device=device, sigma=sigma)
+        q = deep_like_device(nq, d, latent, seed=q_seed, device=device, sigma=sigma)
+        graph, entry, tb = build_or_load_graph(svs, x, n, d, R, local_rank, "")
+        d_entry = torch.tensor([entry], dtype=torch.int32, device=device)
+        index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), d_entry, n, d, np.float32, device=local_rank)
+        gt, _ = index.flat_search_device(q, k)
+        torch.cuda.synchronize()
+        ids = torch.empty((nq, k), dtype=torch.int64, device=device)
+        dd = torch.empty((nq, k), dtype=torch.float32, device=device)
+        st = torch.zeros((nq, 6), dtype=torch.int32, device=device)
+
+        def timed(with_stats=False):
+            index.search_device(q, k, sp, d_ids64=ids, d_dists=dd, d_stats=st if with_stats else None)
+            for _ in range(max(args.warmup, 12)):
+                index.search_device(q, k, sp, d_ids64=ids, d_dists=dd)
+            torch.cuda.synchronize()
+            ev_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(5, args.steps // 2))]
+            for a_, b_ in ev_:
+                a_.record()
+                index.search_device(q, k, sp, d_ids64=ids, d_dists=dd)
+                b_.record()
+            torch.cuda.synchronize()
+            return float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev_]))
+
+        ms_plain = timed()
+        ids_plain = ids.clone()
+        index.build_bound_codes(2)
+        ms = timed(with_stats=True)
+        kinfo = index.last_kernel_info()
+        rb = int(index.memory()["record_size"])
+        lines = designed_lines(st.to(torch.int64), (R + 15) // 16 * 16, d * 4, 2, d, k, rb)
+        point = {"generator": f"{name}, unit norm, base seed 1, query seed {q_seed}", "qps": nq / (ms * 1e-3), "kernel_ms": ms, "recall_at_10": recall_at(gt, ids, k),
+                 "record_bytes": rb, "kernel": "svsx::" + kinfo, "expansions_per_query": int(st[:, 0].sum()) / nq,
+                 "distance_evals_per_query": int(st[:, 2].sum()) / nq, "bound_code_rejects_per_query": int(st[:, 5].sum()) / nq,
+                 "reject_share": float(st[:, 5].sum()) / max(float(st[:, 2].sum()), 1.0), "designed_lines_per_query": lines["total"] / nq,
+                 "frac_designed": lines["total"] * LINE / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_traffic": None,
+                 "plain_kernel_ms": ms_plain, "speedup_over_plain_kernel": ms_plain / ms, "ids_equal_plain_kernel": bool((ids == ids_plain).all()),
+                 "build_seconds": tb, "seconds": None}
+        try:  # ids against the reference's own code on a query sample (oracle/_ref; the C oracle where it is not available)
+            from oracle.oracle import L2, Oracle, Ref
+
+            ns = 256
+            xh, gh = x.cpu().numpy(), device_graph_to_svs(graph, R)
+            if Ref.available():
+                ri, _ = Ref().search(L2, xh, gh, np.array([entry], np.uint32), q[:ns].cpu().numpy(), k, args.window, nthreads=host_cores())
+                who = "oracle/_ref"
+            else:
+                ri, _ = Oracle().search(L2, xh, gh, np.array([entry], np.uint32), q[:ns].cpu().numpy(), k, args.window)
+                who = "C oracle"
+            point["reference_sample"] = {"queries": ns, "checker": who, "ids_identical": bool((ri.astype(np.int64) == ids[:ns].cpu().numpy()).all())}
+            del xh, gh
+        except Exception as e:  # noqa: BLE001
+            point["reference_sample"] = {"error": f"{type(e).__name__}: {e}"}
+        point["seconds"] = time.time() - t0
+        out.append(point)
+        del index, x, q, graph, gt
+        torch.cuda.empty_cache()
+    return out
 
 
 def config4_point(args, svs, device, local_rank, k, t_run0):
@@ -1078,6 +1176,17 @@ def main():
             del q4, ids4, dists4, st4
         except Exception as e:
             log(f"[bench] 4x batch point skipped: {e}")
+        if not args.no_extras:
+            try:
+                head = {"generator": "G(24, 0.1), unit norm (the headline's set)", "qps": result["value"], "kernel_ms": kern_ms, "recall_at_10": recall,
+                        "record_bytes": record_bytes, "kernel": "svsx::" + kinfo, "expansions_per_query": exp_total / nq,
+                        "distance_evals_per_query": int(st[:, 2].sum()) / nq, "bound_code_rejects_per_query": int(st[:, 5].sum()) / nq,
+                        "reject_share": float(st[:, 5].sum()) / max(float(st[:, 2].sum()), 1.0), "designed_lines_per_query": lines["total"] / nq,
+                        "frac_designed": achieved / HBM_PEAK_GBS, "frac_traffic": result["roofline"]["frac_traffic"]}
+                result["config"].setdefault("other_configs", {})["c2_spectrum"] = spectrum_points(args, svs, device, local_rank, 2, k, R, head)
+            except Exception as e:  # informational: never fail the line over it
+                result["config"].setdefault("other_configs", {})["c2_spectrum"] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"[bench] spectrum points failed: {e}")
         if not args.no_extras:
             try:  # BASELINE config 3 as a point of the same line: sift-1M-like, 1 M x 128 float16 rows, float32 queries, inner product
                 from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device

@@ -150,6 +150,8 @@ def lib() -> C.CDLL:
         L.svsx_flat_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.svsx_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.svsx_index_memory.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.svsx_sharded_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.svsx_sharded_phase_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.svsx_iterator_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
         L.svsx_iterator_destroy.argtypes = [C.c_void_p]
         L.svsx_iterator_destroy.restype = None

@@ -786,6 +786,37 @@ __device__ __forceinline__ void int_row_sums(
     bb = sbb;
 }
 
+// The same sums on EIGHT lanes per row (round 6; 8-bit rows of a static dimension that is a multiple of 64: the 768-byte rows of SURVEY 8d
+// C4(b)): every lane holds 8 bytes of each 64-byte block (Bc8Row, the mapping of the float path's eight-lane form -- for exact integer sums any
+// mapping gives the same value), so ALL loads of a row are in flight before the first use and the search kernel can request the rows of the next
+// pass before it computes this one.  The four-lane form above pays three dependent round trips per 768-byte row.  Results in the lanes sub < 4.
+template <int DT, int DS>
+__device__ __forceinline__ void int_row_sums8(const Bc8Row<DS>& r, const uint32_t* __restrict__ qw, int sub, int& ab, int& bb) {
+    static_assert(DT == DT_I8 || DT == DT_U8, "8-bit rows");
+    const unsigned char* lane_q = reinterpret_cast<const unsigned char*>(qw) + 16 * (sub & 3) + 8 * (sub >> 2);
+    int sab = 0, sbb = 0;
+#pragma unroll
+    for (int t = 0; t < (DS >> 6); ++t) {
+        const uint2 q = *reinterpret_cast<const uint2*>(lane_q + 64 * t);
+        const uint2 x = r.raw[t];
+        if constexpr (DT == DT_I8) {
+            sab = __builtin_amdgcn_sdot4(q.x, x.x, sab, false);
+            sab = __builtin_amdgcn_sdot4(q.y, x.y, sab, false);
+            sbb = __builtin_amdgcn_sdot4(x.x, x.x, sbb, false);
+            sbb = __builtin_amdgcn_sdot4(x.y, x.y, sbb, false);
+        } else {
+            sab = (int)__builtin_amdgcn_udot4(q.x, x.x, (unsigned)sab, false);
+            sab = (int)__builtin_amdgcn_udot4(q.y, x.y, (unsigned)sab, false);
+            sbb = (int)__builtin_amdgcn_udot4(x.x, x.x, (unsigned)sbb, false);
+            sbb = (int)__builtin_amdgcn_udot4(x.y, x.y, (unsigned)sbb, false);
+        }
+    }
+    sab = add_xor2i(add_xor1i(sab));
+    sbb = add_xor2i(add_xor1i(sbb));
+    ab = opaque_i(sab + __builtin_amdgcn_mov_dpp(sab, 0x104, 0xf, 0xf, true)); // row_shl:4 -- lane i takes lane i + 4: the other half of the row
+    bb = opaque_i(sbb + __builtin_amdgcn_mov_dpp(sbb, 0x104, 0xf, 0xf, true));
+}
+
 // SQ compress (scalar.h:37-42): clamp(round((v - bias) / scale), MIN, MAX); std::round = half away from zero.
 template <int DT> __device__ __forceinline__ int sq_compress(float v, float scale, float bias) {
     float r = roundf((v - bias) / scale);

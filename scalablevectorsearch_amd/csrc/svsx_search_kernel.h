@@ -55,7 +55,13 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
         // (float32 rows of 128 keep 8 x 16 bytes of a row in flight per lane: 6 waves would spill 92 bytes)
         if ((DS == 96 || DS == 128) && CODES == 2 && BIG == 0 && METRIC != M_COS) return (DT == DT_F32 && DS == 128) ? 4 : (DT == DT_F16 && DS == 96) ? 5 : 6;
         // any dimension, 32- / 64-byte records: <= 96
-        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES <= 3) return 5;
+#ifndef SVSX_FLOOR_DS0
+#define SVSX_FLOOR_DS0 5
+#endif
+        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES <= 3) return SVSX_FLOOR_DS0;
+#ifdef SVSX_FLOOR_DS0_C4
+        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES == 4) return SVSX_FLOOR_DS0_C4;
+#endif
     }
     // windows 513 .. 1024 with 128-byte records (config 4 at recall >= 0.9): 143 VGPRs instead of 181, no scratch -> 3 waves per SIMD instead of 2
     if (DS == 768 && BIG == 2 && CODES == 4 && (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS)) return 3;
@@ -93,7 +99,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
 #define SVSX_BC8 1
 #endif
     constexpr bool BC8 = SVSX_BC8 != 0 && B8 && !GENERAL && use_bc8<DT, DS>(); // 8-bit rows of a long static dimension: eight lanes per row (float_row_distance_bc8)
-    constexpr int G = QMODE == QM_SCALAR ? 1 : BC8 ? 8 : (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
+    constexpr bool INT8L = SVSX_BC8 != 0 && INTPATH && !GENERAL && use_bc8<DT, DS>(); // the integer paths on 8-bit rows of a long static dimension: eight lanes per row too (int_row_sums8)
+    constexpr int G = QMODE == QM_SCALAR ? 1 : (BC8 || INT8L) ? 8 : (INTPATH || B8) ? 4 : 16 / Elem<DT>::E;      // lanes per candidate row
     constexpr int RPP = 64 / G;                        // rows per pass
 
     const uint32_t lane = threadIdx.x;
@@ -386,6 +393,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             return fmain;
         } else if constexpr (QMODE == QM_SCALAR) {
             scalar_row_distance<DT, METRIC>(row, qf, d, fmain, fnrm);
+        } else if constexpr (INT8L) {
+            int_row_sums8<DT, DS>(bc8_load<DS>(row, sub), qw, sub, ab, bb);
         } else if constexpr (INTPATH) {
             int_row_sums<DT>(row, active, qw, d, sub, ab, bb);
         } else if constexpr (B8 && QMODE == QM_SQ_COS) {
@@ -782,15 +791,16 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             // Eight-lane 8-bit rows with inline records (config 4): the rows of pass p + 1 are requested before pass p is computed -- the list of
             // candidates is fixed for the expansion (compact[]), so the requests do not depend on the inserts in between -- and a pass waits
             // for memory only where the arithmetic and the merge of the pass before it were shorter than the round trip.
-            constexpr bool PIPE = BC8 && FAT && (QMODE == QM_SQ_COS || QMODE == QM_SQ_IP);
-            [[maybe_unused]] Bc8Row<(BC8 ? DS : 64)> row_next;
+            constexpr bool PIPE = (BC8 && FAT && (QMODE == QM_SQ_COS || QMODE == QM_SQ_IP)) || (INT8L && FAT);
+            constexpr int PDS = (BC8 || INT8L) ? DS : 64;
+            [[maybe_unused]] Bc8Row<PDS> row_next;
             [[maybe_unused]] uint32_t cid_next = 0u;
             [[maybe_unused]] float bn_next = 0.0f;
             [[maybe_unused]] auto pipe_request = [&](const uint32_t base) { // reads only (see the note on lambdas above)
                 const uint32_t cj = base + grp;
                 cid_next = compact[cj];
                 const uint32_t rj = cj < cnt ? (cid_next & idmask) : 0u;
-                row_next = bc8_load<(BC8 ? DS : 64)>(data + static_cast<size_t>(rj) * static_cast<uint32_t>(a.row_bytes), sub);
+                row_next = bc8_load<PDS>(data + static_cast<size_t>(rj) * static_cast<uint32_t>(a.row_bytes), sub);
                 if constexpr (QMODE == QM_SQ_COS) bn_next = a.sq_row_norm[rj];
             };
             if constexpr (PIPE) {
@@ -808,7 +818,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 [[maybe_unused]] uint2 pre_big[8];
                 [[maybe_unused]] bool pre_big_valid = false;
                 if constexpr (PIPE) {
-                    const Bc8Row<(BC8 ? DS : 64)> row_cur = row_next;
+                    const Bc8Row<PDS> row_cur = row_next;
                     const float bn_cur = bn_next;
                     if (p0 + RPP < cnt) pipe_request(p0 + RPP);
                     if constexpr (BIG == 1 && !GENERAL) { // the merge's entries (up to 8 per lane: buffers of 129 .. 512) arrive under the arithmetic
@@ -816,11 +826,15 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         pre_big_valid = true;
                     }
                     float fmain = 0.0f, fnrm = 0.0f;
-                    if constexpr (QMODE == QM_SQ_COS) {
-                        bc8_compute<DT, M_IP, (BC8 ? DS : 64), true>(row_cur, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+                    if constexpr (INT8L) {
+                        int ab = 0, bb = 0;
+                        int_row_sums8<DT, PDS>(row_cur, qw, sub, ab, bb);
+                        pipe_dist = finish_distance<METRIC, QMODE>(fmain, fnrm, ab, bb, fx, a.sq_scale);
+                    } else if constexpr (QMODE == QM_SQ_COS) {
+                        bc8_compute<DT, M_IP, PDS, true>(row_cur, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
                         pipe_dist = fmain / (bn_cur * fx.norm); // cosine.h:334-335
                     } else {
-                        bc8_compute<DT, METRIC, (BC8 ? DS : 64), false>(row_cur, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
+                        bc8_compute<DT, METRIC, PDS, false>(row_cur, qf, sub, a.sq_scale, a.sq_bias, fmain, fnrm);
                         pipe_dist = finish_distance<METRIC, QMODE>(fmain, fnrm, 0, 0, fx, a.sq_scale);
                     }
                 }
@@ -1080,6 +1094,13 @@ template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const Sear
         if (a.fat != nullptr && a.fat_rb == 128 && a.d == 768) return launch_one<DT, METRIC, QMODE, 768, false, 4>(a, stream);
         if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
     }
+    if constexpr (QMODE == QM_FLOAT && (DT == DT_I8 || DT == DT_U8)) {
+        // float32 queries over raw int8 / uint8 rows (the pairs (float, int8) / (float, uint8) of euclidean.h:318-358: ConvertToFloat<16> loads,
+        // the float accumulate trees): the same records serve them -- the vector the metric sees is float(row element) either way
+        if (a.fat != nullptr && a.fat_rb == 32) return launch_one<DT, METRIC, QMODE, 0, false, 2>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 64) return launch_one<DT, METRIC, QMODE, 0, false, 3>(a, stream);
+        if (a.fat != nullptr && a.fat_rb == 128) return launch_one<DT, METRIC, QMODE, 0, false, 4>(a, stream);
+    }
     if constexpr ((QMODE == QM_INT || QMODE == QM_SQ_L2) && (DT == DT_I8 || DT == DT_U8)) {
         // round 6: the exact integer paths (VNNI pairs euclidean.h:265-313, inner_product.h:222-267, cosine.h:261-326; EuclideanCompressed
         // scalar.h:58-105) behind inline records built over float(row element)
@@ -1109,7 +1130,7 @@ template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const Sear
             }
         }
     }
-    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS) && (DT == DT_I8 || DT == DT_U8)) {
+    if constexpr ((QMODE == QM_SQ_IP || QMODE == QM_SQ_COS || QMODE == QM_INT || QMODE == QM_SQ_L2) && (DT == DT_I8 || DT == DT_U8)) {
         if (a.d == 768) return launch_one<DT, METRIC, QMODE, 768>(a, stream);
     }
     return launch_one<DT, METRIC, QMODE, 0>(a, stream);

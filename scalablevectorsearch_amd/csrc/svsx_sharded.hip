@@ -233,7 +233,7 @@ int svsx_sharded_plan(size_t n_local, int exchange, size_t nq, int have_last, sv
     if (fan_out || nchunk > 1) {
         put(SVSX_OP_RECORD, 0, -1, SVSX_EV_START);
         put(SVSX_OP_WAIT, 1, -1, SVSX_EV_START);
-        put(SVSX_OP_WAIT, 2, -1, SVSX_EV_START);
+        if (fan_out) put(SVSX_OP_WAIT, 2, -1, SVSX_EV_START); // (one local shard: the second internal stream carries nothing)
     }
     for (int c = 0; c < nchunk; ++c) {
         if (!fan_out) {

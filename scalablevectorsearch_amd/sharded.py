@@ -251,6 +251,17 @@ class NativeShardedSearcher:
         _lib.check(_lib.lib().svsx_sharded_search_device(self._h, d_queries.data_ptr(), code, nq, k, C.byref(sp), d_ids64.data_ptr(), d_dists.data_ptr(), C.c_void_p(s)))
         return d_dists, d_ids64
 
+    def set_timing(self, enabled: bool) -> None:
+        """svsx_sharded_set_timing: record phase-boundary events in the calls that follow (off by default)"""
+        _lib.check(_lib.lib().svsx_sharded_set_timing(self._h, int(bool(enabled))))
+
+    def phase_times(self) -> dict:
+        """svsx_sharded_phase_times of the last (timed) call, ms: shard searches, local merge, all-gather (incl. waiting for the slowest rank),
+        world merge -- summed over the call's chunks -- and the span from the first search to the last merge"""
+        ms = (C.c_float * 5)()
+        _lib.check(_lib.lib().svsx_sharded_phase_times(self._h, ms))
+        return dict(search_ms=float(ms[0]), local_merge_ms=float(ms[1]), all_gather_ms=float(ms[2]), world_merge_ms=float(ms[3]), span_ms=float(ms[4]))
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             _lib.lib().svsx_sharded_destroy(self._h)

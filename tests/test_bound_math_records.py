@@ -390,6 +390,12 @@ def test_record_bound_integer_rows(oracle, metric, dt, d, rb):
         if name == "deep-like":
             fired_deep = fired
             assert fired > 0.5 * q.shape[0] * x.shape[0], (fired, q.shape[0] * x.shape[0])
+        # float32 queries over the same rows (pairs (float, int8) / (float, uint8), euclidean.h:318-358): the same records, the float trees
+        qf = (q[:6].astype(f32) + f32(0.37) * np.arange(1, 7, dtype=f32)[:, None]).astype(f32)
+        exact_f = oracle.distance_batch(metric, qf, x)
+        for qi in range(qf.shape[0]):
+            own = rejected(Query(rec, qf[qi]), exact_f[qi])
+            assert not own.any(), (name, "float queries", metric, rb, qi, np.nonzero(own)[0][:5])
     assert fired_deep > 0
 
 

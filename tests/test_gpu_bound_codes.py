@@ -345,13 +345,17 @@ def test_inline_records_integer_rows(svs, oracle, metric, dt, d):
         # 41 at d = 768.  The L2 records subtract the mean and are as strong as for int8 rows.)
         if not (dt == U8 and metric != L2):
             assert rej > 500, (rb, rej)
-    if d == 768:  # float32 queries on the same index: pairs (float, int8) / (float, uint8), euclidean.h:318-358 -- whichever kernel serves them
+    if d in (768, 100):  # float32 queries on the same index: pairs (float, int8) / (float, uint8), euclidean.h:318-358 -- the same records serve them
         idx = svs.VamanaIndex(g, x, svs.DistanceL2() if metric == L2 else svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity(), e)
         idx.build_bound_codes(2)
         qf = q.astype(np.float32) + np.float32(0.25)
-        res = idx.search(qf, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(40), 1))
-        ids, dists = oracle.search(metric, x, g, e, qf, 10, 40)
-        assert (res.indices == _u64(ids)).all() and (_bits(res.distances) == _bits(dists)).all()
+        for w, c, k, vis in CONFIGS:
+            res, st = idx.search(qf, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
+            ids, dists, ost = oracle.search(metric, x, g, e, qf, k, w, c, visited_set=bool(vis), stats=True)
+            assert (res.indices == _u64(ids)).all() and (_bits(res.distances) == _bits(dists)).all(), (w, c, k, vis)
+            assert (st[:, :2] == ost[:, :2]).all()
+            info = idx.last_kernel_info()
+            assert "qmode=0" in info and re.search(r"codes=[234]>", info), info
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -271,6 +271,18 @@ def test_native_sharded_pipeline_large_batches(svs, oracle, n_local, comm):
         torch.cuda.synchronize()
         assert (mi.cpu().numpy() == wi).all() and (_bits(md.cpu().numpy()) == _bits(wd)).all()
         assert (mi2.cpu().numpy() == wi[:7]).all() and (_bits(md2.cpu().numpy()) == _bits(wd[:7])).all()
+    # phase timing (svsx_sharded_set_timing / _phase_times): off by default -> refused; on -> the phases of the last call, same answer
+    with pytest.raises(svs.SvsxError):
+        ns.phase_times()
+    ns.set_timing(True)
+    md, mi = ns.search(dq, k, sp)
+    ph = ns.phase_times()
+    assert (mi.cpu().numpy() == wi).all() and (_bits(md.cpu().numpy()) == _bits(wd)).all()
+    assert ph["search_ms"] > 0 and ph["span_ms"] > 0 and all(v >= 0 for v in ph.values()), ph
+    assert (n_local == 1 or ph["local_merge_ms"] > 0) and (ph["world_merge_ms"] > 0) == comm and (ph["all_gather_ms"] > 0) == comm, ph
+    ns.set_timing(False)
+    with pytest.raises(svs.SvsxError):
+        ns.phase_times()
     ns.close()
 
 
