@@ -7,12 +7,12 @@
 // R = 64, address known as soon as the node is) and a bound on the distance of all 64 candidates is evaluated lane-parallel
 // (lane c <-> neighbour c); only candidates the bound cannot exclude have their vector row fetched.
 //
-// Geometry.  Q = DC orthonormal directions (rows; the leading principal directions of a data sample, host: svsx_api.hip),
-// z = the vector the metric sees (L2: x - mean; inner product: x; cosine: x / ||x||; scalar-quantized rows: the
-// decompressed values), y = Q z its DC coordinates, r = z - Q^T y the remainder, ||r||^2 = ||z||^2 - ||y||^2 exactly.
-// For a query with coordinates u and remainder norm tq:
+// Geometry.  Q = DC orthonormal directions (rows; the leading principal directions of a data sample, host: svsx_records.hip),
+// z = the CENTRED vector the metric sees (L2 and inner product: x - mean; cosine: x / ||x|| - mean of the unit vectors; scalar-quantized
+// rows: the decompressed values), y = Q z its DC coordinates, r = z - Q^T y the remainder, ||r||^2 = ||z||^2 - ||y||^2 exactly.
+// For a query with coordinates u and remainder norm tq (L2: of q - mean; similarities: of q resp. q / ||q||, NOT centred):
 //     L2      ||q - x||^2  =  ||u - y||^2 + ||r_q - r_x||^2  >=  ||u - y||^2 + (tq - tx)^2
-//     IP/cos  q . z        =  u . y + r_q . r_x             <=  u . y + tq tx
+//     IP/cos  q . x        =  q . z + q . mean  =  u . y + r_q . r_x + q . mean  <=  u . y + tq tx + q . mean      (round 6: centred)
 // Record (RB = 32, 64 or 128 bytes -- the host picks the smallest whose directions carry the sample's energy, svsx_api.hip),
 // everything rounded in the SAFE direction:
 //     L2      (RB - 4) x u8 codes c_i = clamp(rint((y_i - b_i) / s), 0, 255) | f16 ex (up) | f16 tx (nearest)
@@ -66,24 +66,44 @@ template <int DT> __device__ __forceinline__ double load_elem(const PcaArgs& a, 
 
 // Coordinates of one vector: z into LDS (`vs`, d doubles), then y_i = Q_i . z for i < dc into LDS (`ys`), n2 = ||z||^2.
 // Lane l owns the elements j = l, l + 64, ...: coalesced reads of the f64 basis rows; kChunk coordinates per sweep.
+// z = x - mean (L2, inner product) or x / ||x|| - mean (cosine: `mean` is then the mean of the UNIT vectors).  Round 6: the similarity
+// metrics are centred too -- q . x = q . (x - mean) + q . mean, the second term is a per-query constant the kernel adds to its bound -- so that
+// data with a common offset (non-negative rows, uint8 rows, embeddings with a dominant mean direction) spends its 8-bit codes on what
+// distinguishes the vectors, not on the offset.  `degenerate`: a zero row under cosine (the reference's distance is NaN: never bounded).
 template <int DT>
-__device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned char* row, double* vs, double* ys, uint32_t lane, double& n2) {
+__device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned char* row, double* vs, double* ys, uint32_t lane, double& n2, bool& degenerate) {
     double part = 0.0;
-    for (uint32_t j = lane; j < a.d; j += 64) {
-        const double z = load_elem<DT>(a, row, j) - static_cast<double>(a.mean[j]);
-        vs[j] = z;
-        part += z * z;
+    degenerate = false;
+    if (a.normalize) {
+        for (uint32_t j = lane; j < a.d; j += 64) {
+            const double x = load_elem<DT>(a, row, j);
+            vs[j] = x;
+            part += x * x;
+        }
+        const double raw2 = wave_sum(part);
+        degenerate = !(raw2 > 0.0);
+        const double inv = raw2 > 0.0 ? 1.0 / sqrt(raw2) : 0.0;
+        part = 0.0;
+        for (uint32_t j = lane; j < a.d; j += 64) { // (every lane rewrites its own elements: no barrier needed in between)
+            const double z = vs[j] * inv - static_cast<double>(a.mean[j]);
+            vs[j] = z;
+            part += z * z;
+        }
+    } else {
+        for (uint32_t j = lane; j < a.d; j += 64) {
+            const double z = load_elem<DT>(a, row, j) - static_cast<double>(a.mean[j]);
+            vs[j] = z;
+            part += z * z;
+        }
     }
     n2 = wave_sum(part);
-    double scale = 1.0;
-    if (a.normalize) scale = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0; // cosine: the unit vector (a zero vector gets ex = inf below)
     __syncthreads();
     for (uint32_t c0 = 0; c0 < a.dc; c0 += kChunk) {
         double y[kChunk];
 #pragma unroll
         for (int i = 0; i < kChunk; ++i) y[i] = 0.0;
         for (uint32_t j = lane; j < a.d; j += 64) {
-            const double z = vs[j] * scale;
+            const double z = vs[j];
 #pragma unroll
             for (int i = 0; i < kChunk; ++i)
                 if (c0 + static_cast<uint32_t>(i) < a.dc) y[i] = __builtin_fma(a.q64[static_cast<size_t>(c0 + i) * a.d + j], z, y[i]);
@@ -94,7 +114,6 @@ __device__ __forceinline__ void coordinates(const PcaArgs& a, const unsigned cha
             if (lane == 0 && c0 + static_cast<uint32_t>(i) < a.dc) ys[c0 + i] = t;
         }
     }
-    if (a.normalize) n2 = n2 > 0.0 ? 1.0 : 0.0;
     __syncthreads();
 }
 
@@ -110,7 +129,8 @@ template <int DT> __global__ __launch_bounds__(64) void pca_stats_kernel(const P
     uint32_t bad = 0;
     for (uint32_t r = blockIdx.x; r < a.n; r += gridDim.x) {
         double n2;
-        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, ys, lane, n2);
+        bool degenerate;
+        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, ys, lane, n2, degenerate);
         double ny2 = 0.0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -154,7 +174,8 @@ template <int DT> __global__ __launch_bounds__(64) void pca_encode_kernel(const 
     const double s = static_cast<double>(a.step), inv = 1.0 / s;
     for (uint32_t r = blockIdx.x; r < a.n; r += gridDim.x) {
         double n2;
-        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, ys, lane, n2);
+        bool degenerate;
+        coordinates<DT>(a, static_cast<const unsigned char*>(a.data) + static_cast<size_t>(r) * a.row_bytes, vs, ys, lane, n2, degenerate);
         if (lane < 32u) recw[lane] = 0u;
         __syncthreads();
         double e2 = 0.0, ny2 = 0.0, nh2 = 0.0;
@@ -190,7 +211,7 @@ template <int DT> __global__ __launch_bounds__(64) void pca_encode_kernel(const 
         const double t2 = n2 - ny2;
         const double tail = t2 > 0.0 ? sqrt(t2) : 0.0;
         uint16_t exh = half_round_up(sqrt(e2) * inv * (1.0 + 1e-12));
-        if (a.normalize && n2 == 0.0) exh = 0x7C00u; // zero vector under cosine: the reference's distance is NaN, never bound it
+        if (degenerate) exh = 0x7C00u; // zero vector under cosine: the reference's distance is NaN, never bound it
         const uint32_t nw = a.rb / 4u;
         if (lane == 0) {
             if (a.signed_codes) { // codes | ex | ny | tx, all upper bounds

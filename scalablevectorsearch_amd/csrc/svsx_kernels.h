@@ -47,14 +47,15 @@ struct SearchArgs {
     uint32_t fat_rb;          // record bytes: 32 / 64 / 128
     uint32_t fat_degshift;    // 0, or 26: the id words of the blocks carry ceil(degree(neighbour) / 8) in bits [26, 31) (indexes of <= 2^26 nodes)
     const float* pca_t;       // [128][pca_pd] leading directions, row-major float32 (rows >= dc are zero), pca_pd = d rounded up to 16
-    const float* pca_mean;    // [pca_pd] (zeros unless L2)
+    const float* pca_mean;    // [pca_pd] what the records were centred with (cosine: the mean of the unit vectors)
     const float* pca_bias;    // [128] per-coordinate code bias (L2)
     uint32_t pca_pd;
     float pca_step;           // s
     float pca_tail_unit;      // tx = half(tx16) * tail_unit
     float pca_delta;          // >= max_i || float32(Q_i) - Q_i ||: rounding of the directions the query is projected with
     float pca_eq_abs;         // absolute slack of the query coding error (rounding of b + s c)
-    float pca_ref_extra;      // scalar-quantized inner product: 2 |bias| sqrt(d), enters the slack for the reference's own rounding
+    float pca_ref_extra;      // inner product: ||mean|| (+ 2 |bias| sqrt(d) for scalar-quantized rows), enters the slack for the reference's own rounding
+    float pca_mean_norm;      // similarity metrics: >= ||mean|| (the records are centred; the kernel adds q . mean to its bound); 0 under L2
     // cancellation (index/vamana/index.h:541-545, greedy_search.h:155): device word polled once per expansion; non-zero = stop
     const int* cancel;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)
@@ -184,7 +185,7 @@ struct PcaArgs {
     int normalize;          // cosine: code the unit vector
     int signed_codes;       // inner product / cosine record layout
     const double* q64;      // [dc][d] orthonormal directions (f64)
-    const float* mean;      // [d] (zeros unless L2)
+    const float* mean;      // [d] the centre (cosine: of the unit vectors)
     const float* bias;      // [dc] per-coordinate code bias (unsigned codes; encode)
     float step, tail_unit;  //                 (encode)
     uint32_t* stat_min;     // [dc] order keys (stats; init 0xFFFFFFFF)

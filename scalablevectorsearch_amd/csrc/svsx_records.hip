@@ -124,7 +124,7 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
         }
     const uint32_t pd = (d + 15u) & ~15u;
     std::vector<float> mean_f(pd, 0.0f);
-    if (l2) {
+    {   // every metric is centred (round 6; svsx_codes.hip has the geometry): under cosine the mean of the UNIT vectors
         std::vector<double> mean(d, 0.0);
         for (size_t r = 0; r < ns; ++r)
             for (uint32_t j = 0; j < d; ++j) mean[j] += xs[r * d + j];
@@ -132,6 +132,9 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
         for (size_t r = 0; r < ns; ++r)
             for (uint32_t j = 0; j < d; ++j) xs[r * d + j] -= static_cast<double>(mean_f[j]);
     }
+    double mean_norm = 0.0;
+    for (uint32_t j = 0; j < d; ++j) mean_norm += static_cast<double>(mean_f[j]) * static_cast<double>(mean_f[j]);
+    mean_norm = std::sqrt(mean_norm);
     // 2. second-moment matrix (upper triangle, then mirrored)
     std::vector<double> cov(static_cast<size_t>(d) * d, 0.0);
     for (size_t r = 0; r < ns; ++r) {
@@ -351,7 +354,9 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
     ix->pca_delta = static_cast<float>(delta * 1.01 + 1e-9);
     // rounding of fl(b + s c) (L2) / fl(s c) (signed codes) in the query's residual: <= 2^-23 (|b| + 255 s) per coordinate
     ix->pca_eq_abs = static_cast<float>(std::sqrt(static_cast<double>(dcu)) * 1.2e-7 * (bmax + 255.0 * stepf) * 1.01);
-    ix->pca_ref_extra = decomp ? static_cast<float>(2.0 * std::fabs(static_cast<double>(ix->sq_bias)) * std::sqrt(static_cast<double>(d)) * 1.01) : 0.0f;
+    // inner product: ||x|| <= ||x - mean|| + ||mean|| enters the slack for the reference's own float32 rounding; scalar-quantized rows add 2 |bias| sqrt(d)
+    ix->pca_ref_extra = static_cast<float>(((l2 ? 0.0 : mean_norm) + (decomp ? 2.0 * std::fabs(static_cast<double>(ix->sq_bias)) * std::sqrt(static_cast<double>(d)) : 0.0)) * 1.01);
+    ix->pca_mean_norm = l2 ? 0.0f : static_cast<float>(mean_norm * 1.000001 + 1e-30);
     return SVSX_SUCCESS;
 }
 

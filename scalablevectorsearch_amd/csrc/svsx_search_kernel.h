@@ -55,13 +55,9 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
         // (float32 rows of 128 keep 8 x 16 bytes of a row in flight per lane: 6 waves would spill 92 bytes)
         if ((DS == 96 || DS == 128) && CODES == 2 && BIG == 0 && METRIC != M_COS) return (DT == DT_F32 && DS == 128) ? 4 : (DT == DT_F16 && DS == 96) ? 5 : 6;
         // any dimension, 32- / 64-byte records: <= 96
-#ifndef SVSX_FLOOR_DS0
-#define SVSX_FLOOR_DS0 5
-#endif
-        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES <= 3) return SVSX_FLOOR_DS0;
-#ifdef SVSX_FLOOR_DS0_C4
-        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES == 4) return SVSX_FLOOR_DS0_C4;
-#endif
+        // (a floor of 6 fits the float32 kernels of 64- / 128-byte records too -- 78-80 registers, 12 bytes of scratch for L2 at 128 -- and is slower:
+        // isotropic rows 2.63 -> 3.14 ms, G(48, 0.2) 1.58 -> 1.60; profiles/r06_notes.md)
+        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES <= 3) return 5;
     }
     // windows 513 .. 1024 with 128-byte records (config 4 at recall >= 0.9): 143 VGPRs instead of 181, no scratch -> 3 waves per SIMD instead of 2
     if (DS == 768 && BIG == 2 && CODES == 4 && (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS)) return 3;
@@ -256,6 +252,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     [[maybe_unused]] int fat_qq = 0;
     [[maybe_unused]] float fat_eq = 0.0f, fat_tq_hi = 0.0f, fat_tq_lo = 0.0f, fat_s2m = 0.0f, fat_nuh = 0.0f, fat_nq = 0.0f;
     [[maybe_unused]] const float fat_wunit = 1.0f / (a.sq_scale * a.sq_scale); // QM_SQ_L2: buffer distances -> code-space distances
+    [[maybe_unused]] float fat_qmu = 0.0f; // similarity metrics: upper bound of q . mean (records are centred, round 6)
     if constexpr (FAT) {
         constexpr int DC = FDC;
         const uint32_t ci = lane & 31u, half = lane >> 5; // lane -> coordinate ci (+ 32 per group), half of the element range
@@ -280,6 +277,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             }
         };
         float r2 = 0.0f, un2 = 0.0f, vv = 0.0f;
+        [[maybe_unused]] float qm = 0.0f; // similarity metrics: q . mean (the records are centred: q . x = q . (x - mean) + q . mean)
         int qq = 0;
         if (lane < 32u) qcodes[lane] = 0u;
         lds_order();
@@ -287,15 +285,19 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         for (int g = 0; g * 32 < DC; ++g) { // 32 coordinates per sweep over the query
             const float4* prow = reinterpret_cast<const float4*>(a.pca_t + static_cast<size_t>(ci + 32u * g) * a.pca_pd + half * hlen);
             float up = 0.0f, vvp = 0.0f;
+            [[maybe_unused]] float qmp = 0.0f;
 #pragma unroll 1
             for (int j0 = 0; j0 < hlen; j0 += 8) { // rolled: the projection must not raise the kernel's register peak
                 const float4 p0 = prow[j0 >> 2], p1 = prow[(j0 >> 2) + 1];
                 float4 v0, v1;
                 q8(j0, v0, v1);
+                const float4 m0 = *reinterpret_cast<const float4*>(mh + j0), m1 = *reinterpret_cast<const float4*>(mh + j0 + 4);
                 if constexpr (METRIC == M_L2) {
-                    const float4 m0 = *reinterpret_cast<const float4*>(mh + j0), m1 = *reinterpret_cast<const float4*>(mh + j0 + 4);
                     v0.x -= m0.x; v0.y -= m0.y; v0.z -= m0.z; v0.w -= m0.w;
                     v1.x -= m1.x; v1.y -= m1.y; v1.z -= m1.z; v1.w -= m1.w;
+                } else { // the query itself is not centred; its product with the centre is a constant of the query
+                    qmp = __builtin_fmaf(v0.x, m0.x, qmp); qmp = __builtin_fmaf(v0.y, m0.y, qmp); qmp = __builtin_fmaf(v0.z, m0.z, qmp); qmp = __builtin_fmaf(v0.w, m0.w, qmp);
+                    qmp = __builtin_fmaf(v1.x, m1.x, qmp); qmp = __builtin_fmaf(v1.y, m1.y, qmp); qmp = __builtin_fmaf(v1.z, m1.z, qmp); qmp = __builtin_fmaf(v1.w, m1.w, qmp);
                 }
                 up = __builtin_fmaf(p0.x, v0.x, up); up = __builtin_fmaf(p0.y, v0.y, up); up = __builtin_fmaf(p0.z, v0.z, up); up = __builtin_fmaf(p0.w, v0.w, up);
                 up = __builtin_fmaf(p1.x, v1.x, up); up = __builtin_fmaf(p1.y, v1.y, up); up = __builtin_fmaf(p1.z, v1.z, up); up = __builtin_fmaf(p1.w, v1.w, up);
@@ -304,6 +306,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
             }
             float u = up + __shfl_xor(up, 32);     // coordinate ci + 32 g (both halves of the wave hold it)
             vv = vvp + __shfl_xor(vvp, 32);        // ||v||^2 (the same in every sweep)
+            if constexpr (METRIC != M_L2) qm = qmp + __shfl_xor(qmp, 32);
             if constexpr (METRIC == M_COS) {
                 // cosine records hold UNIT vectors: work with the unit query q / ||q|| (two more roundings per coordinate, in `urel`)
                 u *= 1.0f / __builtin_sqrtf(vv);
@@ -331,6 +334,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                 reinterpret_cast<uint8_t*>(qcodes)[coord] = static_cast<uint8_t>(cint & 0xFF);
             }
         }
+        [[maybe_unused]] const float vv_raw = vv; // ||q||^2 as the sweeps accumulated it
         if constexpr (METRIC == M_COS) vv = vv > 0.0f ? 1.0f : vv; // a zero query gives NaN coordinates: the bound never fires
         for (int off = 32; off >= 1; off >>= 1) {
             r2 += __shfl_xor(r2, off);
@@ -366,6 +370,15 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         fat_s2m = a.pca_step * a.pca_step * (METRIC == M_L2 ? 0.99999f : 1.0f);
         fat_nuh = uni(a.pca_step * __builtin_sqrtf(static_cast<float>(qq)) * 1.00001f); // ||uhat|| (signed codes)
         fat_nq = uni(vn);
+        if constexpr (METRIC != M_L2) {
+            // an UPPER bound of q . mean (cosine: of (q / ||q||) . mean).  The two half-range fma chains and their sum carry at most
+            // (d / 2 + 2) 2^-24 ||q|| ||mean|| of rounding; the unit-query scaling of cosine two more roundings, and `vn` is ||q|| (cosine: 1)
+            // rounded up.  A non-finite query gives NaN here and the bound never fires.
+            float qmu = qm;
+            if constexpr (METRIC == M_COS) qmu *= 1.0f / __builtin_sqrtf(vv_raw);
+            const float qslack = (static_cast<float>(d / 2 + 6) * 5.9604645e-8f * 1.01f) * vn * a.pca_mean_norm;
+            fat_qmu = uni(qmu + qslack + __builtin_fabsf(qmu) * 1.2e-7f);
+        }
     }
 
     // f32 L2 rows of 65..128 dimensions: stop after the first two cache lines when the partial sum already rules the
@@ -644,7 +657,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         rej = fi * fat_s2m > rhs; // false for NaN / inf thresholds
                         rej_m = wave_ballot(fi * fat_s2m > rhs);
                     } else {
-                        // q . z <= s^2 I + ||uhat|| ex + eq (ny + ex) + tq tx,  I = sum cq cx (exact);  all record fields are upper bounds
+                        // q . z <= s^2 I + ||uhat|| ex + eq (ny + ex) + tq tx,  I = sum cq cx (exact), z = x - mean;  all record fields are upper bounds
                         int dot = 0;
 #pragma unroll
                         for (int w = 0; w < NW - 1; ++w) // word NW-2: codes in its low half, a float16 above -- the query's bytes there are 0
@@ -654,7 +667,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                         const float ny = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last & 0xFFFFu))) * a.pca_step;
                         const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last >> 16))) * a.pca_tail_unit;
                         const float pos = fat_nuh * ex + fat_eq * (ny + ex) + fat_tq_hi * tx;
-                        float ub = main + pos + (__builtin_fabsf(main) + pos) * 4.0e-6f;
+                        float ub = main + pos + (__builtin_fabsf(main) + pos) * 4.0e-6f; // >= q . (x - mean)  (cosine: of the unit vectors)
+                        ub = ub + fat_qmu + (__builtin_fabsf(ub) + __builtin_fabsf(fat_qmu)) * 1.2e-7f; // + q . mean: >= q . x
                         if constexpr (METRIC == M_COS) {
                             // records hold the UNIT vector and the query was scaled to unit norm: `ub` bounds the real cosine; the
                             // reference's float32 result is within (d + 8) 2^-24 of it (|cos| <= 1)

@@ -52,11 +52,14 @@ class Records:
             zs = z * scale[:, None]
         else:
             zs = z
+        # round 6: every metric is centred (cosine: the unit vectors; coordinates() normalises, then subtracts)
         self.mean = np.zeros(d, f32)
-        if l2 and mean_from_sample:
+        if mean_from_sample:
             self.mean = (zs.sum(0) / n).astype(f32)
-        zc = zs - self.mean.astype(f64) if not cosine else zs
-        # cosine: coordinates() subtracts the (zero) mean BEFORE normalising; same thing
+        zc = zs - self.mean.astype(f64)
+        mean_norm = np.sqrt((self.mean.astype(f64) ** 2).sum())
+        self.mean_norm = f32(0.0) if l2 else f32(mean_norm * 1.000001 + 1e-30)
+        degenerate = (nrm == 0) if cosine else np.zeros(n, bool)
         _, sv, vt = np.linalg.svd(zc - 0.0, full_matrices=False)
         q64 = np.zeros((dcu, d))
         q64[: min(dcu, vt.shape[0])] = vt[:dcu]
@@ -72,8 +75,6 @@ class Records:
         self.delta = f32(np.sqrt(((self.P[:dcu].astype(f64) - q64) ** 2).sum(1)).max() * 1.01 + 1e-9)
         y = zc @ q64.T  # [n, dcu] float64 coordinates
         n2 = (zc * zc).sum(1)
-        if cosine:
-            n2 = np.where(n2 > 0, 1.0, 0.0)
         ny2 = (y * y).sum(1)
         tail = np.sqrt(np.maximum(n2 - ny2, 0.0))
         lo = y.astype(f32).min(0).astype(f64)
@@ -112,7 +113,7 @@ class Records:
         e2 = ((y - yh) ** 2).sum(1)
         self.ex = f16_up(np.sqrt(e2) * inv * (1.0 + 1e-12))
         if cosine:
-            self.ex[n2 == 0.0] = np.uint16(0x7C00)
+            self.ex[degenerate] = np.uint16(0x7C00)
         if l2:
             with np.errstate(over="ignore"):
                 self.tx = (tail / f64(self.tail_unit)).astype(f32).astype(np.float16).view(np.uint16)  # nearest
@@ -121,7 +122,7 @@ class Records:
             self.ny = f16_up(np.sqrt((yh * yh).sum(1)) * inv * (1.0 + 1e-12))
             self.tx = f16_up(tail / f64(self.tail_unit) * (1.0 + 1e-12))
         self.eq_abs = f32(np.sqrt(f64(dcu)) * 1.2e-7 * (bmax + 255.0 * f64(step)) * 1.01)
-        self.ref_extra = f32(0.0)
+        self.ref_extra = f32(0.0) if l2 else f32(mean_norm * 1.01)  # inner product: ||x|| <= ||x - mean|| + ||mean||
 
 
 def fma32(a, b, c):
@@ -148,13 +149,18 @@ class Query:
         v = (qp - mp).astype(f32) if l2 else qp
         up = np.zeros((2, rec.dc), f32)
         vvp = np.zeros(2, f32)
+        qmp = np.zeros(2, f32)
         for half in range(2):
             for j in range(half * hlen, (half + 1) * hlen):
                 up[half] = fma32(Pp[:, j], np.broadcast_to(v[j], (rec.dc,)), up[half])
                 vvp[half] = fma32(v[j : j + 1], v[j : j + 1], vvp[half : half + 1])[0]
+                if not l2:
+                    qmp[half] = fma32(v[j : j + 1], mp[j : j + 1], qmp[half : half + 1])[0]
         with np.errstate(all="ignore"):
             u = (up[0] + up[1]).astype(f32)
             vv = f32(vvp[0] + vvp[1])
+            vv_raw = vv
+            qm = f32(qmp[0] + qmp[1])
             if cosine:
                 u = (u * f32(f32(1.0) / np.sqrt(vv, dtype=f32))).astype(f32)
             if l2:
@@ -194,6 +200,12 @@ class Query:
             if not (eq < 3.0e38) or not (tq_hi < 3.0e38):
                 eq = f32(np.inf)
                 tq_hi = f32(np.inf)
+            # upper bound of q . mean (cosine: of the unit query), as the kernel forms it
+            qmu = qm
+            if cosine:
+                qmu = f32(qmu * f32(f32(1.0) / np.sqrt(vv_raw, dtype=f32)))
+            qslack = f32(f32(f32(f32(f32(d // 2 + 6) * EPS24) * f32(1.01)) * vn) * rec.mean_norm)
+            self.qmu = f32(0.0) if l2 else f32(f32(qmu + qslack) + f32(np.abs(qmu) * f32(1.2e-7)))
         self.qq, self.eq, self.tq_hi, self.tq_lo = qq, eq, tq_hi, tq_lo
         self.s2m = f32(f32(rec.step * rec.step) * (f32(0.99999) if l2 else f32(1.0)))
         self.nuh = f32(f32(rec.step * np.sqrt(f32(qq), dtype=f32)) * f32(1.00001))
@@ -238,6 +250,7 @@ def rejected(qs: Query, worst, wunit=None):
         pos = ((qs.nuh * ex).astype(f32) + (qs.eq * (ny + ex).astype(f32)).astype(f32)).astype(f32)
         pos = (pos + (qs.tq_hi * tx).astype(f32)).astype(f32)
         ub = ((main + pos).astype(f32) + ((np.abs(main) + pos).astype(f32) * f32(4.0e-6)).astype(f32)).astype(f32)
+        ub = ((ub + qs.qmu).astype(f32) + ((np.abs(ub) + np.abs(qs.qmu)).astype(f32) * f32(1.2e-7)).astype(f32)).astype(f32)  # + q . mean
         if rec.metric == COS:
             ub = (ub + f32(f32(f32(rec.d + 8) * f32(6.3e-8)) + f32(1.0e-7))).astype(f32)
         else:
@@ -285,7 +298,7 @@ def _check(oracle, metric, x, q, rb, name, sq=None):
         codes, scale, bias = sq
         z = (f32(scale) * codes.astype(f32)).astype(f32) + f32(bias)  # scalar.h:44-46, multiply and add rounded separately
         rec = Records(z, metric, rb)
-        rec.ref_extra = f32(2.0 * abs(f64(bias)) * np.sqrt(f64(x.shape[1])) * 1.01)
+        rec.ref_extra = f32((f64(rec.ref_extra) / 1.01 + 2.0 * abs(f64(bias)) * np.sqrt(f64(x.shape[1]))) * 1.01)
         exact = x  # the caller passes the oracle's compressed distances [nq, n]
     fired = 0
     for qi in range(q.shape[0]):

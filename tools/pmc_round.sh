@@ -13,6 +13,8 @@ for t in $T; do
     c3) tools/collect_pmc.sh ${P}_c3_w128 --config c3 --n 1000000 --window 128 --codes 2 ;;
     c4) tools/collect_pmc.sh ${P}_c4_w285 --config c4 --n 2000000 --nq 4096 --window 285 --degree 128 --build-window 200 --codes 2 ;;
     c4full) tools/collect_pmc.sh ${P}_c4_10M --config c4 --n 10000000 --nq 4096 --window 285 --degree 128 --build-window 200 --codes 2 ;;
+    c4b) tools/collect_pmc.sh ${P}_c4b_10M --config c4b --n 10000000 --nq 4096 --window 1024 --matched --degree 128 --build-window 200 --codes 2 ;;
+    c4b2m) tools/collect_pmc.sh ${P}_c4b_2M --config c4b --n 2000000 --nq 4096 --window 1024 --matched --degree 128 --build-window 200 --codes 2 ;;
     c5) tools/collect_pmc.sh ${P}_c5shard --config c5 --n 12500000 --window 128 --codes 2 ;;
   esac
 done

@@ -26,7 +26,7 @@ if a.config == "c3":    # BASELINE config 3: sift-1M-like, float16 rows, float32
     x = deep_like_device(a.n, d, 32, seed=31, device=dev, normalize=False).half()
     q = deep_like_device(a.nq, d, 32, seed=32, device=dev, normalize=False)
     graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache, distance=fn, alpha=0.95, data_dtype=ddt)
-elif a.config == "c4":  # BASELINE config 4's row type: scalar-quantized int8 codes, float32 queries, cosine
+elif a.config in ("c4", "c4b"):  # BASELINE config 4's row type: scalar-quantized int8 codes, float32 queries, cosine (c4b: the same rows as raw int8, int8 queries)
     d, fn, ddt = 768, svs.DistanceCosineSimilarity(), np.int8
     q = deep_like_device(a.nq, d, 64, seed=2, device=dev, normalize=False)
     mn = mx = None  # two passes over the generator, 1 M rows at a time: the float32 rows of 10 M x 768 never exist at once (bench.config4_point)
@@ -40,7 +40,10 @@ elif a.config == "c4":  # BASELINE config 4's row type: scalar-quantized int8 co
         x[lo:lo + xf.shape[0]] = torch.clamp(torch.round((xf - bias) / scale), -128, 127).to(torch.int8)
     del xf
     sq = (scale, bias)
-    graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache, distance=fn, alpha=0.95, data_dtype=ddt, sq=sq, build_window=a.build_window)
+    graph, entry, _ = build_or_load_graph(svs, x, a.n, d, R, 0, cache.replace(".c4b.", ".c4."), distance=fn, alpha=0.95, data_dtype=ddt, sq=sq, build_window=a.build_window)
+    if a.config == "c4b":  # SURVEY 8d C4(b), as bench.config4b_point runs it: config 4's graph, the codes read as plain int8 vectors, int8 queries
+        q = torch.clamp(torch.round((q - bias) / scale), -128, 127).to(torch.int8)
+        sq = None
 else:
     d, fn, ddt, sq = 96, svs.DistanceL2(), np.float32, None
     x = deep_like_device(a.n, d, 24, seed=1 + 1000 * a.sid, device=dev)
