@@ -516,6 +516,78 @@ def spectrum_points(args, svs, device, local_rank, q_seed, k, R, headline):
     return out
 
 
+def regression_uint8_point(args, svs, device, local_rank, k):
+    """The data TYPE of the reference's own regression inputs (tools/benchmark_inputs/vamana/static-regression.toml: bigann uint8, L2, graph R = 128,
+    L = 200, prune_to 124): 1 M x 128 sift-like non-negative uint8 rows, uint8 queries -- the VNNI pair L2VNNIOp<int16_t,32> (euclidean.h:265-313), exact
+    int32 sums -- behind inline records over float(element) (round 6).  A row is ONE 128-byte line here, so a record saves one line per rejected
+    neighbour, not three."""
+    import torch
+
+    from scalablevectorsearch_amd.build import device_graph_to_svs
+
+    n, d, nq, R = 1_000_000, 128, args.nq, 128
+    t0 = time.time()
+    xf = deep_like_device(n, d, 32, seed=41, device=device, normalize=False).abs()
+    qf = deep_like_device(nq, d, 32, seed=42, device=device, normalize=False).abs()
+    gain = 218.0 / float(xf.max())  # sift's values reach 218
+    x = torch.clamp(torch.round(xf * gain), 0, 255).to(torch.uint8)
+    q = torch.clamp(torch.round(qf * gain), 0, 255).to(torch.uint8)
+    del xf, qf
+    graph, entry, tb = build_or_load_graph(svs, x, n, d, R, local_rank, "", data_dtype=np.uint8, build_window=200)
+    index = svs.VamanaIndex.from_device(graph, x, svs.DistanceL2(), torch.tensor([entry], dtype=torch.int32, device=device), n, d, np.uint8, device=local_rank)
+    gt, _ = index.flat_search_device(q, k)
+    torch.cuda.synchronize()
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(args.window), search_buffer_visited_set=args.visited)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=device)
+    dd = torch.empty((nq, k), dtype=torch.float32, device=device)
+    st = torch.zeros((nq, 6), dtype=torch.int32, device=device)
+
+    def timed(with_stats=False):
+        index.search_device(q, k, sp, d_ids64=ids, d_dists=dd, d_stats=st if with_stats else None)
+        for _ in range(max(args.warmup, 12)):
+            index.search_device(q, k, sp, d_ids64=ids, d_dists=dd)
+        torch.cuda.synchronize()
+        ev_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(5, args.steps // 2))]
+        for a_, b_ in ev_:
+            a_.record()
+            index.search_device(q, k, sp, d_ids64=ids, d_dists=dd)
+            b_.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev_]))
+
+    ms_plain = timed(with_stats=True)
+    ids_plain = ids.clone()
+    # mode 3 (round 6): inline records only where the size rule expects them to pay.  This synthetic set is |G(32, 0.1)| -- taking absolute values
+    # makes it full-rank -- and a 32-byte record (all a 128-byte row allows) rejects 0.07 % of its neighbours: forced records run at 0.80 x the plain
+    # kernel's rate (profiles/r06_notes.md), so the rule declines them and the point reports the plain kernel, which is then what a host gets.
+    chosen = index.build_bound_codes(3)
+    ms = timed(with_stats=True) if chosen else ms_plain
+    rb = int(index.memory()["record_size"])
+    lines = designed_lines(st.to(torch.int64), 128, d, 2 if chosen else 0, d, k, rb or 32)
+    point = {"bound_scheme_chosen_by_mode_3": "inline records" if chosen else "none (the size rule expects no saving on this spectrum)",
+             "workload": f"sift-like 1 M x 128 uint8 rows, uint8 queries, L2, batch={nq}, search_window={args.window}, k=10, graph R=128 L=200 prune_to 124 alpha 1.2 (static-regression.toml's data type), 1xMI355X",
+             "qps": nq / (ms * 1e-3), "kernel_ms": ms, "recall_at_10": recall_at(gt, ids, k), "kernel": "svsx::" + index.last_kernel_info(), "record_bytes": rb,
+             "expansions_per_query": int(st[:, 0].sum()) / nq, "distance_evals_per_query": int(st[:, 2].sum()) / nq, "bound_code_rejects_per_query": int(st[:, 5].sum()) / nq,
+             "reject_share": float(st[:, 5].sum()) / max(float(st[:, 2].sum()), 1.0), "designed_lines_per_query": lines["total"] / nq,
+             "frac_designed": lines["total"] * LINE / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "plain_kernel_ms": ms_plain, "speedup_over_plain_kernel": ms_plain / ms,
+             "ids_equal_plain_kernel": bool((ids == ids_plain).all()), "build_seconds": tb}
+    try:
+        from oracle.oracle import L2, Oracle, Ref
+
+        ns = 256
+        xh, gh = x.cpu().numpy(), device_graph_to_svs(graph, R)
+        chk = Ref() if Ref.available() else Oracle()
+        kw = {"nthreads": host_cores()} if Ref.available() else {}
+        ri, rd = chk.search(L2, xh, gh, np.array([entry], np.uint32), q[:ns].cpu().numpy(), k, args.window, **kw)
+        point["reference_sample"] = {"queries": ns, "checker": "oracle/_ref" if Ref.available() else "C oracle",
+                                     "ids_identical": bool((ri.astype(np.int64) == ids[:ns].cpu().numpy()).all()),
+                                     "distance_bits_identical": bool((rd.view(np.uint32) == dd[:ns].cpu().numpy().view(np.uint32)).all())}
+    except Exception as e:  # noqa: BLE001
+        point["reference_sample"] = {"error": f"{type(e).__name__}: {e}"}
+    point["seconds"] = time.time() - t0
+    return point
+
+
 def config4_point(args, svs, device, local_rank, k, t_run0):
     """BASELINE config 4 inside the default line: synthetic N x 768 scalar-quantized int8 rows (SQDataset-style global scale / bias, scalar.h:454-462),
     float32 queries, cosine, batch 4 096, the reference's regression graph parameters (R = 128, L = 200, prune_to 124, alpha 0.95).  N = --c4-n
@@ -1276,6 +1348,12 @@ def main():
                 del g128, i128, ids128, dd128, st128
             except Exception as e:  # informational: never fail the line over it
                 log(f"[bench] config-2 R=128 point skipped: {e}")
+            try:
+                result["config"].setdefault("other_configs", {})["regression_uint8_r128"] = regression_uint8_point(args, svs, device, local_rank, k)
+            except Exception as e:  # informational: never fail the line over it
+                result["config"].setdefault("other_configs", {})["regression_uint8_r128"] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"[bench] uint8 regression point failed: {e}")
+            torch.cuda.empty_cache()
             try:
                 if args.c4_n > 0:
                     result["config"].setdefault("other_configs", {})["c4"] = config4_point(args, svs, device, local_rank, k, t_run0)

@@ -84,7 +84,8 @@ constexpr int kRecordsDoNotFit = -1000; // build_fat_rows: not even 32-byte reco
 
 // graph-inline records: sample -> leading principal directions (host, f64) -> per-vector records (device) -> node rows (device).
 // *asked_rb / *built_rb: the record size the spectrum rule (or the caller) wanted and the one that fitted the free HBM.
-int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint32_t* built_rb) {
+constexpr int kRecordsDoNotPay = -1001; // build_fat_rows(only_if_worth): the size rule expects no saving over the plain kernel on this data
+int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint32_t* built_rb, bool only_if_worth) {
     const uint32_t d = static_cast<uint32_t>(ix->d), n = static_cast<uint32_t>(ix->n);
     const size_t es = dtype_size(ix->data_dtype);
     const bool l2 = ix->metric == M_L2, cosine = ix->metric == M_COS;
@@ -229,6 +230,13 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
             rb = r;
         }
     }
+    // mode 3: the same estimate for the plain kernel (ids + every neighbour's row); records that are not expected to save a tenth of the lines are
+    // not built -- on full-rank data under a weak bound they cost more than they save (1 M x 128 sift-like uint8, L2: 0.07 % rejected, 0.80 x the
+    // plain kernel's rate; profiles/r06_notes.md)
+    if (only_if_worth && forced_rb == 0) {
+        const double plain_cost = static_cast<double>(ix->gstride) * 4.0 / 128.0 + cand * static_cast<double>((ix->row_bytes + 127) / 128);
+        if (best_cost > 0.9 * plain_cost) return kRecordsDoNotPay;
+    }
     if (forced_rb != 0) { // the caller asked for this record size (svsx_index_build_bound_codes mode 32 / 64 / 128)
         if (forced_rb > rb_max) return fail(SVSX_INVALID_ARGUMENT, "records of %u bytes exceed a third of the %zu-byte rows they protect", forced_rb, ix->row_bytes);
         rb = forced_rb;
@@ -256,6 +264,9 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
         }
         sigma[c] = std::sqrt(std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0));
     }
+    // (Tried in round 6 and removed: putting the unit mean direction into the basis so that a query's offset component is a coded coordinate instead of
+    // part of its remainder.  The query's coordinate along it lies far outside the 8-bit range of the CENTRED rows' coordinates, its code clamps,
+    // the coding error eq swallows the bound: 5 907 -> 0 rejects on the offset cosine set of tools/offset_ab.py; profiles/r06_notes.md.)
     orthonormalize_columns(Q, d, dcu);
     // device copies: float32 rows for the query side (+ delta = how far they are from the f64 directions), f64 rows for the data side
     std::vector<float> host(static_cast<size_t>(kPcaRows) * pd + pd + 128, 0.0f); // P | mean | bias
@@ -369,7 +380,12 @@ extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
         forced_rb = static_cast<uint32_t>(mode);
         mode = 2;
     }
-    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows), 2 (graph-inline records) or 32 / 64 / 128 (inline records of that size)");
+    bool only_if_worth = false;
+    if (mode == 3) { // graph-inline records where the size rule expects them to pay, nothing where it does not
+        only_if_worth = true;
+        mode = 2;
+    }
+    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows), 2 (graph-inline records), 3 (records where they are expected to pay) or 32 / 64 / 128 (inline records of that size)");
     bool fell_from_records = false;
     HIP_TRY(hipSetDevice(ix->device));
     std::lock_guard<std::mutex> lock(ix->shadow_mutex);
@@ -385,7 +401,11 @@ extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
         // then take the record kernels is the dispatch's business (svsx_search_kernel.h launch_dim); the others run the plain kernels.
         if (ix->d < 32 || ix->d > 4096 || !ix->d_graph) return fail(SVSX_NOT_IMPLEMENTED, "graph-inline records cover graph indexes of dimension 32..4096");
         uint32_t asked = 0, built = 0;
-        const int rc = build_fat_rows(ix, forced_rb, &asked, &built);
+        const int rc = build_fat_rows(ix, forced_rb, &asked, &built, only_if_worth);
+        if (rc == kRecordsDoNotPay) { // not a failure and not a fallback: the answer of mode 3 on this data is "no scheme" (svsx_index_memory()[8] == 0)
+            (void)fail(SVSX_SUCCESS, "mode 3: the spectrum of this data promises no saving from inline records: none built");
+            return SVSX_SUCCESS;
+        }
         if (rc == SVSX_SUCCESS && built == asked) return SVSX_SUCCESS;
         if (rc == SVSX_SUCCESS) // smaller records than the spectrum rule / the caller wanted: still inline records, still result-neutral
             return fail(SVSX_FELL_BACK, "graph-inline records of %u bytes do not fit the free HBM: built %u-byte records instead", asked, built);

@@ -435,3 +435,25 @@ def test_records_that_do_not_fit_the_free_hbm_fall_back(svs):
         got = idx.search(q, 10, sp)
         assert (got.indices == want.indices).all() and (_bits(got.distances) == _bits(want.distances)).all()
     torch.cuda.empty_cache()
+
+
+def test_mode_3_builds_records_only_where_they_are_expected_to_pay(svs, oracle, small_world):
+    """svsx_index_build_bound_codes(index, 3): the size rule's own estimate decides between inline records and nothing -- low-rank rows get
+    records, full-rank uint8 rows of one line each (a 32-byte record is all they allow, and it says nothing) get none; results are the oracle's
+    either way, and mode 2 still builds records on the same index when asked to."""
+    sw = small_world
+    idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
+    assert idx.build_bound_codes(3) == 2 and idx.memory()["record_size"] == 32
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 256, (1500, 128)).astype(np.uint8)
+    q = rng.integers(0, 256, (32, 128)).astype(np.uint8)
+    g, e = oracle.build_vamana(L2, x.astype(np.float32), R=24, L=40)
+    idx = svs.VamanaIndex(g, x, svs.DistanceL2(), e)
+    assert idx.build_bound_codes(3) == 0 and idx.memory()["bound_mode"] == 0 and idx.memory()["inline_record_bytes"] == 0
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(32), 1)
+    ids, dists = oracle.search(L2, x, g, e, q, 10, 32)
+    res = idx.search(q, 10, sp)
+    assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all() and "codes=0>" in idx.last_kernel_info()
+    assert idx.build_bound_codes(2) == 2  # asked for explicitly: built, still result-neutral
+    res = idx.search(q, 10, sp)
+    assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all() and "codes=2>" in idx.last_kernel_info()
