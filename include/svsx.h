@@ -383,8 +383,10 @@ int svsx_get_distance(const svsx_index* index, uint64_t id, const void* query, i
  *                 When that does not fit the free HBM the call does NOT fail: it builds smaller records (64, 32 bytes), then mode 1 where the
  *                 row type has it, then nothing, and returns SVSX_FELL_BACK (svsx_last_error() names what was built).
  *   mode 3        mode 2 where the size rule expects the records to save at least a tenth of the lines per hop, NOTHING where it does not (full-rank
- *                 data whose leading directions carry too little: a bound that rejects nothing costs its block lines for nothing); SVSX_SUCCESS
- *                 either way, svsx_index_memory()[8] tells which.  The default a host should use when it does not know its data.
+ *                 data whose leading directions carry too little: a bound that rejects nothing costs its block lines for nothing).  Indexes of
+ *                 >= 100 000 vectors get a second opinion: the records are timed against the plain kernel on 2 048 of the index's own rows as
+ *                 queries and kept only if faster.  SVSX_SUCCESS either way, svsx_index_memory()[8] tells which, svsx_last_error() why.
+ *                 The default a host should use when it does not know its data.
  *   mode 32 / 64 / 128   the same as mode 2 with exactly this record size (refused when larger than a third of the rows it protects)
  *   mode 1        one 128-byte row per vector: 8-bit codes of its first min(d, 120) components + exact coding error (float32 / float16
  *                 rows, L2, d = 96 or 128; +128 B per vector, one extra line per candidate).  For indexes whose inline rows do not fit.

@@ -373,6 +373,66 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
 
 } // namespace
 
+namespace {
+
+// Mode 3's second opinion: the size rule is a model (share of the second moment -> expected rejects), and it can be wrong -- under the similarity
+// metrics it does not see how much of a QUERY lies outside the coded directions.  So the records it decided to build are timed against the plain
+// kernel on a sample of the index's own rows as queries (2 048 rows, window 64, the row's own element type; float32 for scalar-quantized rows),
+// and kept only if they are faster by 5 %.  Small indexes are launch-latency bound and are not timed.  Returns 1 keep, 0 drop; errors keep.
+int records_pay_on_a_sample(svsx_index* ix) {
+    if (ix->n < 100000 || !ix->d_fat) return 1;
+    const size_t nq = 2048, k = 10, d = ix->d;
+    const int q_dtype = ix->sq_enabled ? DT_F32 : ix->data_dtype;
+    const size_t qes = dtype_size(q_dtype), es = dtype_size(ix->data_dtype), step = ix->n / nq;
+    DeviceBuffer dq, di, dd;
+    if (dq.alloc(nq * d * qes) != hipSuccess || di.alloc(nq * k * 8) != hipSuccess || dd.alloc(nq * k * 4) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    if (!ix->sq_enabled) {
+        if (hipMemcpy2D(dq.p, d * es, ix->d_data, step * ix->row_bytes, d * es, nq, hipMemcpyDeviceToDevice) != hipSuccess) return 1;
+    } else { // the queries of a scalar-quantized index are float vectors: the rows' decompressed values (scalar.h:44-46)
+        std::vector<unsigned char> raw(nq * d);
+        std::vector<float> qf(nq * d);
+        if (hipMemcpy2D(raw.data(), d, ix->d_data, step * ix->row_bytes, d, nq, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        for (size_t i = 0; i < nq * d; ++i) {
+            const float c = ix->data_dtype == DT_I8 ? static_cast<float>(static_cast<int8_t>(raw[i])) : static_cast<float>(raw[i]);
+            qf[i] = ix->sq_scale * c + ix->sq_bias;
+        }
+        if (hipMemcpy(dq.p, qf.data(), qf.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    }
+    svsx_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.search_window_size = 64;
+    sp.search_buffer_capacity = 64;
+    sp.visited_set = 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    auto best_of = [&](float& ms) -> bool {
+        ms = 1e30f;
+        for (int rep = 0; rep < 5; ++rep) { // two warm-ups, three timed
+            if (hipEventRecord(e0, nullptr) != hipSuccess) return false;
+            if (svsx_search_device(ix, dq.p, q_dtype, nq, k, &sp, static_cast<uint64_t*>(di.p), nullptr, static_cast<float*>(dd.p), nullptr, nullptr) != SVSX_SUCCESS) return false;
+            if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return false;
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return false;
+            if (rep >= 2 && t < ms) ms = t;
+        }
+        return true;
+    };
+    float t_rec = 0.0f, t_plain = 0.0f;
+    bool ok = best_of(t_rec);
+    void* fat = ix->d_fat;
+    ix->d_fat = nullptr; // the same index without its records = the plain kernel
+    ok = best_of(t_plain) && ok;
+    ix->d_fat = fat;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) return 1;
+    ix->calib_ms_records = t_rec;
+    ix->calib_ms_plain = t_plain;
+    return t_rec < 0.95f * t_plain ? 1 : 0;
+}
+
+} // namespace
+
 extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
     if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
     uint32_t forced_rb = 0;
@@ -404,6 +464,13 @@ extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
         const int rc = build_fat_rows(ix, forced_rb, &asked, &built, only_if_worth);
         if (rc == kRecordsDoNotPay) { // not a failure and not a fallback: the answer of mode 3 on this data is "no scheme" (svsx_index_memory()[8] == 0)
             (void)fail(SVSX_SUCCESS, "mode 3: the spectrum of this data promises no saving from inline records: none built");
+            return SVSX_SUCCESS;
+        }
+        if (rc == SVSX_SUCCESS && only_if_worth && records_pay_on_a_sample(ix) == 0) { // the model said yes, the clock says no
+            (void)hipFree(ix->d_fat);
+            ix->d_fat = nullptr;
+            (void)fail(SVSX_SUCCESS, "mode 3: inline records of %u bytes ran at %.3f ms against %.3f ms for the plain kernel on a sample of the index's own rows: not kept",
+                       built, ix->calib_ms_records, ix->calib_ms_plain);
             return SVSX_SUCCESS;
         }
         if (rc == SVSX_SUCCESS && built == asked) return SVSX_SUCCESS;

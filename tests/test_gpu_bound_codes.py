@@ -457,3 +457,48 @@ def test_mode_3_builds_records_only_where_they_are_expected_to_pay(svs, oracle, 
     assert idx.build_bound_codes(2) == 2  # asked for explicitly: built, still result-neutral
     res = idx.search(q, 10, sp)
     assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all() and "codes=2>" in idx.last_kernel_info()
+
+
+def test_mode_3_times_its_records_on_indexes_large_enough_to_time(svs):
+    """indexes of >= 100 000 vectors: mode 3 times the records it built against the plain kernel on a sample of the index's own rows and keeps
+    them only if faster.  On the headline's kind of data (low-rank float32 rows, L2) they are 3 x faster and must be kept; on uint8 rows around
+    an offset under inner product the bound is weak (tools/offset_ab.py: 0.78 ms plain, 0.99 ms with records at 1 M) and whatever the clock
+    decides, the answers stay those of the plain kernel."""
+    import torch
+
+    from bench import deep_like_device
+    from scalablevectorsearch_amd.build import VamanaBuildParameters, build_vamana_device
+
+    dev = torch.device("cuda", 0)
+    n, k = 200_000, 10
+    sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(48), 1)
+    x = deep_like_device(n, 96, 24, 1, dev)
+    q = deep_like_device(512, 96, 24, 2, dev)
+    g, e = build_vamana_device(x, n, 96, svs.DistanceL2(), VamanaBuildParameters(alpha=1.2, graph_max_degree=32, window_size=64, prune_to=28))
+    idx = svs.VamanaIndex.from_device(g, x, svs.DistanceL2(), torch.tensor([e], dtype=torch.int32, device=dev), n, 96, np.float32)
+    ia = torch.empty((512, k), dtype=torch.int64, device=dev)
+    da = torch.empty((512, k), dtype=torch.float32, device=dev)
+    idx.search_device(q, k, sp, d_ids64=ia, d_dists=da)
+    torch.cuda.synchronize()
+    assert idx.build_bound_codes(3) == 2, "records on low-rank float32 rows must survive the timing"
+    ib, db = torch.empty_like(ia), torch.empty_like(da)
+    idx.search_device(q, k, sp, d_ids64=ib, d_dists=db)
+    torch.cuda.synchronize()
+    assert (ia == ib).all() and (da.view(torch.int32) == db.view(torch.int32)).all() and "codes=2>" in idx.last_kernel_info()
+    xf = deep_like_device(n, 128, 32, 31, dev, normalize=False)
+    gain = 100.0 / float(xf.abs().max())
+    xu = torch.clamp(torch.round(xf * gain + 128), 0, 255).to(torch.uint8)
+    qu = torch.clamp(torch.round(deep_like_device(512, 128, 32, 32, dev, normalize=False) * gain + 128), 0, 255).to(torch.uint8)
+    g, e = build_vamana_device(xu, n, 128, svs.DistanceIP(), VamanaBuildParameters(alpha=0.95, graph_max_degree=32, window_size=64, prune_to=28), data_dtype=np.uint8)
+    idx = svs.VamanaIndex.from_device(g, xu, svs.DistanceIP(), torch.tensor([e], dtype=torch.int32, device=dev), n, 128, np.uint8)
+    ids0 = torch.empty((512, k), dtype=torch.int64, device=dev)
+    d0 = torch.empty((512, k), dtype=torch.float32, device=dev)
+    idx.search_device(qu, k, sp, d_ids64=ids0, d_dists=d0)
+    torch.cuda.synchronize()
+    chosen = idx.build_bound_codes(3)
+    assert chosen in (0, 2) and idx.memory()["bound_mode"] == chosen
+    ids1 = torch.empty_like(ids0)
+    d1 = torch.empty_like(d0)
+    idx.search_device(qu, k, sp, d_ids64=ids1, d_dists=d1)
+    torch.cuda.synchronize()
+    assert (ids0 == ids1).all() and (d0.view(torch.int32) == d1.view(torch.int32)).all()
