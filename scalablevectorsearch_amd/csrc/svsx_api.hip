@@ -458,7 +458,10 @@ static int search_host_pipelined(
     // (pageable) arrays and the device staging: the runtime's own pipelined bounce (1.5 MB in 41 us, 3.8 MB in 92 us on the bench host)
     // beats memcpy into a page-locked mirror followed by the DMA (33 + 37 us, 79 + 76 us; profiles/r04_notes.md section 6).
     // (three chunks 2 048 + 4 096 + rest with direct copies: 1.30-1.31 ms against 1.25-1.27, profiles/r04_notes.md section 6)
-    size_t first = nq > 4096 ? 4096 : nq;
+#ifndef SVSX_HOST_FIRST
+#define SVSX_HOST_FIRST 4096
+#endif
+    size_t first = nq > SVSX_HOST_FIRST ? SVSX_HOST_FIRST : nq;
     if (first < nq) {
         nc = 2;
         bounds[1] = first;
@@ -486,6 +489,14 @@ static int search_host_pipelined(
     const size_t q_row = ix->d * dtype_size(q_dtype);
     c->dirty = true; // from here on an early return leaves copies / kernels in flight: the lease drains the streams before the context is reused
     auto dptr = [&](int r, size_t row) -> void* { return r < 0 ? nullptr : static_cast<unsigned char*>(c->d_out) + regions[r].offset + regions[r].row_bytes * row; };
+#ifdef SVSX_DIAG_HOST
+    const auto t_begin = std::chrono::steady_clock::now();
+    double stamp_us[16];
+    int n_stamp = 0;
+#define SVSX_HOST_STAMP() stamp_us[n_stamp++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count()
+#else
+#define SVSX_HOST_STAMP()
+#endif
     for (int i = 0; i < nc; ++i) {
         const size_t lo = bounds[i], cnt = bounds[i + 1] - lo;
         if (cnt == 0) continue;
@@ -493,6 +504,7 @@ static int search_host_pipelined(
         void* dq = static_cast<unsigned char*>(c->d_in) + q_stride * lo;
         // never past the caller's last row
         HIP_TRY(hipMemcpyAsync(dq, static_cast<const unsigned char*>(queries) + q_stride * lo, q_stride * (cnt - 1) + q_row, hipMemcpyHostToDevice, st));
+        SVSX_HOST_STAMP();
         svsx_search_aux daux;
         memset(&daux, 0, sizeof(daux));
         daux.query_row_stride_bytes = q_stride;
@@ -506,6 +518,7 @@ static int search_host_pipelined(
             for (int j = 0; j <= i; ++j) (void)hipStreamSynchronize(c->streams[j]);
             return rc;
         }
+        SVSX_HOST_STAMP();
     }
     // results: a copy into pageable memory returns when it has happened, so they are requested only after every launch is enqueued
     for (int i = 0; i < nc; ++i) {
@@ -516,8 +529,20 @@ static int search_host_pipelined(
             HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(regions[r].host) + regions[r].row_bytes * lo, static_cast<unsigned char*>(c->d_out) + off,
                                    regions[r].row_bytes * cnt, hipMemcpyDeviceToHost, c->streams[i]));
         }
+        SVSX_HOST_STAMP();
         HIP_TRY(hipStreamSynchronize(c->streams[i]));
+        SVSX_HOST_STAMP();
     }
+#ifdef SVSX_DIAG_HOST
+    {   // diagnostic builds only: host-side time line of the call, us since its start: per chunk [copy in, launch], then per chunk [results requested, stream idle]
+        static std::atomic<int> calls{0};
+        if (calls.fetch_add(1) % 4 == 3) {
+            fprintf(stderr, "[svsx host] nc=%d", nc);
+            for (int j = 0; j < n_stamp; ++j) fprintf(stderr, " %.0f", stamp_us[j]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     c->dirty = false; // every stream has been synchronised
     return SVSX_SUCCESS;
 }

@@ -46,11 +46,11 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_pmc_summaries_are_stamped_and_consistent():
-    """each committed round-5 PMC summary names its workload and the kernel sources it was measured on, its traffic agrees with the designed
+    """each committed round-6 PMC summary names its workload and the kernel sources it was measured on, its traffic agrees with the designed
     bytes of the same launches (no wasted re-reads), and the kernel trace of the profiled process agrees with that process's own HIP-event time
     (within 5 %: the tracer adds ~10-30 us per dispatch, 3 % of a 0.31 ms launch)"""
     shas = set()
-    for tag in ("r05_c2_w128", "r05_c2_matched", "r05_c5shard", "r05_c3_w128", "r05_c4_w285"):
+    for tag in ("r06_c2_w128", "r06_c2_matched", "r06_c5shard", "r06_c3_w128", "r06_c4_10M", "r06_c4b_10M"):
         j = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
         assert len(j["kernel_src_sha"]) == 16 and j["workload_key"].count(":") >= 6
         shas.add(j["kernel_src_sha"])
@@ -64,7 +64,7 @@ def test_pmc_summaries_are_stamped_and_consistent():
     sys.path.insert(0, ROOT)
     from bench import kernel_src_sha
 
-    assert shas == {kernel_src_sha()}, "the committed PMC summaries belong to other kernel sources: re-collect (tools/pmc_round.sh r05)"
+    assert shas == {kernel_src_sha()}, "the committed PMC summaries belong to other kernel sources: re-collect (tools/pmc_round.sh r06)"
 
 
 def test_counter_generator_is_reproducible():

@@ -20,6 +20,11 @@ if [ ! -d $R/gpurun_out/pmc_calib ]; then
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_calib -o p -- python $R/tools/pmc_calib.py > $R/gpurun_out/pmc_calib.log 2>&1
 fi
 cd $R
-# keep the merged-back payload small: drop the per-dispatch kernel-trace CSVs of the PMC passes
+# keep the merged-back payload small (gpurun merges at most 64 MiB back): drop the per-dispatch kernel-trace CSVs of the PMC passes, and of the
+# other CSVs keep the header and the rows of the search kernel only (a 10 M-vector target also traces the graph builder's ~10^5 dispatches)
 find $OUT $R/gpurun_out/pmc_calib -name "p_kernel_trace.csv" -delete
+for f in $(find $OUT -name "*counter_collection.csv" -o -name "t_kernel_trace.csv"); do
+  (head -1 $f; grep search_kernel $f) > $f.tmp && mv $f.tmp $f
+done
+find $OUT -name "*agent_info.csv" -delete
 # summarise locally after the merge: python tools/summarize_pmc.py $TAG
