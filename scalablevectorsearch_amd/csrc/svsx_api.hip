@@ -280,6 +280,7 @@ static SearchArgs base_search_args(const svsx_index* ix, const void* d_queries, 
         a.pca_delta = ix->pca_delta;
         a.pca_ref_extra = ix->pca_ref_extra;
         a.pca_mean_norm = ix->pca_mean_norm;
+        a.pca_mean_dir = ix->pca_mean_dir;
         a.pca_eq_abs = ix->pca_eq_abs;
     }
     return a;

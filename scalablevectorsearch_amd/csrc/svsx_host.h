@@ -55,6 +55,7 @@ struct svsx_index {
     uint32_t fat_degshift = 0; // 26 when the blocks' id words carry the neighbours' degree classes (n <= 2^26), else 0
     float* d_pca = nullptr;      // [32][dpad] leading directions (float32, row-major, zero padded) | [dpad] mean | [32] bias
     float pca_step = 1.0f, pca_tail_unit = 1.0f, pca_delta = 0.0f, pca_eq_abs = 0.0f, pca_ref_extra = 0.0f, pca_mean_norm = 0.0f;
+    uint32_t pca_mean_dir = 0;   // similarity metrics: coordinate 0 of the basis is the unit mean direction; the kernel keeps the query's coordinate 0 in float32
     float calib_ms_records = 0.0f, calib_ms_plain = 0.0f; // mode 3's timing of records against the plain kernel (svsx_records.hip)
     // host-pointer calls (svsx_search): persistent staging contexts, one per concurrent caller (HostCallContext below)
     mutable std::mutex ctx_mutex;

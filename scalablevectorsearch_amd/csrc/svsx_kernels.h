@@ -56,6 +56,7 @@ struct SearchArgs {
     float pca_eq_abs;         // absolute slack of the query coding error (rounding of b + s c)
     float pca_ref_extra;      // inner product: ||mean|| (+ 2 |bias| sqrt(d) for scalar-quantized rows), enters the slack for the reference's own rounding
     float pca_mean_norm;      // similarity metrics: >= ||mean|| (the records are centred; the kernel adds q . mean to its bound); 0 under L2
+    uint32_t pca_mean_dir;    // similarity metrics: 1 = coordinate 0 of the basis is the unit mean direction and the QUERY's coordinate 0 stays in float32 (not coded)
     // cancellation (index/vamana/index.h:541-545, greedy_search.h:155): device word polled once per expansion; non-zero = stop
     const int* cancel;
     // general variant of the kernel (std::sort-exact entry initialisation for > 16 entry points; BatchIterator state)

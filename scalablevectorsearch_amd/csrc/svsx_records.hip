@@ -264,9 +264,29 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
         }
         sigma[c] = std::sqrt(std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0));
     }
-    // (Tried in round 6 and removed: putting the unit mean direction into the basis so that a query's offset component is a coded coordinate instead of
-    // part of its remainder.  The query's coordinate along it lies far outside the 8-bit range of the CENTRED rows' coordinates, its code clamps,
-    // the coding error eq swallows the bound: 5 907 -> 0 rejects on the offset cosine set of tools/offset_ab.py; profiles/r06_notes.md.)
+    // Similarity metrics on data with a common offset (round 6).  The records describe x - mean but the QUERY is not centred: its component along
+    // the mean direction -- large whenever the data has a large mean -- would sit in its uncoded remainder tq and blow up the tq tx term of the
+    // bound (Cauchy-Schwarz), and as a CODED coordinate it would lie far outside the 8-bit range of the centred rows' coordinates (its code clamps,
+    // the coding error eq swallows the bound: measured, profiles/r06_notes.md section 8).  So when the mean is not negligible against the spread,
+    // the unit mean direction becomes coordinate 0 of the basis (in place of the weakest coded direction; Gram-Schmidt keeps it and cleans the
+    // others) and the kernel keeps the QUERY's coordinate 0 in float32 instead of coding it (SearchArgs::pca_mean_dir): u0 * s * c0(row) next to the
+    // integer dot product of the other coordinates.  Any orthonormal set is valid for the bound.
+    bool mean_dir = false;
+    if (!l2 && dcu >= 2 && mean_norm * mean_norm > 0.01 * trace) {
+        mean_dir = true;
+        for (uint32_t i = 0; i < d; ++i) {
+            for (uint32_t c = dcu - 1; c >= 1; --c) Q[static_cast<size_t>(i) * dcu + c] = Q[static_cast<size_t>(i) * dcu + c - 1];
+            Q[static_cast<size_t>(i) * dcu] = static_cast<double>(mean_f[i]) / mean_norm;
+        }
+        for (uint32_t c = dcu - 1; c >= 1; --c) sigma[c] = sigma[c - 1];
+        double var0 = 0.0; // spread of the centred sample along the mean direction: m^T C m
+        for (uint32_t i = 0; i < d; ++i) {
+            double ci = 0.0;
+            for (uint32_t j = 0; j < d; ++j) ci += cov[static_cast<size_t>(i) * d + j] * static_cast<double>(mean_f[j]) / mean_norm;
+            var0 += ci * static_cast<double>(mean_f[i]) / mean_norm;
+        }
+        sigma[0] = std::sqrt(std::max(var0, 0.0));
+    }
     orthonormalize_columns(Q, d, dcu);
     // device copies: float32 rows for the query side (+ delta = how far they are from the f64 directions), f64 rows for the data side
     std::vector<float> host(static_cast<size_t>(kPcaRows) * pd + pd + 128, 0.0f); // P | mean | bias
@@ -368,6 +388,7 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
     // inner product: ||x|| <= ||x - mean|| + ||mean|| enters the slack for the reference's own float32 rounding; scalar-quantized rows add 2 |bias| sqrt(d)
     ix->pca_ref_extra = static_cast<float>(((l2 ? 0.0 : mean_norm) + (decomp ? 2.0 * std::fabs(static_cast<double>(ix->sq_bias)) * std::sqrt(static_cast<double>(d)) : 0.0)) * 1.01);
     ix->pca_mean_norm = l2 ? 0.0f : static_cast<float>(mean_norm * 1.000001 + 1e-30);
+    ix->pca_mean_dir = mean_dir ? 1u : 0u;
     return SVSX_SUCCESS;
 }
 

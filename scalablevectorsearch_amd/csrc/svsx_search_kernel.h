@@ -253,6 +253,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     [[maybe_unused]] float fat_eq = 0.0f, fat_tq_hi = 0.0f, fat_tq_lo = 0.0f, fat_s2m = 0.0f, fat_nuh = 0.0f, fat_nq = 0.0f;
     [[maybe_unused]] const float fat_wunit = 1.0f / (a.sq_scale * a.sq_scale); // QM_SQ_L2: buffer distances -> code-space distances
     [[maybe_unused]] float fat_qmu = 0.0f; // similarity metrics: upper bound of q . mean (records are centred, round 6)
+    [[maybe_unused]] float fat_u0s = 0.0f; // similarity metrics, mean direction as coordinate 0: (query's coordinate 0) x step
     if constexpr (FAT) {
         constexpr int DC = FDC;
         const uint32_t ci = lane & 31u, half = lane >> 5; // lane -> coordinate ci (+ 32 per group), half of the element range
@@ -278,6 +279,7 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         };
         float r2 = 0.0f, un2 = 0.0f, vv = 0.0f;
         [[maybe_unused]] float qm = 0.0f; // similarity metrics: q . mean (the records are centred: q . x = q . (x - mean) + q . mean)
+        [[maybe_unused]] float u0 = 0.0f; // similarity metrics with the mean direction as coordinate 0: the query's coordinate along it (lane 0 of the first sweep)
         int qq = 0;
         if (lane < 32u) qcodes[lane] = 0u;
         lds_order();
@@ -320,6 +322,12 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     c = c < 0.0f ? 0.0f : (c > 255.0f ? 255.0f : c);
                     if (!(c == c)) c = 0.0f;
                     uh = b + a.pca_step * c;
+                } else if (coord == 0u && a.pca_mean_dir != 0u) {
+                    // the unit mean direction (svsx_records.hip): the query's coordinate along it is kept in float32, not coded -- it lies far outside
+                    // the code range of the centred rows.  No code (the integer dot product skips it), no coding residual.
+                    c = 0.0f;
+                    uh = u;
+                    u0 = u;
                 } else {
                     c = __builtin_rintf(u / a.pca_step);
                     c = c < -127.0f ? -127.0f : (c > 127.0f ? 127.0f : c);
@@ -369,6 +377,13 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         fat_tq_lo = uni(tq_lo);
         fat_s2m = a.pca_step * a.pca_step * (METRIC == M_L2 ? 0.99999f : 1.0f);
         fat_nuh = uni(a.pca_step * __builtin_sqrtf(static_cast<float>(qq)) * 1.00001f); // ||uhat|| (signed codes)
+        if constexpr (METRIC != M_L2) {
+            if (a.pca_mean_dir != 0u) { // uhat = (u0, s c_1, s c_2, ...): the float32 coordinate joins the norm; u0 * s multiplies the row's code 0
+                const float u0u = uni(u0); // lane 0 holds it (coordinate ci = 0 of sweep 0, half 0)
+                fat_nuh = uni(__builtin_sqrtf(fat_nuh * fat_nuh + u0u * u0u) * 1.00001f);
+                fat_u0s = uni(u0u * a.pca_step);
+            }
+        }
         fat_nq = uni(vn);
         if constexpr (METRIC != M_L2) {
             // an UPPER bound of q . mean (cosine: of (q / ||q||) . mean).  The two half-range fma chains and their sum carry at most
@@ -662,7 +677,9 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
 #pragma unroll
                         for (int w = 0; w < NW - 1; ++w) // word NW-2: codes in its low half, a float16 above -- the query's bytes there are 0
                             dot = __builtin_amdgcn_sdot4(static_cast<int>(recw(w)), static_cast<int>(qw[w]), dot, false);
-                        const float main = fat_s2m * static_cast<float>(dot);
+                        float main = fat_s2m * static_cast<float>(dot);
+                        if (a.pca_mean_dir != 0u) // coordinate 0 = the mean direction: the query's side in float32, the row's side its code 0 (the query's code byte 0 is 0)
+                            main = __builtin_fmaf(fat_u0s, static_cast<float>(static_cast<int>(static_cast<int8_t>(recw(0) & 0xFFu))), main);
                         const float ex = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(prev >> 16))) * a.pca_step;
                         const float ny = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last & 0xFFFFu))) * a.pca_step;
                         const float tx = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(last >> 16))) * a.pca_tail_unit;

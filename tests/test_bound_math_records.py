@@ -60,14 +60,22 @@ class Records:
         mean_norm = np.sqrt((self.mean.astype(f64) ** 2).sum())
         self.mean_norm = f32(0.0) if l2 else f32(mean_norm * 1.000001 + 1e-30)
         degenerate = (nrm == 0) if cosine else np.zeros(n, bool)
+        # similarity metrics with a mean that matters: the unit mean direction is coordinate 0 of the basis and the query keeps its coordinate along
+        # it in float32 (svsx_records.hip / SearchArgs::pca_mean_dir)
+        trace = (zc * zc).sum() / n
+        self.mean_dir = bool((not l2) and dcu >= 2 and mean_norm * mean_norm > 0.01 * trace)
         _, sv, vt = np.linalg.svd(zc - 0.0, full_matrices=False)
         q64 = np.zeros((dcu, d))
         q64[: min(dcu, vt.shape[0])] = vt[:dcu]
         if vt.shape[0] < dcu:  # fewer samples than directions: complete with any orthonormal rows
             rng = np.random.default_rng(1)
             q64[vt.shape[0] :] = rng.standard_normal((dcu - vt.shape[0], d))
+        if self.mean_dir:
+            q64 = np.concatenate([(self.mean.astype(f64) / mean_norm)[None, :], q64[: dcu - 1]])
         q64, _ = np.linalg.qr(q64.T)
         q64 = q64.T.copy()
+        if self.mean_dir and (q64[0] @ self.mean.astype(f64)) < 0:
+            q64[0] = -q64[0]  # (QR may flip the sign; either is an orthonormal basis, keep the direction of the mean)
         sigma = np.zeros(dcu)
         sigma[: min(dcu, sv.shape[0])] = sv[:dcu] / np.sqrt(n)
         self.P = np.zeros((self.dc, d), f32)
@@ -173,6 +181,9 @@ class Query:
                 c = np.clip(c, -127.0, 127.0)
                 c[~(c == c)] = 0.0
                 uh = (rec.step * c.astype(f32)).astype(f32)
+                if rec.mean_dir:  # coordinate 0 stays in float32: no code, no residual
+                    c[0] = 0.0
+                    uh[0] = u[0]
             r = (u - uh).astype(f32)
             r2 = f32(0.0)
             un2 = f32(0.0)
@@ -209,6 +220,11 @@ class Query:
         self.qq, self.eq, self.tq_hi, self.tq_lo = qq, eq, tq_hi, tq_lo
         self.s2m = f32(f32(rec.step * rec.step) * (f32(0.99999) if l2 else f32(1.0)))
         self.nuh = f32(f32(rec.step * np.sqrt(f32(qq), dtype=f32)) * f32(1.00001))
+        self.u0s = f32(0.0)
+        if (not l2) and rec.mean_dir:
+            with np.errstate(all="ignore"):
+                self.nuh = f32(np.sqrt(f32(f32(self.nuh * self.nuh) + f32(u[0] * u[0])), dtype=f32) * f32(1.00001))
+                self.u0s = f32(u[0] * rec.step)
         self.nq = vn
         self.rec = rec
 
@@ -244,6 +260,8 @@ def rejected(qs: Query, worst, wunit=None):
             return out
         dot = (rec.codes * qs.codes[None, :]).sum(1)
         main = (qs.s2m * dot.astype(f32)).astype(f32)
+        if rec.mean_dir:
+            main = fma32(np.broadcast_to(qs.u0s, main.shape).astype(f32), rec.codes[:, 0].astype(f32), main)
         ex = (f16_val(rec.ex) * rec.step).astype(f32)
         ny = (f16_val(rec.ny) * rec.step).astype(f32)
         tx = (f16_val(rec.tx) * rec.tail_unit).astype(f32)
