@@ -1027,6 +1027,25 @@ def main():
         host_pointer["ids_equal_device_path"] = bool((h_ids.astype(np.int64) == loc_i.cpu().numpy()).all())
         dev_med = float(np.median([a.elapsed_time(b) for a, b in ev]))
         host_pointer["over_device_resident"] = dev_med / host_pointer["median_ms"]
+        try:  # the same call on PAGE-LOCKED caller arrays (a host that pins its query / result buffers): the copies become truly asynchronous
+            qp = torch.empty((nq, d), dtype=torch.float32).pin_memory()
+            qp.copy_(q.cpu())
+            ip_, dp_ = torch.empty((nq, k), dtype=torch.int64).pin_memory(), torch.empty((nq, k), dtype=torch.float32).pin_memory()
+
+            def pinned_call():
+                _lib.check(L.svsx_search(index0._h, qp.data_ptr(), 0, nq, k, C.byref(spc), ip_.data_ptr(), None, dp_.data_ptr(), C.byref(aux0)))
+
+            pinned_call()
+            pin_ms = []
+            for _ in range(5):
+                t0h = time.perf_counter()
+                pinned_call()
+                pin_ms.append(1e3 * (time.perf_counter() - t0h))
+            host_pointer["page_locked_caller_arrays"] = dict(stat3(pin_ms, nq), ids_equal_device_path=bool((ip_.numpy() == loc_i.cpu().numpy()).all()),
+                                                             over_device_resident=dev_med / float(np.median(pin_ms)))
+            del qp, ip_, dp_
+        except Exception as e:  # noqa: BLE001 (informational)
+            host_pointer["page_locked_caller_arrays"] = {"error": f"{type(e).__name__}: {e}"}
         host_pointer["how"] = ("device staging and two streams kept with the index, copies straight from / to the caller's pageable arrays; two launches: the first "
                                "4 096 queries start as soon as their bytes have crossed PCIe, the rest is copied while they run (DESIGN.md section 1, "
                                "profiles/r03_notes.md section 5, profiles/r04_notes.md section 6)")
