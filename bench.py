@@ -1017,13 +1017,31 @@ def main():
         def host_call():
             _lib.check(L.svsx_search(index0._h, qh.ctypes.data, 0, nq, k, C.byref(spc), h_ids.ctypes.data, None, h_d.ctypes.data, C.byref(aux0)))
 
-        host_call()
-        host_ms = []
-        for _ in range(5):
-            t0h = time.perf_counter()
-            host_call()
-            host_ms.append(1e3 * (time.perf_counter() - t0h))
-        host_pointer = stat3(host_ms, nq)
+        def timed_host(fn):
+            """The reference's protocol is 1 warm-up + 5 timed calls (search.h:209-219).  Like the device-resident launches, the first host calls after
+            the idle gap in front of them run slow (the kernels inside them end at 1 308, 1 244, 1 139, 1 114, 1 091, 1 089 us of the call on one lease:
+            profiles/r06_notes.md section 10), so the same rule as for `value` applies: untimed calls until three consecutive ones agree within 1 %
+            (at least 8, at most 16), THEN the 5 timed ones.  The untimed calls' times are reported too (`warmup_calls_ms`): the first five of them are
+            what the reference's own 1 + 5 protocol would have recorded."""
+            warm = []
+            for i in range(16):
+                t0h = time.perf_counter()
+                fn()
+                warm.append(1e3 * (time.perf_counter() - t0h))
+                if i >= 7 and max(warm[-3:]) <= 1.01 * min(warm[-3:]):
+                    break
+            timed = []
+            for _ in range(5):
+                t0h = time.perf_counter()
+                fn()
+                timed.append(1e3 * (time.perf_counter() - t0h))
+            out = stat3(timed, nq)
+            out["warmup_calls_ms"] = [round(v, 4) for v in warm]
+            out["protocol"] = "untimed calls until three agree within 1 % (8..16), then 5 timed: min / median / max"
+            out["reference_protocol_1_plus_5_median_ms"] = float(np.median((warm + timed)[1:6]))  # calls 2..6 of this sequence
+            return out, timed
+
+        host_pointer, host_ms = timed_host(host_call)
         host_pointer["ids_equal_device_path"] = bool((h_ids.astype(np.int64) == loc_i.cpu().numpy()).all())
         dev_med = float(np.median([a.elapsed_time(b) for a, b in ev]))
         host_pointer["over_device_resident"] = dev_med / host_pointer["median_ms"]
@@ -1035,13 +1053,8 @@ def main():
             def pinned_call():
                 _lib.check(L.svsx_search(index0._h, qp.data_ptr(), 0, nq, k, C.byref(spc), ip_.data_ptr(), None, dp_.data_ptr(), C.byref(aux0)))
 
-            pinned_call()
-            pin_ms = []
-            for _ in range(5):
-                t0h = time.perf_counter()
-                pinned_call()
-                pin_ms.append(1e3 * (time.perf_counter() - t0h))
-            host_pointer["page_locked_caller_arrays"] = dict(stat3(pin_ms, nq), ids_equal_device_path=bool((ip_.numpy() == loc_i.cpu().numpy()).all()),
+            pin_stats, pin_ms = timed_host(pinned_call)
+            host_pointer["page_locked_caller_arrays"] = dict(pin_stats, ids_equal_device_path=bool((ip_.numpy() == loc_i.cpu().numpy()).all()),
                                                              over_device_resident=dev_med / float(np.median(pin_ms)))
             del qp, ip_, dp_
         except Exception as e:  # noqa: BLE001 (informational)

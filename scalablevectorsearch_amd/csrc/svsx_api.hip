@@ -463,6 +463,14 @@ static int search_host_pipelined(
 #define SVSX_HOST_FIRST 4096
 #endif
     size_t first = nq > SVSX_HOST_FIRST ? SVSX_HOST_FIRST : nq;
+#ifdef SVSX_HOST_THIRD  // diagnostic builds: a small third chunk, so that the last result copy (the exposed one) is short
+    if (first + SVSX_HOST_THIRD + 1024 < nq) {
+        nc = 3;
+        bounds[1] = first;
+        bounds[2] = nq - SVSX_HOST_THIRD;
+        bounds[3] = nq;
+    } else
+#endif
     if (first < nq) {
         nc = 2;
         bounds[1] = first;

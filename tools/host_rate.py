@@ -43,7 +43,19 @@ for nq in [int(v) for v in a.nq.split(",")]:
             host_ms.append(1e3 * (time.perf_counter() - t0))
         for _ in range(6):
             t0 = time.perf_counter(); r = idx.search(qh, k, sp); py_ms.append(1e3 * (time.perf_counter() - t0))
+        # round 6: does it matter whether the result arrays are the same ones every call (as above) or fresh ones (as the reference's harness has them:
+        # Traits::search returns a new QueryResult per call, benchmark/include/svs-benchmark/search.h:209-219; idx.search allocates too)?
+        fresh_ms, again_ms = [], []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            f64_, fd_ = np.empty((nq, k), np.uint64), np.empty((nq, k), np.float32)
+            _lib.check(L.svsx_search(idx._h, qh.ctypes.data, 0, nq, k, C.byref(spc), f64_.ctypes.data, None, fd_.ctypes.data, C.byref(aux)))
+            fresh_ms.append(1e3 * (time.perf_counter() - t0))
+        for _ in range(6):
+            t0 = time.perf_counter()
+            _lib.check(L.svsx_search(idx._h, qh.ctypes.data, 0, nq, k, C.byref(spc), h64.ctypes.data, None, hd.ctypes.data, C.byref(aux)))
+            again_ms.append(1e3 * (time.perf_counter() - t0))
         same = bool((h64.astype(np.int64) == ids.cpu().numpy()).all() and (r.indices == h64).all())
         med = lambda v: statistics.median(v[1:])
-        print(json.dumps({"nq": nq, "window": w, "device_ms": med(dev_ms), "host_c_abi_ms": med(host_ms), "host_c_abi_min_ms": min(host_ms[1:]), "host_python_ms": med(py_ms),
+        print(json.dumps({"nq": nq, "window": w, "device_ms": med(dev_ms), "host_c_abi_ms": med(host_ms), "host_c_abi_min_ms": min(host_ms[1:]), "host_python_ms": med(py_ms), "host_c_abi_fresh_result_arrays_ms": med(fresh_ms), "host_c_abi_same_arrays_again_ms": med(again_ms),
                           "host_over_device": med(dev_ms) / med(host_ms), "ids_identical": same}), flush=True)
