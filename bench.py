@@ -158,7 +158,7 @@ def designed_lines(stats_i64, gstride, row_bytes, bound_codes, d, k, record_byte
             full_chunks = int(groups // 8)
             rem = groups - 8 * full_chunks
             id_lines = 2 * full_chunks + (-(-int(round(rem * 32)) // LINE) if rem > 0 else 0)
-            adj = int(round(exp * (id_lines + (record_bytes // 16) * groups)))
+            adj = int(round(exp * (id_lines + (record_bytes / 16.0) * groups)))  # (28-byte records: a 16- and a 12-byte plane = 1.75 lines per group of 8 slots)
         else:
             adj = exp * (-(-(gstride * (4 + record_bytes)) // LINE))
         code = 0
@@ -658,7 +658,7 @@ def config4_point(args, svs, device, local_rank, k, t_run0):
     torch.cuda.synchronize()
     ms4 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev4]))
     k4 = i4.last_kernel_info()
-    rb4 = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(k4[-8:], 128)
+    rb4 = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128, "codes=5>": 28}.get(k4[-8:], 128)
     l4 = designed_lines(st4.to(torch.int64), 128, d4, 2, d4, k, rb4)
     point = {"workload": f"synthetic {n4} x 768 scalar-quantized int8 (global scale / bias), float32 queries, cosine, batch={nq4}, k=10, graph R=128 L=200 prune_to 124 alpha 0.95, 1xMI355X",
              "vectors": n4, "size_note": why or "BASELINE config 4's size", "window_for_recall_0.9": lo_w, "recall_at_10": recall_at(gt4, ids4, k), "qps": nq4 / (ms4 * 1e-3), "kernel_ms": ms4,
@@ -954,7 +954,7 @@ def main():
     # SURVEY 8(d) algorithmic bytes of the REFERENCE traversal (visited set off, whole rows): reported, never used as the roofline fraction
     ref_alg_bytes = 4 * (exp_total + slots_total) + slots_total * d * 4 + local_shards * nq * (d * 4 + d * 4 + k * 12)
     kinfo = shards[0]["index"].last_kernel_info()  # ...codes=2/3/4> = 32- / 64- / 128-byte inline records
-    record_bytes = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(kinfo[-8:], 32)
+    record_bytes = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128, "codes=5>": 28}.get(kinfo[-8:], 32)
     lines = designed_lines(stats.to(torch.int64).reshape(-1, 6), gstride, d * 4, mode, d, k, record_bytes)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----------------------------------------
@@ -1336,7 +1336,7 @@ def main():
                          "frac_of_dense_f16_peak_2500_tflops": 2.0 * n3 * d3 * nq / (f3ms * 1e-3) / 1e12 / 2500.0,
                          "queries_recomputed_exhaustively": int(f3cnt.item()) // 7, "runs": 7, "exact_answers_per_second": nq / (f3ms * 1e-3)}
                 k3 = i3.last_kernel_info()
-                rb3 = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(k3[-8:], 32)
+                rb3 = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128, "codes=5>": 28}.get(k3[-8:], 32)
                 l3 = designed_lines(st3.to(torch.int64), gstride, d3 * 2, 2, d3, k, rb3)
                 result["config"].setdefault("other_configs", {})["c3"] = {
                     "workload": f"sift-1M-like d=128 float16 rows, float32 queries, inner product, batch={nq}, search_window={args.window}, k=10, 1xMI355X",
@@ -1371,7 +1371,7 @@ def main():
                 torch.cuda.synchronize()
                 ms128 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev128]))
                 k128 = i128.last_kernel_info()
-                l128 = designed_lines(st128.to(torch.int64), 128, d * 4, 2, d, k, {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128}.get(k128[-8:], 32))
+                l128 = designed_lines(st128.to(torch.int64), 128, d * 4, 2, d, k, {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128, "codes=5>": 28}.get(k128[-8:], 32))
                 result["config"].setdefault("other_configs", {})["c2_regression_graph_r128"] = {
                     "workload": f"deep-1M-like d=96 float32 L2, batch={nq}, search_window={args.window}, k=10, graph R=128 L=200 prune_to 124 alpha 1.2 (static-regression.toml), 1xMI355X",
                     "qps": nq / (ms128 * 1e-3), "kernel_ms": ms128, "recall_at_10": recall_at(gt, ids128, k), "kernel": "svsx::" + k128,

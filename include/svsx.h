@@ -375,7 +375,7 @@ int svsx_get_distance(const svsx_index* index, uint64_t id, const void* query, i
  *   mode 2        graph-inline records (the default of bench.py): every adjacency row carries a 32- / 64- / 128-byte record per neighbour
  *                 (8-bit codes of the leading coordinates in a principal basis of the data, coding error, norm of the uncoded remainder),
  *                 so one hop reads ONE contiguous block of (4 + record) * max_degree bytes and bounds all its neighbours at once.  The record
- *                 size is chosen from the data's spectrum (expected lines per hop).  float32 / float16 rows, scalar-quantized rows (the
+ *                 size (28 / 32 / 64 / 128 bytes) is chosen from the data's spectrum (expected lines per hop).  float32 / float16 rows, scalar-quantized rows (the
  *                 compressed L2 distance with records in code space, scalar.h:58-105) and raw int8 / uint8 rows searched with queries of
  *                 their own type (the VNNI pairs), under any metric; dimension 32..4096.
  *                 MEMORY: + (4 + record) * graph_row_stride bytes of HBM per vector -- 2.3 GB for 1 M vectors at R = 64 with 32-byte records
@@ -387,7 +387,8 @@ int svsx_get_distance(const svsx_index* index, uint64_t id, const void* query, i
  *                 >= 100 000 vectors get a second opinion: the records are timed against the plain kernel on 2 048 of the index's own rows as
  *                 queries and kept only if faster.  SVSX_SUCCESS either way, svsx_index_memory()[8] tells which, svsx_last_error() why.
  *                 The default a host should use when it does not know its data.
- *   mode 32 / 64 / 128   the same as mode 2 with exactly this record size (refused when larger than a third of the rows it protects)
+ *   mode 28 / 32 / 64 / 128   the same as mode 2 with exactly this record size (refused when larger than a third of the rows it protects; 28:
+ *                 float32 / float16 rows only -- a 16- and a 12-byte plane, so that a 64-slot block is 2 048 bytes = 16 lines instead of 18)
  *   mode 1        one 128-byte row per vector: 8-bit codes of its first min(d, 120) components + exact coding error (float32 / float16
  *                 rows, L2, d = 96 or 128; +128 B per vector, one extra line per candidate).  For indexes whose inline rows do not fit.
  *   mode 0        frees either.

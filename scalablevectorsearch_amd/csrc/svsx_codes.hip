@@ -246,22 +246,29 @@ __global__ __launch_bounds__(256) void degree_class_kernel(const uint32_t* __res
 // neighbour's record, so that one load instruction of the search kernel reads one contiguous plane.  With `cls` the id word of a neighbour
 // carries that neighbour's degree class in bits [degshift, 31): the search kernel finds it in the candidate buffer when the neighbour is
 // expanded and requests only the lines of the block that hold neighbours (svsx_search_kernel.h, main loop).
-__global__ __launch_bounds__(64) void fat_build_kernel(const uint32_t* __restrict__ graph, uint32_t gstride, uint32_t n, const uint4* __restrict__ records,
-                                                       uint32_t rw, unsigned char* __restrict__ fat, size_t fat_stride, const uint8_t* __restrict__ cls, uint32_t degshift) {
+__global__ __launch_bounds__(64) void fat_build_kernel(const uint32_t* __restrict__ graph, uint32_t gstride, uint32_t n, const uint32_t* __restrict__ records,
+                                                       uint32_t rb, unsigned char* __restrict__ fat, size_t fat_stride, const uint8_t* __restrict__ cls, uint32_t degshift) {
+    // rb = record bytes: 32 / 64 / 128 (whole 16-byte planes) or 28 (round 6: a 16-byte plane and a 12-byte one -- 64 x (4 + 28) bytes = 16 lines)
     const uint32_t lane = threadIdx.x;
+    const uint32_t nw = rb / 4u, full = nw / 4u, tail = nw % 4u; // words per record, full planes, words of the last (narrow) plane
     for (uint32_t v = blockIdx.x; v < n; v += gridDim.x) {
         unsigned char* out = fat + static_cast<size_t>(v) * fat_stride;
         for (uint32_t gbase = 0; gbase < gstride; gbase += 64) {
             const uint32_t cs = (gstride - gbase) < 64u ? (gstride - gbase) : 64u;
-            uint32_t* ids = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(gbase) * (4u + 16u * rw));
+            uint32_t* ids = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(gbase) * (4u + rb));
             uint4* planes = reinterpret_cast<uint4*>(ids + cs);
             if (lane < cs) {
                 const uint32_t nb = graph[static_cast<size_t>(v) * gstride + gbase + lane];
                 ids[lane] = (nb != kInvalidId && cls != nullptr) ? (nb | (static_cast<uint32_t>(cls[nb]) << degshift)) : nb;
-                for (uint32_t p = 0; p < rw; ++p) {
-                    uint4 r = make_uint4(0, 0, 0, 0);
-                    if (nb != kInvalidId) r = records[static_cast<size_t>(nb) * rw + p];
-                    planes[static_cast<size_t>(p) * cs + lane] = r;
+                const uint32_t* r = records + static_cast<size_t>(nb != kInvalidId ? nb : 0u) * nw;
+                for (uint32_t p = 0; p < full; ++p) {
+                    uint4 q = make_uint4(0, 0, 0, 0);
+                    if (nb != kInvalidId) q = make_uint4(r[4 * p], r[4 * p + 1], r[4 * p + 2], r[4 * p + 3]);
+                    planes[static_cast<size_t>(p) * cs + lane] = q;
+                }
+                if (tail != 0u) {
+                    uint32_t* narrow = reinterpret_cast<uint32_t*>(planes + static_cast<size_t>(full) * cs) + tail * lane;
+                    for (uint32_t t = 0; t < tail; ++t) narrow[t] = nb != kInvalidId ? r[4 * full + t] : 0u;
                 }
             }
         }
@@ -293,7 +300,7 @@ static uint32_t grid_for(uint32_t n) { return n < 32768u ? (n ? n : 1u) : 32768u
 
 template <int DT> static hipError_t launch_both(const PcaArgs& a, bool encode, hipStream_t stream) {
     const size_t lds = (static_cast<size_t>(a.d) + 128) * sizeof(double);
-    if (lds > 60 * 1024 || a.dc > static_cast<uint32_t>(kMaxDc) || (a.rb != 32 && a.rb != 64 && a.rb != 128)) return hipErrorInvalidValue;
+    if (lds > 60 * 1024 || a.dc > static_cast<uint32_t>(kMaxDc) || (a.rb != 28 && a.rb != 32 && a.rb != 64 && a.rb != 128)) return hipErrorInvalidValue;
     if (encode) hipLaunchKernelGGL(pca_encode_kernel<DT>, dim3(grid_for(a.n)), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL(pca_stats_kernel<DT>, dim3(grid_for(a.n)), dim3(64), lds, stream, a);
     return hipGetLastError();
@@ -318,7 +325,7 @@ hipError_t launch_fat_build(const uint32_t* d_graph, uint32_t gstride, uint32_t 
         hipLaunchKernelGGL(degree_class_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_graph, gstride, n, d_class_scratch);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(fat_build_kernel, dim3(grid_for(n)), dim3(64), 0, stream, d_graph, gstride, n, static_cast<const uint4*>(d_records), record_bytes / 16u,
+    hipLaunchKernelGGL(fat_build_kernel, dim3(grid_for(n)), dim3(64), 0, stream, d_graph, gstride, n, static_cast<const uint32_t*>(d_records), record_bytes,
                        static_cast<unsigned char*>(d_fat), fat_stride, static_cast<const uint8_t*>(d_class_scratch), degshift);
     return hipGetLastError();
 }

@@ -217,15 +217,18 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
     for (uint32_t i = 0; i < d; ++i) trace += cov[static_cast<size_t>(i) * d + i];
     const double row_lines = static_cast<double>((ix->row_bytes + 127) / 128) * (decomp ? 8.0 : 1.0); // (integer paths: v_dot4, no decompression)
     const double cand = 0.9 * static_cast<double>(ix->gstride);
+    // Round 6: float32 / float16 rows also have a 28-byte form (a 16- and a 12-byte plane: a 64-slot block is 16 lines instead of 18, four codes
+    // fewer); it competes with the 32-byte form on the estimate alone (same kernel family, same registers), larger records must win by 10 %.
+    const bool has28 = (ix->data_dtype == DT_F32 || ix->data_dtype == DT_F16) && !ix->sq_enabled;
     uint32_t rb = 32;
     double best_cost = 0.0;
-    for (uint32_t r = 32; r <= rb_max; r *= 2) {
+    for (uint32_t r = has28 ? 28u : 32u; r <= rb_max; r = r == 28u ? 32u : r * 2u) {
         double got = 0.0;
         for (uint32_t c = 0; c < r - meta && c < m; ++c) got += std::max(T[static_cast<size_t>(order[c]) * m + order[c]], 0.0);
         const double f = trace > 0.0 ? got / trace : 1.0;
         const double rej = 0.88 * std::min(std::max((f - 0.6) / 0.3, 0.0), 1.0) + 0.05 * std::min(std::max((f - 0.9) / 0.1, 0.0), 1.0);
         const double cost = static_cast<double>(ix->gstride) * (4.0 + r) / 128.0 + cand * (1.0 - rej) * row_lines;
-        if (r == 32 || cost < 0.9 * best_cost) {
+        if (r == (has28 ? 28u : 32u) || (r == 32u && rb == 28u && cost < best_cost) || cost < 0.9 * best_cost) {
             best_cost = cost;
             rb = r;
         }
@@ -238,6 +241,7 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
         if (best_cost > 0.9 * plain_cost) return kRecordsDoNotPay;
     }
     if (forced_rb != 0) { // the caller asked for this record size (svsx_index_build_bound_codes mode 32 / 64 / 128)
+        if (forced_rb == 28 && !has28) return fail(SVSX_NOT_IMPLEMENTED, "28-byte records exist for float32 / float16 rows");
         if (forced_rb > rb_max) return fail(SVSX_INVALID_ARGUMENT, "records of %u bytes exceed a third of the %zu-byte rows they protect", forced_rb, ix->row_bytes);
         rb = forced_rb;
     }
@@ -250,6 +254,7 @@ int build_fat_rows(svsx_index* ix, uint32_t forced_rb, uint32_t* asked_rb, uint3
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         auto need = [&](uint32_t r) { return static_cast<double>(n) * (static_cast<double>((ix->gstride * (4 + r) + 127) & ~size_t(127)) + r + 1.0) + (64 << 20); };
         while (rb > 32 && need(rb) > 0.98 * static_cast<double>(free_b)) rb /= 2;
+        if (rb == 32 && has28 && need(rb) > 0.98 * static_cast<double>(free_b)) rb = 28;
         if (need(rb) > 0.98 * static_cast<double>(free_b)) return kRecordsDoNotFit;
     }
     *built_rb = rb;
@@ -457,7 +462,7 @@ int records_pay_on_a_sample(svsx_index* ix) {
 extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
     if (!ix) return fail(SVSX_NOT_INITIALIZED, "Index not initialized");
     uint32_t forced_rb = 0;
-    if (mode == 32 || mode == 64 || mode == 128) { // graph-inline records of exactly this size
+    if (mode == 28 || mode == 32 || mode == 64 || mode == 128) { // graph-inline records of exactly this size
         forced_rb = static_cast<uint32_t>(mode);
         mode = 2;
     }
@@ -466,7 +471,7 @@ extern "C" int svsx_index_build_bound_codes(svsx_index* ix, int mode) {
         only_if_worth = true;
         mode = 2;
     }
-    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows), 2 (graph-inline records), 3 (records where they are expected to pay) or 32 / 64 / 128 (inline records of that size)");
+    if (mode < 0 || mode > 2) return fail(SVSX_INVALID_ARGUMENT, "bound-code mode must be 0 (off), 1 (128-B rows), 2 (graph-inline records), 3 (records where they are expected to pay) or 28 / 32 / 64 / 128 (inline records of that size)");
     bool fell_from_records = false;
     HIP_TRY(hipSetDevice(ix->device));
     std::lock_guard<std::mutex> lock(ix->shadow_mutex);

@@ -53,11 +53,11 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
     if (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         // configs 2, 3, 5 (static 96 / 128, 32-byte records): <= 80 VGPRs -- the scalar registers allow 6 waves; float16 rows of 96 need 88
         // (float32 rows of 128 keep 8 x 16 bytes of a row in flight per lane: 6 waves would spill 92 bytes)
-        if ((DS == 96 || DS == 128) && CODES == 2 && BIG == 0 && METRIC != M_COS) return (DT == DT_F32 && DS == 128) ? 4 : (DT == DT_F16 && DS == 96) ? 5 : 6;
+        if ((DS == 96 || DS == 128) && (CODES == 2 || CODES == 5) && BIG == 0 && METRIC != M_COS) return (DT == DT_F32 && DS == 128) ? 4 : (DT == DT_F16 && DS == 96) ? 5 : 6;
         // any dimension, 32- / 64-byte records: <= 96
         // (a floor of 6 fits the float32 kernels of 64- / 128-byte records too -- 78-80 registers, 12 bytes of scratch for L2 at 128 -- and is slower:
         // isotropic rows 2.63 -> 3.14 ms, G(48, 0.2) 1.58 -> 1.60; profiles/r06_notes.md)
-        if (DS == 0 && BIG == 0 && METRIC != M_COS && CODES <= 3) return 5;
+        if (DS == 0 && BIG == 0 && METRIC != M_COS && (CODES <= 3 || CODES == 5)) return 5;
     }
     // windows 513 .. 1024 with 128-byte records (config 4 at recall >= 0.9): 143 VGPRs instead of 181, no scratch -> 3 waves per SIMD instead of 2
     if (DS == 768 && BIG == 2 && CODES == 4 && (QMODE == QM_SQ_IP || QMODE == QM_SQ_COS)) return 3;
@@ -85,10 +85,13 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL, int CODES, int BI
 template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES = 0, int BIG = 0>
 __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t qi, unsigned char* smem) {
     constexpr bool GREATER = METRIC != M_L2;
-    // CODES: 0 none, 1 128-byte code rows (svsx_distance.hip), 2 / 3 / 4 graph-inline records of 32 / 64 / 128 bytes (svsx_codes.hip)
+    // CODES: 0 none, 1 128-byte code rows (svsx_distance.hip), 2 / 3 / 4 graph-inline records of 32 / 64 / 128 bytes (svsx_codes.hip),
+    // 5 (round 6) records of 28 bytes: a 16-byte plane and a 12-byte one, so that a 64-slot block is 64 x (4 + 28) = 2 048 bytes = 16 lines
+    // instead of 18 -- four codes fewer per neighbour for two lines fewer per expansion, where the spectrum allows it
     constexpr bool FAT = CODES >= 2;
-    constexpr int RW = FAT ? (2 << (CODES - 2)) : 2;              // 16-byte planes per record
-    constexpr int FDC = RW * 16 - (METRIC == M_L2 ? 4 : 6);       // coded coordinates per record
+    constexpr int RW = !FAT ? 2 : CODES == 5 ? 2 : (2 << (CODES - 2)); // planes per record (all 16 bytes wide; the last one of the 28-byte form 12)
+    constexpr int RB = CODES == 5 ? 28 : RW * 16;                 // record bytes
+    constexpr int FDC = RB - (METRIC == M_L2 ? 4 : 6);            // coded coordinates per record
     constexpr bool INTPATH = (QMODE == QM_INT || QMODE == QM_SQ_L2);
     constexpr bool B8 = !INTPATH && use_block_cyclic<DT>();  // 8-bit rows on the float path: block-cyclic mapping
 #ifndef SVSX_BC8
@@ -127,8 +130,8 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
     uint32_t* compact = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes); // 64 ids; inline-record kernels: one slot per adjacency slot
     const uint32_t compact_bytes = FAT ? ((a.gstride + 63u) & ~63u) * 4u : 256u;
     // FAT: the query's own record codes; 32-byte records keep them in SGPRs afterwards, so the 128 bytes alias the compaction scratch
-    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + (CODES >= 3 ? compact_bytes : 0u));
-    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + compact_bytes + (CODES >= 3 ? 128u : 0u)); // GENERAL only
+    [[maybe_unused]] uint32_t* qcodes = reinterpret_cast<uint32_t*>(smem + buf_bytes + q_bytes + filt_bytes + (RW > 2 ? compact_bytes : 0u));
+    uint2* sort_stack = reinterpret_cast<uint2*>(smem + buf_bytes + q_bytes + filt_bytes + compact_bytes + (RW > 2 ? 128u : 0u)); // GENERAL only
 
     // ---- BatchIterator::next prologue (iterator.h:249-262): done() check, increment_buffer, resume or restart ---------
     uint32_t* it_meta = nullptr;
@@ -569,13 +572,23 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
         [[maybe_unused]] auto fat_load = [&](const uint32_t base, uint32_t& out_id, uint4 (&out_rec)[RW]) {
             const uint32_t cs = (a.gstride - base) < 64u ? (a.gstride - base) : 64u;
             const uint32_t lim = (slot_limit - base) < cs ? (slot_limit - base) : cs; // >= 1
-            const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(base) * (4u + 16u * RW));
+            const uint32_t* fids = reinterpret_cast<const uint32_t*>(a.fat + static_cast<size_t>(node) * a.fat_stride + static_cast<size_t>(base) * (4u + static_cast<uint32_t>(RB)));
             const uint4* planes = reinterpret_cast<const uint4*>(fids + cs);
             const uint32_t ll = opaque_u(lane); // lane-derived offsets are recomputed here, not kept across the distance pass (opaque_u)
             const uint32_t li = ll < lim ? ll : lim - 1u;
             const uint32_t w = fids[li];
 #pragma unroll
-            for (int p = 0; p < RW; ++p) out_rec[p] = planes[static_cast<uint32_t>(p) * cs + li];
+            for (int p = 0; p < RW; ++p) {
+                if constexpr (CODES == 5) {
+                    if (p == RW - 1) { // the 12-byte plane: three words per slot behind the full planes
+                        const uint32_t* p12 = reinterpret_cast<const uint32_t*>(planes + static_cast<uint32_t>(RW - 1) * cs) + 3u * li;
+                        const uint3 t = *reinterpret_cast<const uint3*>(p12);
+                        out_rec[p] = make_uint4(t.x, t.y, t.z, 0u);
+                        continue;
+                    }
+                }
+                out_rec[p] = planes[static_cast<uint32_t>(p) * cs + li];
+            }
             out_id = ll < lim ? w : kInvalidId;
         };
         // (8-bit rows only: the float32 / float16 kernels of d = 96 / 128 sit at their 80-register bracket and would spill the nine registers)
@@ -629,16 +642,16 @@ __device__ __forceinline__ void search_one(const SearchArgs& a, const uint32_t q
                     // the second record plane are awaited under this arithmetic, not in front of it.
                     bool rej;
                     unsigned long long rej_m; // wave mask of the ONE compare that decides (see wave_ballot: masks are combined in scalar registers)
-                    constexpr int NW = RW * 4;  // words per record; the last one holds float16 fields
+                    constexpr int NW = RB / 4;  // words per record; the last one holds float16 fields
                     auto recw = [&](int w) -> uint32_t {
                         const uint4& r = rec[w >> 2];
                         return (w & 3) == 0 ? r.x : (w & 3) == 1 ? r.y : (w & 3) == 2 ? r.z : r.w;
                     };
                     uint32_t qw[NW];
-                    if constexpr (RW == 2) {
+                    if constexpr (RW == 2) { // (28-byte records: 24 / 22 codes, the bytes behind them are zero in qcodes and so in fq)
 #pragma unroll
                         for (int w = 0; w < 7; ++w) qw[w] = fq[w];
-                        qw[7] = 0u;
+                        if constexpr (NW == 8) qw[7] = 0u;
                     } else { // larger records: the query's code words come from LDS (broadcast reads)
 #pragma unroll
                         for (int p = 0; p < RW; ++p) {
@@ -1078,7 +1091,7 @@ template <int DT, int METRIC, int QMODE, int DS, bool GENERAL = false, int CODES
     const size_t buf_bytes = ((static_cast<size_t>(a.capacity) + 1) * 8 + 15) & ~size_t(15);
     const size_t lds = buf_bytes + (intpath ? static_cast<size_t>(dpad) : static_cast<size_t>(dpad) * 4) +
                        (a.filter_entries ? static_cast<size_t>(a.filter_entries) * (a.filter_tag8 ? 1 : 2) : 0) +
-                       (CODES >= 2 ? ((static_cast<size_t>(a.gstride) + 63) & ~size_t(63)) * 4 : 64 * 4) /* compaction / merge scratch */ + (CODES >= 3 ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
+                       (CODES >= 2 ? ((static_cast<size_t>(a.gstride) + 63) & ~size_t(63)) * 4 : 64 * 4) /* compaction / merge scratch */ + ((CODES == 3 || CODES == 4) ? 128 : 0) + (GENERAL ? 64 * 8 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #ifdef SVSX_DIAG
     size_t lds_request = lds;
@@ -1102,6 +1115,13 @@ template <int DT, int METRIC, int QMODE> static hipError_t launch_dim(const Sear
     if (a.general || QMODE == QM_SCALAR) return launch_one<DT, METRIC, QMODE, 0, true>(a, stream); // runtime-d kernel: same arithmetic, same results (the scalar-loop pairs have no other variant)
     if constexpr (QMODE == QM_FLOAT && (DT == DT_F32 || DT == DT_F16)) {
         // static dimensions: the reference's list (distance_core.h:31-32: 64, 96, 100, 128, 160, 200, 512, 768, Dynamic)
+        if (a.fat != nullptr && a.fat_rb == 28) { // round 6: 28-byte records, the dimensions of the benchmark configs and runtime d
+            switch (a.d) {
+                case 96: return launch_one<DT, METRIC, QMODE, 96, false, 5>(a, stream);
+                case 128: return launch_one<DT, METRIC, QMODE, 128, false, 5>(a, stream);
+                default: return launch_one<DT, METRIC, QMODE, 0, false, 5>(a, stream);
+            }
+        }
         if (a.fat != nullptr && a.fat_rb == 32) {
             switch (a.d) {
                 case 64: return launch_one<DT, METRIC, QMODE, 64, false, 2>(a, stream);

@@ -256,8 +256,8 @@ class VamanaIndex:
 
     def build_bound_codes(self, mode: int | bool = 1) -> int:
         """svsx_index_build_bound_codes: result-neutral bound rejection.  mode 2: graph-inline records per neighbour, size chosen from the
-        data's spectrum (float32 / float16 rows, scalar-quantized rows, raw int8 / uint8 rows; any metric; 32 <= d <= 4096); 32 / 64 / 128: the
-        same with that record size; mode 1 (True): 128-byte code row per vector (float rows, L2, d = 96 / 128); 0 (False): off.
+        data's spectrum (float32 / float16 rows, scalar-quantized rows, raw int8 / uint8 rows; any metric; 32 <= d <= 4096); 3: the same, but only
+        where the records are expected to pay; 28 / 32 / 64 / 128: mode 2 with that record size (28: float32 / float16 rows); mode 1 (True): 128-byte code row per vector (float rows, L2, d = 96 / 128); 0 (False): off.
         Returns the scheme in effect (0 / 1 / 2): records that do not fit the free HBM shrink or fall back with a RuntimeWarning, not an error."""
         rc = _lib.lib().svsx_index_build_bound_codes(self._h, int(mode))
         if rc == _lib.FELL_BACK:  # not a failure: a smaller scheme than asked for was built (the one asked for does not fit the free HBM)

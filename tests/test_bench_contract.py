@@ -42,7 +42,7 @@ def test_committed_bench_line_has_the_contract_fields():
     sh = j["config"]["sharded_c5"]                      # SURVEY 8e in the same line: fixed 8 shards, RCCL communicator inside the library
     assert sh["shards_total"] == 8 and sh["shards_per_gpu"] * sh["n_gpus"] == 8 and sh["rccl_communicator"] is True and sh["recall_at_10"] > 0.99
     c3 = j["config"]["other_configs"]["c3"]
-    assert "codes=2>" in c3["kernel"] and c3["recall_at_10"] > 0.9
+    assert ("codes=2>" in c3["kernel"] or "codes=5>" in c3["kernel"]) and c3["recall_at_10"] > 0.9
 
 
 def test_pmc_summaries_are_stamped_and_consistent():

@@ -333,7 +333,7 @@ def _check(oracle, metric, x, q, rb, name, sq=None):
 
 
 @pytest.mark.parametrize("metric", [L2, IP, COS])
-@pytest.mark.parametrize("d,rb", [(32, 32), (96, 32), (96, 128), (768, 64), (768, 128)])
+@pytest.mark.parametrize("d,rb", [(32, 32), (96, 28), (96, 32), (96, 128), (128, 28), (768, 64), (768, 128)])
 def test_record_bound_never_rejects_a_candidate_against_its_own_distance(oracle, metric, d, rb):
     total_fired = 0
     for name, x, q in _sets(d):

@@ -39,7 +39,7 @@ def _check(svs, oracle, x, graph, entry, q, configs, expect_rejects=True, mode=1
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
         if not vis:
             assert (st[:, 2] == ost[:, 2]).all()  # every candidate is still accounted for
-        assert re.search(r"codes=[234]>" if mode == 2 else r"codes=1>", idx.last_kernel_info()), idx.last_kernel_info()
+        assert re.search(r"codes=[2345]>" if mode == 2 else r"codes=1>", idx.last_kernel_info()), idx.last_kernel_info()
         rej += int(st[:, 5].sum())
     if expect_rejects:
         assert rej > 0
@@ -207,7 +207,7 @@ def _check_sq(svs, oracle, metric, x, q, code_dtype, configs, R=24, inline=False
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, code_dtype, w, c, k, vis)
         assert (st[:, 0] == ost[:, 0]).all() and (st[:, 1] == ost[:, 1]).all()
         if inline:
-            assert re.search(r"codes=[234]>", idx.last_kernel_info()), idx.last_kernel_info()  # 32- / 64- / 128-byte records
+            assert re.search(r"codes=[2345]>", idx.last_kernel_info()), idx.last_kernel_info()  # 32- / 64- / 128-byte records
         rej += int(st[:, 5].sum())
     return rej
 
@@ -239,7 +239,7 @@ def _check_float(svs, oracle, metric, x, q, graph, entry, configs, nan_rows=Fals
         assert (res.indices == _u64(ids)).all(), (metric, x.dtype, w, c, k, vis)
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, x.dtype, w, c, k, vis)
         assert (st[:, :2] == ost[:, :2]).all()
-        assert re.search(r"codes=[234]>", idx.last_kernel_info())
+        assert re.search(r"codes=[2345]>", idx.last_kernel_info())
         rej += int(st[:, 5].sum())
     return rej
 
@@ -323,7 +323,7 @@ def _check_int(svs, oracle, metric, x, q, graph, entry, configs, nan_rows=False,
         assert (_bits(res.distances) == _bits(dists)).all(), (metric, x.dtype, w, c, k, vis)
         assert (st[:, :2] == ost[:, :2]).all()
         info = idx.last_kernel_info()
-        assert "qmode=1" in info and re.search(r"codes=[234]>", info), info
+        assert "qmode=1" in info and re.search(r"codes=[2345]>", info), info
         rej += int(st[:, 5].sum())
     return rej
 
@@ -355,7 +355,7 @@ def test_inline_records_integer_rows(svs, oracle, metric, dt, d):
             assert (res.indices == _u64(ids)).all() and (_bits(res.distances) == _bits(dists)).all(), (w, c, k, vis)
             assert (st[:, :2] == ost[:, :2]).all()
             info = idx.last_kernel_info()
-            assert "qmode=0" in info and re.search(r"codes=[234]>", info), info
+            assert "qmode=0" in info and re.search(r"codes=[2345]>", info), info
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -443,7 +443,7 @@ def test_mode_3_builds_records_only_where_they_are_expected_to_pay(svs, oracle, 
     either way, and mode 2 still builds records on the same index when asked to."""
     sw = small_world
     idx = svs.VamanaIndex(sw["graph"], sw["x"], svs.DistanceL2(), sw["entry"])
-    assert idx.build_bound_codes(3) == 2 and idx.memory()["record_size"] == 32
+    assert idx.build_bound_codes(3) == 2 and idx.memory()["record_size"] in (28, 32)
     rng = np.random.default_rng(12)
     x = rng.integers(0, 256, (1500, 128)).astype(np.uint8)
     q = rng.integers(0, 256, (32, 128)).astype(np.uint8)
@@ -456,7 +456,7 @@ def test_mode_3_builds_records_only_where_they_are_expected_to_pay(svs, oracle, 
     assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all() and "codes=0>" in idx.last_kernel_info()
     assert idx.build_bound_codes(2) == 2  # asked for explicitly: built, still result-neutral
     res = idx.search(q, 10, sp)
-    assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all() and "codes=2>" in idx.last_kernel_info()
+    assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all() and re.search(r"codes=[25]>", idx.last_kernel_info())
 
 
 def test_mode_3_times_its_records_on_indexes_large_enough_to_time(svs):
@@ -484,7 +484,7 @@ def test_mode_3_times_its_records_on_indexes_large_enough_to_time(svs):
     ib, db = torch.empty_like(ia), torch.empty_like(da)
     idx.search_device(q, k, sp, d_ids64=ib, d_dists=db)
     torch.cuda.synchronize()
-    assert (ia == ib).all() and (da.view(torch.int32) == db.view(torch.int32)).all() and "codes=2>" in idx.last_kernel_info()
+    assert (ia == ib).all() and (da.view(torch.int32) == db.view(torch.int32)).all() and re.search(r"codes=[25]>", idx.last_kernel_info())
     xf = deep_like_device(n, 128, 32, 31, dev, normalize=False)
     gain = 100.0 / float(xf.abs().max())
     xu = torch.clamp(torch.round(xf * gain + 128), 0, 255).to(torch.uint8)
@@ -502,3 +502,33 @@ def test_mode_3_times_its_records_on_indexes_large_enough_to_time(svs):
     idx.search_device(qu, k, sp, d_ids64=ids1, d_dists=d1)
     torch.cuda.synchronize()
     assert (ids0 == ids1).all() and (d0.view(torch.int32) == d1.view(torch.int32)).all()
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("xdt,qdt", [(np.float32, np.float32), (np.float16, np.float32), (np.float16, np.float16)])
+@pytest.mark.parametrize("d", [96, 128, 100])
+def test_inline_records_of_28_bytes(svs, oracle, metric, xdt, qdt, d):
+    """round 6: the 28-byte record form (a 16- and a 12-byte plane: a 64-slot block is 16 lines instead of 18; 24 / 22 codes) -- static (96, 128)
+    and runtime (100) dimensions, float32 / float16 rows, the three metrics, every buffer level; ids, distance bits and tracker counts equal the
+    oracle, the kernel named is the codes=5 instantiation, wide graphs (two adjacency chunks) included"""
+    x = deep_like(1500, d, 16, seed=d + metric + 3, normalize=False).astype(xdt)
+    q = deep_like(32, d, 16, seed=d + 9, normalize=False).astype(qdt)
+    fn = svs.DistanceL2() if metric == L2 else svs.DistanceIP() if metric == IP else svs.DistanceCosineSimilarity()
+    for R in (24, 100):
+        g, e = oracle.build_vamana(metric, x, R=R, L=max(40, R))
+        idx = svs.VamanaIndex(g, x, fn, e)
+        assert idx.build_bound_codes(28) == 2 and idx.memory()["record_size"] == 28
+        rej = 0
+        for w, c, k, vis in CONFIGS + [(200, 260, 10, 1), (600, 600, 10, 0)]:
+            res, st = idx.search(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(w, c), vis), stats=True)
+            ids, dists, ost = oracle.search(metric, x, g, e, q, k, w, c, visited_set=bool(vis), stats=True)
+            assert (res.indices == _u64(ids)).all(), (metric, R, w, c, k, vis)
+            assert (_bits(res.distances) == _bits(dists)).all(), (metric, R, w, c, k, vis)
+            assert (st[:, :2] == ost[:, :2]).all()
+            assert "codes=5>" in idx.last_kernel_info(), idx.last_kernel_info()
+            rej += int(st[:, 5].sum())
+        assert rej > 500
+    raw = np.clip(np.round(x.astype(np.float32) * 20), -128, 127).astype(np.int8)
+    idx = svs.VamanaIndex(g, raw, fn, e)
+    with pytest.raises(svs.SvsxError):  # the 28-byte form exists for float32 / float16 rows
+        idx.build_bound_codes(28)

@@ -156,7 +156,7 @@ def test_inline_record_instantiations_for_configs_3_and_4(svs, oracle, sift_like
     for qdt in (np.float32, np.float16):
         q = s_["q"].astype(qdt)
         res, st = idx.search(q, 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(128), 1), stats=True)
-        assert idx.last_kernel_info() == "search_kernel<dt=1,metric=1,qmode=0,ds=128,general=0,codes=2>"
+        assert idx.last_kernel_info() in [f"search_kernel<dt=1,metric=1,qmode=0,ds=128,general=0,codes={c}>" for c in (2, 5)]  # 32- or 28-byte records, as the rule decides
         ids, dists, ost = oracle.search(IP, s_["x"], s_["graph"], s_["entry"], q, 10, 128, visited_set=True, stats=True)
         assert (res.indices == ids.astype(np.uint64)).all() and (_bits(res.distances) == _bits(dists)).all()
         assert (st[:, :2] == ost[:, :2]).all() and st[:, 5].sum() > 0.5 * st[:, 2].sum()
@@ -180,7 +180,7 @@ def test_bound_code_instantiations_are_reported(svs, small_world, world128):
             for mode in (1, 2):
                 idx.build_bound_codes(mode)
                 idx.search(w["q"], 10, svs.VamanaSearchParameters(svs.SearchBufferConfig(32)))
-                assert idx.last_kernel_info() == f"search_kernel<dt={ddt},metric=0,qmode=0,ds={d},general=0,codes={mode}>"
+                assert idx.last_kernel_info() in [f"search_kernel<dt={ddt},metric=0,qmode=0,ds={d},general=0,codes={c}>" for c in ((1,) if mode == 1 else (2, 5))]
 
 
 # ---- config 5 on ONE GPU: four shards, global ids beyond 2^32 -------------------------------------------------------------
@@ -397,7 +397,7 @@ def test_config3_full_size_ids_identical_to_reference(svs, ref):
         st = torch.zeros((nq, 6), dtype=torch.int32, device=dev)
         idx.search_device(q, k, svs.VamanaSearchParameters(svs.SearchBufferConfig(window), vis), d_ids64=ids, d_dists=dist, d_stats=st)
         torch.cuda.synchronize()
-        assert idx.last_kernel_info() == f"search_kernel<dt=1,metric=1,qmode=0,ds=128,general=0,codes={mode}>"
+        assert idx.last_kernel_info() in [f"search_kernel<dt=1,metric=1,qmode=0,ds=128,general=0,codes={c}>" for c in ((0,) if mode == 0 else (2, 5))]
         assert (ids.cpu().numpy() == rid.astype(np.int64)).all(), mode
         assert (_bits(dist.cpu().numpy()) == _bits(rd)).all(), mode
         if mode == 2:

@@ -24,7 +24,7 @@ for spec in a.sets.split(","):
     for w in [int(v) for v in a.windows.split(",")]:
         sp = svs.VamanaSearchParameters(svs.SearchBufferConfig(w), 1)
         base = None
-        for mode in (0, 2, 32, 64, 128):
+        for mode in (0, 2, 28, 32, 64, 128):
             idx.build_bound_codes(mode)
             idx.search_device(q, k, sp, d_ids64=ids, d_dists=dd, d_stats=st)
             for _ in range(15): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dd)
