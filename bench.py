@@ -347,7 +347,7 @@ def sharded_c5_point(args, svs, q, k, R, d, rank, world, local_rank, device, reu
     n5 = sharded_shard_size(args, world, total_hbm)
     gs5 = (R + 15) // 16 * 16
     mode5 = args.bound_codes
-    if mode5 == 2 and per * n5 * (d * 4 + gs5 * 4 + gs5 * 36 + 64) > 0.75 * total_hbm - torch.cuda.memory_allocated(device):
+    if mode5 >= 2 and per * n5 * (d * 4 + gs5 * 4 + gs5 * 36 + 64) > 0.75 * total_hbm - torch.cuda.memory_allocated(device):
         mode5 = 1  # the inline records of this GPU's shards do not fit next to their vectors: 128-byte code rows (the same choice `--config c5` makes)
     t0 = time.time()
     keep, indexes = [], []
@@ -794,7 +794,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the multi-GPU code path (RCCL all-gather + merge) even at world size 1")
     ap.add_argument("--visited", type=int, default=1, help="visited filter: 0 off, 1 default size, >=64 explicit LDS entries (result-neutral)")
-    ap.add_argument("--bound-codes", type=int, default=2, help="result-neutral lower-bound rejection: 2 graph-inline records (default), 1 128-B code rows, 0 off")
+    ap.add_argument("--bound-codes", type=int, default=32, help="result-neutral lower-bound rejection: 32 graph-inline records of 32 bytes (default: the headline of rounds 2-6), "
+                    "2 inline records of the size the library's rule picks (28 bytes on this set: other_configs.c2_records_rule), 28 / 64 / 128 that size, 1 128-B code rows, 0 off")
     ap.add_argument("--graph-cache", default="", help="load/save the built graph(s) here (lets a profiler run skip the build)")
     ap.add_argument("--c5-n", type=int, default=0, help="vectors per shard of the sharded_search point (0 = BASELINE config 5's 12 500 000 at every N; -1 = skip the point)")
     ap.add_argument("--sharded-timeout", type=float, default=0.0, help="watchdog of the sharded_search point in seconds (0 = scaled with shards per GPU x shard size); when it fires the line is printed with sharded_search.failed and the run exits 3")
@@ -845,7 +846,7 @@ def main():
     total_hbm = torch.cuda.get_device_properties(device).total_memory
     gstride = (R + 15) // 16 * 16
     mode = args.bound_codes
-    if mode == 2 and local_shards * n * (d * 4 + gstride * 4 + gstride * 36 + 64) > 0.75 * total_hbm:
+    if mode >= 2 and local_shards * n * (d * 4 + gstride * 4 + gstride * 36 + 64) > 0.75 * total_hbm:
         mode = 1  # the graph-inline records of every local shard do not fit next to the vectors: 128-byte code rows instead
         log(f"[bench] rank {rank}: {local_shards} shards x {n} vectors: graph-inline records would not fit, using 128-byte code rows")
     for s in range(local_shards):
@@ -955,7 +956,7 @@ def main():
     ref_alg_bytes = 4 * (exp_total + slots_total) + slots_total * d * 4 + local_shards * nq * (d * 4 + d * 4 + k * 12)
     kinfo = shards[0]["index"].last_kernel_info()  # ...codes=2/3/4> = 32- / 64- / 128-byte inline records
     record_bytes = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128, "codes=5>": 28}.get(kinfo[-8:], 32)
-    lines = designed_lines(stats.to(torch.int64).reshape(-1, 6), gstride, d * 4, mode, d, k, record_bytes)
+    lines = designed_lines(stats.to(torch.int64).reshape(-1, 6), gstride, d * 4, min(mode, 2), d, k, record_bytes)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -1246,7 +1247,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         mk_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in mev]))
-        mlines = designed_lines(mstats.to(torch.int64), gstride, d * 4, mode, d, k, record_bytes)
+        mlines = designed_lines(mstats.to(torch.int64), gstride, d * 4, min(mode, 2), d, k, record_bytes)
         mt, mt_src, _ = measured_traffic(f"{args.config}:n={n}:nq={nq}:window={lo_w}:R={R}:visited={args.visited}:codes={mode}")
         matched = {"window": lo_w, "recall_at_10": recall_at(gt, ids, k), "gpu_qps": nq * args.steps / dt, "kernel_ms": mk_ms,
                    "designed_lines_per_query": mlines["total"] / nq, "achieved_GBs": mlines["total"] * LINE / (mk_ms * 1e-3) / 1e9,
@@ -1273,13 +1274,66 @@ def main():
                 b_.record()
             torch.cuda.synchronize()
             ms4 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in e4]))
-            l4 = designed_lines(st4.to(torch.int64), gstride, d * 4, mode, d, k, record_bytes)
+            l4 = designed_lines(st4.to(torch.int64), gstride, d * 4, min(mode, 2), d, k, record_bytes)
             result["config"]["batch_x4"] = {"queries": nq4, "kernel_ms": ms4, "qps": nq4 / (ms4 * 1e-3), "designed_lines_per_query": l4["total"] / nq4,
                                             "achieved_GBs": l4["total"] * LINE / (ms4 * 1e-3) / 1e9, "frac": l4["total"] * LINE / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                             "note": "not the headline batch; shows the per-launch ramp/drain share of the 10 000-query figure"}
             del q4, ids4, dists4, st4
         except Exception as e:
             log(f"[bench] 4x batch point skipped: {e}")
+        if not args.no_extras and mode >= 2:
+            try:  # the same index with the record size the LIBRARY's rule picks (mode 2): on this set the 28-byte form of round 6 -- fewer lines, more QPS
+                index.build_bound_codes(0)  # (mode 2 keeps records that exist, whatever their size)
+                index.build_bound_codes(2)
+                strule = torch.zeros((nq, 6), dtype=torch.int32, device=device)
+                idsr = torch.empty((nq, k), dtype=torch.int64, device=device)
+                index.search_device(q, k, sp, d_ids64=idsr, d_dists=dists, d_stats=strule)
+                for _ in range(max(args.warmup, 12)):
+                    index.search_device(q, k, sp, d_ids64=idsr, d_dists=dists)
+                torch.cuda.synchronize()
+                evr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                t0 = time.perf_counter()
+                for a_, b_ in evr:
+                    a_.record()
+                    index.search_device(q, k, sp, d_ids64=idsr, d_dists=dists)
+                    b_.record()
+                torch.cuda.synchronize()
+                dtr = time.perf_counter() - t0
+                msr = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evr]))
+                rbr = int(index.memory()["record_size"])
+                lr = designed_lines(strule.to(torch.int64), gstride, d * 4, 2, d, k, rbr)
+                tr, tr_src, _ = measured_traffic(f"{args.config}:n={n}:nq={nq}:window={args.window}:R={R}:visited={args.visited}:codes=2")
+                index.search_device(q, k, sp_m, d_ids64=idsr, d_dists=dists)
+                for _ in range(max(args.warmup, 12)):
+                    index.search_device(q, k, sp_m, d_ids64=idsr, d_dists=dists)
+                torch.cuda.synchronize()
+                evm = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                for a_, b_ in evm:
+                    a_.record()
+                    index.search_device(q, k, sp_m, d_ids64=idsr, d_dists=dists)
+                    b_.record()
+                torch.cuda.synchronize()
+                msm = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evm]))
+                tm, tm_src, _ = measured_traffic(f"{args.config}:n={n}:nq={nq}:window={matched['window']}:R={R}:visited={args.visited}:codes=2")
+                result["config"].setdefault("other_configs", {})["c2_records_rule"] = {
+                    "what": "the headline's index, batch and window with the record size svsx_index_build_bound_codes(index, 2) picks by itself instead of the 32 bytes the headline "
+                            "has used since round 2: fewer lines per expansion, so MORE queries per second at a LOWER fraction of the bandwidth roof",
+                    "record_bytes": rbr, "kernel": "svsx::" + index.last_kernel_info(), "qps": nq * args.steps / dtr, "kernel_ms": msr,
+                    "ids_equal_headline": None,
+                    "designed_lines_per_query": lr["total"] / nq, "bound_code_rejects_per_query": int(strule[:, 5].sum()) / nq,
+                    "traffic": tr, "traffic_source": tr_src, "frac_traffic": (tr / (msr * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
+                    "matched_window": {"window": matched["window"], "kernel_ms": msm, "qps": nq / (msm * 1e-3), "traffic": tm, "traffic_source": tm_src,
+                                       "frac_traffic": (tm / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS) if tm else None}}
+                index.search_device(q, k, sp, d_ids64=idsr, d_dists=dists)
+                torch.cuda.synchronize()
+                index.build_bound_codes(0)
+                index.build_bound_codes(mode)
+                index.search_device(q, k, sp, d_ids64=ids, d_dists=dists)
+                torch.cuda.synchronize()
+                result["config"]["other_configs"]["c2_records_rule"]["ids_equal_headline"] = bool((idsr == ids).all())
+            except Exception as e:  # informational: never fail the line over it
+                result["config"].setdefault("other_configs", {})["c2_records_rule"] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"[bench] rule-sized records point failed: {e}")
         if not args.no_extras:
             try:
                 head = {"generator": "G(24, 0.1), unit norm (the headline's set)", "qps": result["value"], "kernel_ms": kern_ms, "recall_at_10": recall,

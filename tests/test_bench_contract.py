@@ -50,7 +50,7 @@ def test_pmc_summaries_are_stamped_and_consistent():
     bytes of the same launches (no wasted re-reads), and the kernel trace of the profiled process agrees with that process's own HIP-event time
     (within 5 %: the tracer adds ~10-30 us per dispatch, 3 % of a 0.31 ms launch)"""
     shas = set()
-    for tag in ("r06_c2_w128", "r06_c2_matched", "r06_c5shard", "r06_c3_w128", "r06_c4_10M", "r06_c4b_10M"):
+    for tag in ("r06_c2_w128_rb32", "r06_c2_matched_rb32", "r06_c2_w128", "r06_c2_matched", "r06_c5shard", "r06_c3_w128", "r06_c4_10M", "r06_c4b_10M"):
         j = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
         assert len(j["kernel_src_sha"]) == 16 and j["workload_key"].count(":") >= 6
         shas.add(j["kernel_src_sha"])

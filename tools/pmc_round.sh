@@ -8,6 +8,8 @@ P=$1; shift
 T=${*:-"c2 c2m c3 c4 c5"}
 for t in $T; do
   case $t in
+    c2rb32) tools/collect_pmc.sh ${P}_c2_w128_rb32 --n 1000000 --window 128 --codes 32 ;;
+    c2mrb32) tools/collect_pmc.sh ${P}_c2_matched_rb32 --n 1000000 --window 128 --codes 32 --matched ;;
     c2) tools/collect_pmc.sh ${P}_c2_w128 --n 1000000 --window 128 --codes 2 ;;
     c2m) tools/collect_pmc.sh ${P}_c2_matched --n 1000000 --window 128 --codes 2 --matched ;;
     c3) tools/collect_pmc.sh ${P}_c3_w128 --config c3 --n 1000000 --window 128 --codes 2 ;;

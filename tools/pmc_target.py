@@ -79,7 +79,7 @@ e0.record()
 for _ in range(a.launches): idx.search_device(q, k, sp, d_ids64=ids, d_dists=dist)
 e1.record(); torch.cuda.synchronize()
 rb = {"codes=2>": 32, "codes=3>": 64, "codes=4>": 128, "codes=5>": 28}.get(idx.last_kernel_info()[-8:], 32)
-lines = designed_lines(stats.to(torch.int64), (R + 15) // 16 * 16, x.shape[1] * x.element_size(), a.codes, d, k, rb)
+lines = designed_lines(stats.to(torch.int64), (R + 15) // 16 * 16, x.shape[1] * x.element_size(), min(a.codes, 2), d, k, rb)
 print(json.dumps({"workload_key": f"{a.config}:n={a.n}:nq={a.nq}:window={window}:R={R}:visited={a.visited}:codes={a.codes}", "kernel_src_sha": kernel_src_sha(),
                   "window": window, "launches": a.launches, "designed_lines_per_launch": lines, "designed_bytes_per_launch": lines["total"] * LINE,
                   "kernel_ms_unprofiled_or_profiled": e0.elapsed_time(e1) / a.launches, "kernel_ms_hip_events_this_process": e0.elapsed_time(e1) / a.launches, "kernel": idx.last_kernel_info(),
